@@ -1,0 +1,177 @@
+/*
+ * viprs_hip.h -- C ABI of libviprs_hip.so: the MI355X (gfx950) implementation of viprs's
+ * coordinate-ascent variational E-step over LD-matrix blocks.
+ *
+ * This header is the drop-in boundary.  Every entry point names the reference interface it
+ * replaces (paths relative to the shz9/viprs tree, v0.1.4):
+ *
+ *   reference (Cython -> C++ templates)                         this library
+ *   ----------------------------------------------------------  -------------------------------
+ *   e_step_cpp.pyx:91-122   cpp_e_step          -> e_step.hpp:343-442   viprs_e_step
+ *   e_step_cpp.pyx:125-159  cpp_e_step_mixture  -> e_step.hpp:447-551   viprs_e_step_mixture
+ *   e_step_cpp.pyx:161-195  cpp_e_step_grid     -> e_step.hpp:555-647   viprs_e_step_grid
+ *   e_step_cpp.pyx:71-76    check_blas_support / check_omp_support      viprs_check_*_support
+ *   VIPRS.py:151-172        "load LD matrices to memory" (VIPRS.__init__) viprs_plan_create
+ *   VIPRS.py:393-422        per-chromosome loop in VIPRS.e_step()       viprs_state_* (resident)
+ *
+ * Conventions
+ *   - plain pointers + sizes + dtype codes; no C++/torch types cross this boundary;
+ *   - every function returns 0 on success, a negative VIPRS_E* code otherwise;
+ *     viprs_last_error() returns a thread-local message for the last failure;
+ *   - host buffers stay caller-owned; device mirrors are owned by the opaque handles;
+ *   - results always follow the reference's `threads = 1` (exact serial Gauss-Seidel)
+ *     semantics; the `threads` argument is accepted for signature parity and ignored
+ *     (the reference's threads > 1 path is a racy Hogwild loop, e_step.hpp:384-387).
+ */
+#ifndef VIPRS_HIP_H
+#define VIPRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dtype codes (mirror the Cython fused types, e_step_cpp.pxd:7-17) ------------------- */
+enum viprs_float_dtype { VIPRS_F32 = 0, VIPRS_F64 = 1 };               /* `floating`          */
+enum viprs_ld_dtype {                                                   /* noncomplex_numeric  */
+    VIPRS_LD_I8 = 0, VIPRS_LD_I16 = 1, VIPRS_LD_I32 = 2, VIPRS_LD_I64 = 3,
+    VIPRS_LD_F32 = 4, VIPRS_LD_F64 = 5
+};
+enum viprs_indptr_dtype { VIPRS_IP_I32 = 0, VIPRS_IP_I64 = 1 };        /* indptr_type         */
+
+/* ---- status codes ----------------------------------------------------------------------- */
+enum viprs_status {
+    VIPRS_OK = 0,
+    VIPRS_EINVAL = -1,     /* bad argument / dtype code                                        */
+    VIPRS_ELAYOUT = -2,    /* LD index arrays violate the contiguous-window contract            */
+    VIPRS_EDEVICE = -3,    /* HIP runtime error (message in viprs_last_error)                   */
+    VIPRS_ENOMEM = -4,
+    VIPRS_EUNSUPPORTED = -5
+};
+
+/* ---- E-step numerics mode ---------------------------------------------------------------- */
+enum viprs_math_mode {
+    /* Bit-for-bit the reference's arithmetic (glibc-2.35 expf reproduced in double on the
+     * device, sigmoid divide in double as e_step.hpp:254-260 does).  Default.                 */
+    VIPRS_MATH_EXACT = 0,
+    /* Hardware v_exp_f32 / v_rcp_f32 sigmoid (<= 2 ulp from EXACT per evaluation; well inside
+     * the 1e-5 relative parity tolerance).  Shorter serial chain per SNP.                     */
+    VIPRS_MATH_FAST = 1
+};
+
+/* ---- block kinds reported by the planner ------------------------------------------------- */
+enum viprs_block_kind {
+    VIPRS_BLOCK_DENSE_SYM = 0,    /* every row's window == the whole block (symmetric form)    */
+    VIPRS_BLOCK_DENSE_UPPER = 1,  /* row j's window == (j, block_end)      (upper-tri form)    */
+    VIPRS_BLOCK_RAGGED = 2        /* anything else (banded / thresholded windows)              */
+};
+
+typedef struct viprs_plan viprs_plan;     /* device-resident LD + block schedule               */
+typedef struct viprs_state viprs_state;   /* device-resident variational state bound to a plan */
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char* viprs_last_error(void);
+const char* viprs_version(void);
+int viprs_device_count(int* count);
+/* Mirrors check_blas_support() / check_omp_support() (e_step_cpp.pyx:71-76): neither BLAS
+ * nor OpenMP is involved on the device path, both report 0.                                   */
+int viprs_check_blas_support(void);
+int viprs_check_omp_support(void);
+
+/* ---- planner (pure host code; usable without a GPU) -------------------------------------- */
+/* Validates the LD index arrays (bit-exact integer checks: indptr[0] == 0, indptr monotone,
+ * 0 <= left_bound[j], left_bound[j] + len_j <= m; symmetric form: window contains j;
+ * upper form: left_bound[j] == j + 1) and partitions SNPs 0..m-1 into independent LD blocks
+ * (= connected components of the row windows; the reference has no explicit block loop,
+ * independence is implicit in (left_bound, indptr): e_step.hpp:389-392).
+ *
+ *   block_start  out, capacity m + 1: block b covers SNPs [block_start[b], block_start[b+1])
+ *   block_kind   out, capacity m (may be NULL)
+ */
+int viprs_plan_blocks(int64_t m, const int32_t* ld_left_bound, const void* ld_indptr,
+                      int indptr_dtype, int low_memory, int64_t* n_blocks, int64_t* block_start,
+                      int32_t* block_kind);
+
+/* ---- plan: upload LD once (replaces "load LD to memory", VIPRS.py:151-172) ---------------- */
+int viprs_plan_create(viprs_plan** plan, int64_t m, const int32_t* ld_left_bound,
+                      const void* ld_indptr, int indptr_dtype, const void* ld_data, int ld_dtype,
+                      int low_memory, int device);
+int viprs_plan_destroy(viprs_plan* plan);
+
+enum viprs_plan_info_key {
+    VIPRS_INFO_M = 0, VIPRS_INFO_NNZ = 1, VIPRS_INFO_N_BLOCKS = 2, VIPRS_INFO_N_DENSE = 3,
+    VIPRS_INFO_N_RAGGED = 4, VIPRS_INFO_MAX_BLOCK = 5, VIPRS_INFO_LD_BYTES_DEVICE = 6,
+    VIPRS_INFO_LD_ELEM_SIZE = 7, VIPRS_INFO_DEVICE = 8, VIPRS_INFO_LOW_MEMORY = 9,
+    VIPRS_INFO_N_CU = 10
+};
+int viprs_plan_info(const viprs_plan* plan, int key, int64_t* value);
+/* Copies the planner's block boundaries (n_blocks + 1 entries) */
+int viprs_plan_get_blocks(const viprs_plan* plan, int64_t* block_start, int32_t* block_kind);
+int viprs_plan_set_math_mode(viprs_plan* plan, int math_mode);
+
+/* ---- one-shot calls on host buffers: the drop-ins for the Cython entry points ------------ */
+/* Argument order and meaning follow e_step_cpp.pyx:91-122 after the plan handle (which stands
+ * for ld_left_bound / ld_indptr / ld_data).  var_gamma, var_mu, eta, q, eta_diff are updated
+ * in place exactly as e_step.hpp:343-442 does; all float buffers share `float_dtype`.         */
+int viprs_e_step(viprs_plan* plan, int float_dtype, const void* std_beta, void* var_gamma,
+                 void* var_mu, void* eta, void* q, void* eta_diff, const void* u_logs,
+                 const void* sqrt_half_var_tau, const void* mu_mult, double dq_scale, int threads,
+                 int low_memory);
+
+/* e_step_cpp.pyx:125-159: (m, K) arrays are C-ordered.                                        */
+int viprs_e_step_mixture(viprs_plan* plan, int float_dtype, int K, const void* std_beta,
+                         void* var_gamma, void* var_mu, void* eta, void* q, void* eta_diff,
+                         const void* log_null_pi, const void* u_logs,
+                         const void* sqrt_half_var_tau, const void* mu_mult, double dq_scale,
+                         int threads, int low_memory);
+
+/* e_step_cpp.pyx:161-195: (m, G) arrays are column-major; active_model_idx is contiguous here
+ * (the ctypes shim gathers a strided int[:]).                                                 */
+int viprs_e_step_grid(viprs_plan* plan, int float_dtype, int G, const void* std_beta,
+                      void* var_gamma, void* var_mu, void* eta, void* q, void* eta_diff,
+                      const void* u_logs, const void* half_var_tau, const void* mu_mult,
+                      double dq_scale, const int32_t* active_model_idx, int n_active, int threads,
+                      int low_memory);
+
+/* ---- device-resident state: what VIPRS.e_step()'s per-iteration loop keeps alive --------- */
+enum viprs_model_kind { VIPRS_MODEL_SPIKE_SLAB = 0, VIPRS_MODEL_MIXTURE = 1, VIPRS_MODEL_GRID = 2 };
+
+enum viprs_field {
+    /* inputs */
+    VIPRS_FIELD_STD_BETA = 0, VIPRS_FIELD_U_LOGS = 1, VIPRS_FIELD_SQRT_HALF_VAR_TAU = 2,
+    VIPRS_FIELD_MU_MULT = 3, VIPRS_FIELD_LOG_NULL_PI = 4,
+    /* in/out state */
+    VIPRS_FIELD_VAR_GAMMA = 5, VIPRS_FIELD_VAR_MU = 6, VIPRS_FIELD_ETA = 7, VIPRS_FIELD_Q = 8,
+    VIPRS_FIELD_ETA_DIFF = 9,
+    VIPRS_FIELD_COUNT = 10
+};
+
+/* `width` = 1 (spike-and-slab), K (mixture) or G (grid).                                      */
+int viprs_state_create(viprs_state** state, viprs_plan* plan, int float_dtype, int model_kind,
+                       int width);
+int viprs_state_destroy(viprs_state* state);
+/* Whole-field copies; sizes follow the reference shapes ((m,), (m,K) C-order, (m,G) F-order).  */
+int viprs_state_upload(viprs_state* state, int field, const void* host);
+int viprs_state_download(viprs_state* state, int field, void* host);
+/* Device-side re-initialisation to the reference's standard start (VIPRS.py:344-358):
+ * var_gamma = pi, var_mu = eta = q = eta_diff = 0.                                            */
+int viprs_state_reset(viprs_state* state, double pi);
+/* One E-step sweep over every LD block with the resident inputs; asynchronous on the plan's
+ * stream unless `sync` != 0.                                                                  */
+int viprs_state_e_step(viprs_state* state, double dq_scale, const int32_t* active_model_idx,
+                       int n_active, int sync);
+int viprs_state_synchronize(viprs_state* state);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------------- */
+/* HIP-event time (ms) of the kernels of the last viprs_state_e_step / viprs_e_step* call on
+ * this plan, measured on the stream they were launched on.  `which`: 0 = all kernels of the
+ * sweep, 1 = dominant (panel) kernel only.                                                    */
+int viprs_plan_last_kernel_ms(viprs_plan* plan, int which, double* ms);
+/* Number of SNPs of the last sweep that took the skip branch (e_step.hpp:410-413).            */
+int viprs_plan_last_skipped(viprs_plan* plan, int64_t* n_skipped);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIPRS_HIP_H */

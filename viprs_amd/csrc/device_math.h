@@ -1,0 +1,155 @@
+// Device-side scalar math of the per-SNP posterior update, written so that every IEEE operation
+// matches the reference's C++ (e_step.hpp) operation for operation.  Build with
+// -ffp-contract=off: fma is used exactly where the reference calls std::fma and nowhere else.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace viprs {
+
+// ---------------------------------------------------------------------------------------------
+// expf, bit-identical to the host libm the reference links against (glibc 2.35,
+// sysdeps/ieee754/flt-32/e_expf.c, the FMA ifunc variant selected on every x86-64 CPU with FMA).
+// glibc evaluates expf in double: k = round(x * 32/ln2), r = x*32/ln2 - k (contracted to one
+// fma), 2^(k/32) from a 32-entry table, a cubic in r, one final rounding to float.  Those are
+// exactly-specified IEEE double operations, so executing the same sequence on the device yields
+// the same bits.  oracle/estep_oracle.c holds the same model; tests sweep it against expf() over
+// all 2.2e9 floats in [-104, 88.7] (0 mismatches) and the device copy against it on the GPU.
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ const uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+// The table spread over the lanes of a wave (lane l holds entry l & 31), so a lookup is two
+// v_readlane (wave-uniform index) or two ds_bpermute (per-lane index) instead of a memory load
+// on the serial chain.
+struct ExpTab {
+    int lo, hi;
+    __device__ __forceinline__ void init() {
+        const uint64_t t = kExp2fTab[threadIdx.x & 31];
+        lo = (int)(uint32_t)t;
+        hi = (int)(uint32_t)(t >> 32);
+    }
+};
+
+// Polynomial + scaling shared by both lookup flavours.  `t` = table bits + (k << 47).
+__device__ __forceinline__ float expf_glibc_finish(double r, uint64_t t) {
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double s = __longlong_as_double((long long)t);
+    const double zz = fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = fma(C2, r, 1.0);
+    y = fma(zz, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+// x <= 0 is all the E-step needs (sigmoid / softmax arguments are -|x| or u - max(u)).
+// UNIFORM: every lane of the wave passes the same x (the serial chain is computed redundantly
+// by all 64 lanes), so the table index is wave-uniform.
+template <bool UNIFORM>
+__device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+    if (x < -104.0f) return 0.0f;  // glibc: __math_uflowf below -0x1.9fe368p6; (float)y is 0 here
+    const double xd = (double)x;
+    const double z = InvLn2N * xd;
+    const double kd = rint(z);                 // == (z + 0x1.8p52) - 0x1.8p52 in round-to-nearest
+    const double r = fma(InvLn2N, xd, -kd);
+    const int ki = (int)kd;                    // |kd| < 2^13
+    const int idx = ki & 31;
+    int tlo, thi;
+    if (UNIFORM) {
+        const int sidx = __builtin_amdgcn_readfirstlane(idx);
+        tlo = __builtin_amdgcn_readlane(tab.lo, sidx);
+        thi = __builtin_amdgcn_readlane(tab.hi, sidx);
+    } else {
+        tlo = __builtin_amdgcn_ds_bpermute(idx << 2, tab.lo);
+        thi = __builtin_amdgcn_ds_bpermute(idx << 2, tab.hi);
+    }
+    // t = tab + (ki << 47): only the high word changes (ki << 15), two's complement wraps as
+    // the 64-bit add in glibc does (tab low word is untouched: 47 >= 32).
+    thi += (int)((unsigned)ki << 15);
+    const uint64_t t = ((uint64_t)(uint32_t)thi << 32) | (uint32_t)tlo;
+    return expf_glibc_finish(r, t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sigmoid<T> (e_step.hpp:245-261).  With T = float the literal `1.` there is a double, so the add
+// and the divide happen in double and the quotient is rounded to float once.
+// ---------------------------------------------------------------------------------------------
+template <bool UNIFORM>
+__device__ __forceinline__ float sigmoid_exact(float x, const ExpTab& tab) {
+    const float e = expf_glibc_nonpos<UNIFORM>(-fabsf(x), tab);
+    const double ed = (double)e;
+    const double num = (x < 0.0f) ? ed : 1.0;
+    return (float)(num / (1.0 + ed));
+}
+
+// Hardware-transcendental variant (VIPRS_MATH_FAST): v_exp_f32 with a compensated x*log2(e)
+// product and v_rcp_f32; a few ulp from sigmoid_exact.
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    const float t = -fabsf(x);
+    const float L_hi = 0x1.715476p+0f;         // log2(e) rounded to float
+    const float L_lo = 0x1.4ae0cp-26f;         // log2(e) - L_hi
+    const float p = t * L_hi;
+    const float perr = __builtin_fmaf(t, L_lo, __builtin_fmaf(t, L_hi, -p));
+    const float e0 = __builtin_amdgcn_exp2f(p);
+    const float e = __builtin_fmaf(e0 * 0x1.62e43p-1f, perr, e0);
+    const float num = (x < 0.0f) ? e : 1.0f;
+    return num * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// double state (float_precision='float64'): ocml exp (<= 1 ulp, not bit-identical to glibc exp).
+__device__ __forceinline__ double sigmoid_f64(double x) {
+    const double e = exp(-fabs(x));
+    const double num = (x < 0.0) ? e : 1.0;
+    return num / (1.0 + e);
+}
+
+template <typename T> struct Eps;
+template <> struct Eps<float> { static constexpr float value = 1.1920928955078125e-07f; };   // max(FLT_EPSILON, 1e-8f)
+template <> struct Eps<double> { static constexpr double value = 1e-8; };                     // max(DBL_EPSILON, 1e-8)
+
+template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c);
+template <> __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename T> __device__ __forceinline__ T abs_t(T a);
+template <> __device__ __forceinline__ float abs_t<float>(float a) { return fabsf(a); }
+template <> __device__ __forceinline__ double abs_t<double>(double a) { return fabs(a); }
+
+// One spike-and-slab posterior update (e_step.hpp:401-408) from the current q_j.
+//   mu = fma(mm, beta, -(mm*q)); u = s*mu; gamma = sigmoid(fma(u,u,ulog)); d = fma(gamma, mu, -eta)
+template <bool EXACT, bool UNIFORM>
+__device__ __forceinline__ void snp_update(float mm, float beta, float s, float ulog, float eta_old,
+                                           float qj, const ExpTab& tab, float& mu, float& gamma,
+                                           float& d) {
+    const float p = mm * qj;
+    mu = __builtin_fmaf(mm, beta, -p);
+    const float u = s * mu;
+    const float x = __builtin_fmaf(u, u, ulog);
+    gamma = EXACT ? sigmoid_exact<UNIFORM>(x, tab) : sigmoid_fast(x);
+    d = __builtin_fmaf(gamma, mu, -eta_old);
+}
+
+template <bool EXACT, bool UNIFORM>
+__device__ __forceinline__ void snp_update(double mm, double beta, double s, double ulog,
+                                           double eta_old, double qj, const ExpTab&, double& mu,
+                                           double& gamma, double& d) {
+    const double p = mm * qj;
+    mu = __builtin_fma(mm, beta, -p);
+    const double u = s * mu;
+    const double x = __builtin_fma(u, u, ulog);
+    gamma = sigmoid_f64(x);
+    d = __builtin_fma(gamma, mu, -eta_old);
+}
+
+}  // namespace viprs

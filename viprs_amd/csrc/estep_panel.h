@@ -1,0 +1,274 @@
+// Panel kernel for dense LD blocks (spike-and-slab, T = float): the MI355X hot path.
+//
+// One workgroup owns one LD block; blocks are pulled from a work queue in descending cost order
+// by persistent workgroups.  The serial Gauss-Seidel sweep of e_step<T,U,I>
+// (e_step.hpp:387-433) is re-blocked into panels of 64 SNPs (= one wavefront) without changing
+// a single floating-point operation or its order per q-entry:
+//
+//   wave 0 ("chain")     for panel p: q_p  <- LDS; apply a_{p-1} through the 64x64 tile
+//                        R[p-1, p] (64 ordered fma per lane); then the 64 serial SNP updates
+//                        against the diagonal tile R[p, p] -- every lane computes the scalar
+//                        chain redundantly, lane i owns q[p*64 + i], the diagonal-tile rows are
+//                        streamed from HBM 16 rows ahead of their use.
+//   waves 1.. ("updaters") while the chain solves panel p they apply a_{p-1} -- the trailing
+//                        rank-64 update -- to every other column of the block: each lane owns 4
+//                        columns, walks the 64 rows of panel p-1 in order (one coalesced 16-byte
+//                        load per lane per row) and performs q[c] = fma(R[j][c], a_j, q[c]);
+//                        they also stage tile R[p, p+1] into LDS for the chain's next phase.
+//
+// Per q-entry the sequence of fma operations is exactly the reference's (row j before row j+1),
+// so with VIPRS_MATH_EXACT the block's outputs are bit-identical to e_step.hpp in symmetric mode.
+// In upper-triangular mode (low_memory) only columns right of the diagonal are touched here and
+// the reference's second pass (update_q_factor, e_step.hpp:331-337) runs as its own fully
+// parallel kernel (estep_upper_epilogue_kernel below).
+#pragma once
+#include "device_math.h"
+#include "kernels_common.h"
+
+namespace viprs {
+
+// ---- 4-element row loads, converted with static_cast<float> as e_step.hpp:173 does ----------
+template <typename U> __device__ __forceinline__ float4 load4(const U* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+}
+template <> __device__ __forceinline__ float4 load4<int8_t>(const int8_t* p) {
+    const int w = *reinterpret_cast<const int*>(p);
+    return make_float4((float)(int8_t)(w), (float)(int8_t)(w >> 8), (float)(int8_t)(w >> 16),
+                       (float)(int8_t)(w >> 24));
+}
+template <> __device__ __forceinline__ float4 load4<int16_t>(const int16_t* p) {
+    const int2 w = *reinterpret_cast<const int2*>(p);
+    return make_float4((float)(int16_t)(w.x), (float)(int16_t)(w.x >> 16), (float)(int16_t)(w.y),
+                       (float)(int16_t)(w.y >> 16));
+}
+
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
+constexpr int kStripPrefetch = 8;    // row loads in flight per updater lane
+
+// LDS carve (floats): q[qcap] | a[2][64] | T[2][64*64]
+__host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
+
+// Trailing update of one 256-column strip by one wave: q[c..c+3] = fma(R[row][c..c+3], a_row, .)
+// for the `nrows` rows of a panel, in row order.
+template <typename U>
+__device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int nrows, float avec,
+                                             float* __restrict__ lq_c) {
+    float4 qv = *reinterpret_cast<float4*>(lq_c);
+    float4 buf[kStripPrefetch];
+#pragma unroll
+    for (int k = 0; k < kStripPrefetch; ++k)
+        if (k < nrows) buf[k] = load4<U>(rowp + (int64_t)k * stride);
+#pragma unroll
+    for (int k = 0; k < kPanel; ++k) {
+        if (k < nrows) {
+            const float4 v = buf[k % kStripPrefetch];
+            if (k + kStripPrefetch < kPanel && k + kStripPrefetch < nrows)
+                buf[k % kStripPrefetch] = load4<U>(rowp + (int64_t)(k + kStripPrefetch) * stride);
+            const float a = rl(avec, k);
+            qv.x = __builtin_fmaf(v.x, a, qv.x);
+            qv.y = __builtin_fmaf(v.y, a, qv.y);
+            qv.z = __builtin_fmaf(v.z, a, qv.z);
+            qv.w = __builtin_fmaf(v.w, a, qv.w);
+        }
+    }
+    *reinterpret_cast<float4*>(lq_c) = qv;
+}
+
+template <typename U, bool UPPER, bool EXACT, int NW>
+__global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A, int qcap) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lq = smem;
+    float* la = smem + qcap;
+    float* lT = la + 2 * kPanel;
+    __shared__ int s_blk;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    ExpTab tab;
+    tab.init();
+    unsigned long long my_skipped = 0;
+    const float eps = Eps<float>::value;
+
+    for (;;) {
+        if (tid == 0) s_blk = atomicAdd(A.counter, 1);
+        __syncthreads();
+        const int blk = s_blk;
+        __syncthreads();
+        if (blk >= A.n_blocks) break;
+
+        const BlockDesc bd = A.blocks[blk];
+        const int64_t s0 = bd.start;
+        const int b = bd.size;
+        const int stride = bd.stride;
+        const U* __restrict__ base = ldd + bd.ld_off;
+        const int np = (b + kPanel - 1) / kPanel;
+        const int bpad = np * kPanel;
+
+        for (int i = tid; i < bpad + kStrip; i += NW * 64) lq[i] = (i < b) ? A.q[s0 + i] : 0.0f;
+        __syncthreads();
+
+        float a_prev = 0.0f;   // chain wave: lane j = dq * eta_diff of SNP j of the previous panel
+
+        for (int p = 0; p <= np; ++p) {
+            if (wave == 0) {
+                // ================================ chain ======================================
+                if (p < np) {
+                    const int r0 = p * kPanel;
+                    const int nrows = min(kPanel, b - r0);
+                    const int64_t j = s0 + r0 + lane;
+                    const bool live = lane < nrows;
+                    const float mm = live ? A.mu_mult[j] : 0.0f;
+                    const float beta = live ? A.std_beta[j] : 0.0f;
+                    const float sv = live ? A.shvt[j] : 0.0f;
+                    const float ulog = live ? A.u_logs[j] : 0.0f;
+                    const float eta_old = live ? A.eta[j] : 0.0f;
+
+                    // diagonal tile rows, streamed kChainPrefetch rows ahead
+                    const U* __restrict__ dptr = base + (int64_t)r0 * stride + r0 + lane;
+                    float drow[kPanel];
+#pragma unroll
+                    for (int k = 0; k < kChainPrefetch; ++k)
+                        if (k < nrows) drow[k] = static_cast<float>(dptr[(int64_t)k * stride]);
+
+                    float qc = lq[r0 + lane];
+                    if (p > 0) {
+                        // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
+                        const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
+#pragma unroll
+                        for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
+                    }
+
+                    float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
+#pragma unroll
+                    for (int jj = 0; jj < kPanel; ++jj) {
+                        if (jj < nrows) {
+                            if (jj + kChainPrefetch < kPanel && jj + kChainPrefetch < nrows)
+                                drow[jj + kChainPrefetch] =
+                                    static_cast<float>(dptr[(int64_t)(jj + kChainPrefetch) * stride]);
+                            const float qj = rl(qc, jj);
+                            float mu, gamma, d;
+                            snp_update<EXACT, true>(rl(mm, jj), rl(beta, jj), rl(sv, jj), rl(ulog, jj),
+                                                    rl(eta_old, jj), qj, tab, mu, gamma, d);
+                            const bool skip = fabsf(d) < eps;
+                            const float a = skip ? 0.0f : A.dq * d;
+                            qc = __builtin_fmaf(drow[jj], a, qc);
+                            if (!UPPER) qc = (lane == jj && !skip) ? qc - d : qc;
+                            qcap_v = (lane == jj) ? qj : qcap_v;
+                        }
+                    }
+
+                    // lane-parallel replay of the 64 updates (same operations, same inputs ->
+                    // same bits) to produce the per-SNP outputs without serialising the stores
+                    float mu, gamma, d;
+                    snp_update<EXACT, false>(mm, beta, sv, ulog, eta_old, qcap_v, tab, mu, gamma, d);
+                    const bool skip = fabsf(d) < eps;
+                    if (live) {
+                        if (!skip) {
+                            A.var_mu[j] = mu;
+                            A.var_gamma[j] = gamma;
+                            A.eta_diff[j] = d;
+                            A.eta[j] = eta_old + d;
+                        } else {
+                            A.eta_diff[j] = 0.0f;
+                        }
+                    }
+                    my_skipped += __popcll(__ballot(live && skip));
+                    a_prev = (live && !skip) ? A.dq * d : 0.0f;
+                    la[(p & 1) * kPanel + lane] = a_prev;
+                    lq[r0 + lane] = qc;
+                }
+            } else {
+                // ================================ updaters ===================================
+                const int uw = wave - 1;
+                // stage tile R[p, p+1] for the chain's next phase
+                if (p + 1 < np) {
+                    float* __restrict__ T = lT + ((p + 1) & 1) * kPanel * kPanel;
+                    const int trow = lane >> 4, tcol = (lane & 15) * 4;
+                    for (int i = uw; i < kPanel / 4; i += NW - 1) {
+                        const int row = 4 * i + trow;
+                        const float4 v = load4<U>(base + (int64_t)(p * kPanel + row) * stride + (p + 1) * kPanel + tcol);
+                        *reinterpret_cast<float4*>(T + row * kPanel + tcol) = v;
+                    }
+                }
+                if (p > 0) {
+                    const int pp = p - 1;                       // panel whose a-vector is applied
+                    const int rr0 = pp * kPanel;
+                    const int nrows = min(kPanel, b - rr0);
+                    const float avec = la[(pp & 1) * kPanel + lane];
+                    if (__ballot(avec != 0.0f)) {
+                        const int nstrips = (bpad + kStrip - 1) / kStrip;
+                        for (int s = uw; s < nstrips; s += NW - 1) {
+                            const int c = s * kStrip + 4 * lane;
+                            const int cp = c >> 6;
+                            bool active = (c < b) && (cp != pp) && (cp != p);
+                            if (UPPER) active = active && (cp > p);
+                            if (active)
+                                strip_update<U>(base + (int64_t)rr0 * stride + c, stride, nrows, avec, lq + c);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < b; i += NW * 64) A.q[s0 + i] = lq[i];
+        __syncthreads();
+    }
+    if (lane == 0 && my_skipped) atomicAdd(A.skipped, my_skipped);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Upper-triangular second pass (update_q_factor, e_step.hpp:331-337):
+//     q[j] += dq * dot(eta_diff[j+1 .. end), R[j, j+1 .. end))
+// with the dot a serial fma chain from 0 in column order (e_step.hpp:100-102).  One wave owns 64
+// rows; 64x64 tiles are loaded row-wise (coalesced), transposed through LDS so that lane r walks
+// row r in column order.  Lower-left entries of the repacked block are zero (exactly neutral).
+// ---------------------------------------------------------------------------------------------
+struct EpiItem { int32_t blk; int32_t row0; };
+
+template <typename U, int NW>
+__global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs<float> A, const EpiItem* items,
+                                                                       int n_items) {
+    __shared__ float tile[NW][kPanel * (kPanel + 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const int item = blockIdx.x * NW + wave;
+    if (item >= n_items) return;
+    const EpiItem it = items[item];
+    const BlockDesc bd = A.blocks[it.blk];
+    const int b = bd.size, stride = bd.stride, r0 = it.row0;
+    const int64_t s0 = bd.start;
+    const U* __restrict__ base = ldd + bd.ld_off;
+    const int nrows = min(kPanel, b - r0);
+    float* tl = tile[wave];
+    float s = 0.0f;
+    for (int c0 = r0; c0 < b; c0 += kPanel) {
+        const int col = c0 + lane;
+        const float dv = (col < b) ? A.eta_diff[s0 + col] : 0.0f;
+        // row-wise coalesced loads -> LDS (pitch 65)
+#pragma unroll 8
+        for (int k = 0; k < kPanel; ++k) {
+            float v = 0.0f;
+            if (k < nrows && col < b) v = static_cast<float>(base[(int64_t)(r0 + k) * stride + col]);
+            tl[k * (kPanel + 1) + lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane r walks row r in column order
+#pragma unroll 8
+        for (int i = 0; i < kPanel; ++i) {
+            const float v = tl[lane * (kPanel + 1) + i];
+            const float di = rl(dv, i);
+            if (c0 + i > r0 + lane) s = __builtin_fmaf(v, di, s);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < nrows) A.q[s0 + r0 + lane] += A.dq * s;
+}
+
+}  // namespace viprs

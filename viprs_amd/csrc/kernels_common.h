@@ -1,0 +1,54 @@
+// Shared device-side descriptors for the E-step kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace viprs {
+
+constexpr int kPanel = 64;          // SNPs per panel = lanes per wavefront on gfx950
+constexpr int kStrip = 256;         // columns per updater strip (64 lanes x 4 columns)
+
+// One LD block as the device sees it.
+struct BlockDesc {
+    int32_t start;      // first SNP (index into the per-SNP vectors)
+    int32_t size;       // SNPs in the block
+    int32_t stride;     // row stride (elements) of the repacked dense block (multiple of 64)
+    int32_t kind;       // viprs_block_kind
+    int64_t ld_off;     // element offset of the repacked block inside the dense LD buffer
+};
+
+// Per-call argument pack for the spike-and-slab kernels (T = state float type).
+template <typename T>
+struct EStepArgs {
+    const BlockDesc* blocks;     // schedule order (descending cost)
+    int32_t n_blocks;
+    int32_t* counter;            // work-queue head (zeroed before every launch)
+    unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
+    // raw LD as the caller laid it out (generic kernel)
+    const int32_t* lb;
+    const int64_t* ip;
+    const void* ld_raw;
+    // repacked dense blocks (panel kernels)
+    const void* ld_dense;
+    // per-SNP vectors
+    const T* std_beta;
+    const T* u_logs;
+    const T* shvt;        // sqrt_half_var_tau (spike-and-slab, mixture) or half_var_tau (grid)
+    const T* mu_mult;
+    const T* log_null_pi; // mixture only
+    T* var_gamma;
+    T* var_mu;
+    T* eta;
+    T* q;
+    T* eta_diff;
+    T dq;
+    int32_t low_memory;
+    int32_t width;        // K (mixture) / G (grid); 1 otherwise
+    int64_t m;            // SNPs in the plan (column stride of grid matrices)
+    const int32_t* active; // grid: active model indices
+    int32_t n_active;
+};
+
+template <typename U> struct LdLoad;   // element -> float/double conversion (static_cast, as e_step.hpp:173)
+
+}  // namespace viprs

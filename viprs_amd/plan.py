@@ -1,0 +1,233 @@
+"""Python handles over the C ABI: ``LDPlan`` (device-resident LD + block schedule) and
+``DeviceState`` (device-resident variational state).
+
+``LDPlan`` replaces the "load LD matrices to memory" step of ``VIPRS.__init__``
+(viprs/model/VIPRS.py:151-172 in the reference): the LD arrays are validated, partitioned into
+independent LD blocks, uploaded and re-laid-out for the panel kernels once; every later E-step
+only moves per-SNP vectors.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+_FLOAT_CODE = {np.dtype(np.float32): L.F32, np.dtype(np.float64): L.F64}
+_LD_CODE = {np.dtype(np.int8): L.LD_I8, np.dtype(np.int16): L.LD_I16, np.dtype(np.int32): L.LD_I32,
+            np.dtype(np.int64): L.LD_I64, np.dtype(np.float32): L.LD_F32, np.dtype(np.float64): L.LD_F64}
+_IP_CODE = {np.dtype(np.int32): L.IP_I32, np.dtype(np.int64): L.IP_I64}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _check_index_arrays(ld_left_bound, ld_indptr):
+    # same errors the Cython memoryviews raise (e_step_cpp.pyx:91-93: int[::1], indptr_type[::1])
+    if not isinstance(ld_left_bound, np.ndarray) or ld_left_bound.dtype != np.int32:
+        raise ValueError("Buffer dtype mismatch, expected 'int' but got "
+                         f"'{getattr(ld_left_bound, 'dtype', type(ld_left_bound))}' (ld_left_bound)")
+    if not isinstance(ld_indptr, np.ndarray) or ld_indptr.dtype not in _IP_CODE:
+        raise ValueError("Buffer dtype mismatch, expected int32/int64 ld_indptr but got "
+                         f"'{getattr(ld_indptr, 'dtype', type(ld_indptr))}'")
+    for name, a in (("ld_left_bound", ld_left_bound), ("ld_indptr", ld_indptr)):
+        if a.ndim != 1:
+            raise ValueError(f"Buffer has wrong number of dimensions (expected 1, got {a.ndim}) ({name})")
+        if not a.flags.c_contiguous:
+            raise ValueError(f"ndarray is not C-contiguous ({name})")
+    if ld_indptr.shape[0] != ld_left_bound.shape[0] + 1:
+        raise ValueError("ld_indptr must have len(ld_left_bound) + 1 entries")
+
+
+def plan_blocks(ld_left_bound, ld_indptr, low_memory):
+    """Host-only block discovery (no GPU needed).  Returns ``(block_start, block_kind)`` with
+    ``block_start`` of length ``n_blocks + 1``."""
+    _check_index_arrays(ld_left_bound, ld_indptr)
+    m = ld_left_bound.shape[0]
+    n = ctypes.c_int64(0)
+    starts = np.zeros(m + 1, dtype=np.int64)
+    kinds = np.zeros(max(m, 1), dtype=np.int32)
+    L.check(L.lib.viprs_plan_blocks(m, _ptr(ld_left_bound), _ptr(ld_indptr), _IP_CODE[ld_indptr.dtype],
+                                    int(bool(low_memory)), ctypes.byref(n), _ptr(starts), _ptr(kinds)))
+    return starts[: n.value + 1].copy(), kinds[: n.value].copy()
+
+
+class LDPlan:
+    """Device-resident LD matrix of one chromosome (or any set of LD blocks)."""
+
+    def __init__(self, ld_left_bound, ld_indptr, ld_data, low_memory, device=0, math_mode="exact"):
+        _check_index_arrays(ld_left_bound, ld_indptr)
+        if not isinstance(ld_data, np.ndarray) or ld_data.dtype not in _LD_CODE:
+            raise ValueError("Buffer dtype mismatch for ld_data: "
+                             f"'{getattr(ld_data, 'dtype', type(ld_data))}' is not a supported LD dtype")
+        if ld_data.ndim != 1 or not ld_data.flags.c_contiguous:
+            raise ValueError("ld_data must be a C-contiguous 1-d array")
+        self.m = int(ld_left_bound.shape[0])
+        if self.m and int(ld_indptr[-1]) != ld_data.shape[0]:
+            raise ValueError("ld_indptr[-1] must equal len(ld_data)")
+        self.low_memory = bool(low_memory)
+        self.ld_dtype = ld_data.dtype
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        L.check(L.lib.viprs_plan_create(ctypes.byref(self._h), self.m, _ptr(ld_left_bound), _ptr(ld_indptr),
+                                        _IP_CODE[ld_indptr.dtype], _ptr(ld_data), _LD_CODE[ld_data.dtype],
+                                        int(self.low_memory), self.device))
+        self.set_math_mode(math_mode)
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib.viprs_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ValueError("LDPlan is closed")
+        return self._h
+
+    # -- queries ------------------------------------------------------------------------------
+    def info(self, key):
+        v = ctypes.c_int64(0)
+        L.check(L.lib.viprs_plan_info(self.handle, key, ctypes.byref(v)))
+        return v.value
+
+    @property
+    def n_blocks(self):
+        return self.info(L.INFO_N_BLOCKS)
+
+    @property
+    def nnz(self):
+        return self.info(L.INFO_NNZ)
+
+    def blocks(self):
+        n = self.n_blocks
+        starts = np.zeros(n + 1, dtype=np.int64)
+        kinds = np.zeros(max(n, 1), dtype=np.int32)
+        L.check(L.lib.viprs_plan_get_blocks(self.handle, _ptr(starts), _ptr(kinds)))
+        return starts, kinds[:n]
+
+    def set_math_mode(self, mode):
+        code = {"exact": L.MATH_EXACT, "fast": L.MATH_FAST}.get(mode, mode)
+        L.check(L.lib.viprs_plan_set_math_mode(self.handle, int(code)))
+        self.math_mode = "exact" if code == L.MATH_EXACT else "fast"
+
+    def last_kernel_ms(self, which=0):
+        ms = ctypes.c_double(0.0)
+        L.check(L.lib.viprs_plan_last_kernel_ms(self.handle, int(which), ctypes.byref(ms)))
+        return ms.value
+
+    def last_skipped(self):
+        n = ctypes.c_int64(0)
+        L.check(L.lib.viprs_plan_last_skipped(self.handle, ctypes.byref(n)))
+        return n.value
+
+    # -- one-shot host-buffer E-steps (drop-ins for the Cython entry points) -------------------
+    def e_step(self, std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs, sqrt_half_var_tau, mu_mult,
+               dq_scale, threads=1, low_memory=None):
+        T = _FLOAT_CODE[std_beta.dtype]
+        low_memory = self.low_memory if low_memory is None else low_memory
+        L.check(L.lib.viprs_e_step(self.handle, T, _ptr(std_beta), _ptr(var_gamma), _ptr(var_mu), _ptr(eta),
+                                   _ptr(q), _ptr(eta_diff), _ptr(u_logs), _ptr(sqrt_half_var_tau),
+                                   _ptr(mu_mult), float(dq_scale), int(threads), int(bool(low_memory))))
+
+    def e_step_mixture(self, std_beta, var_gamma, var_mu, eta, q, eta_diff, log_null_pi, u_logs,
+                       sqrt_half_var_tau, mu_mult, dq_scale, threads=1, low_memory=None):
+        T = _FLOAT_CODE[std_beta.dtype]
+        low_memory = self.low_memory if low_memory is None else low_memory
+        K = var_mu.shape[1]
+        L.check(L.lib.viprs_e_step_mixture(self.handle, T, int(K), _ptr(std_beta), _ptr(var_gamma), _ptr(var_mu),
+                                           _ptr(eta), _ptr(q), _ptr(eta_diff), _ptr(log_null_pi), _ptr(u_logs),
+                                           _ptr(sqrt_half_var_tau), _ptr(mu_mult), float(dq_scale),
+                                           int(threads), int(bool(low_memory))))
+
+    def e_step_grid(self, std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs, half_var_tau, mu_mult,
+                    dq_scale, active_model_idx, threads=1, low_memory=None):
+        T = _FLOAT_CODE[std_beta.dtype]
+        low_memory = self.low_memory if low_memory is None else low_memory
+        G = var_mu.shape[1]
+        active = np.ascontiguousarray(active_model_idx, dtype=np.int32)
+        L.check(L.lib.viprs_e_step_grid(self.handle, T, int(G), _ptr(std_beta), _ptr(var_gamma), _ptr(var_mu),
+                                        _ptr(eta), _ptr(q), _ptr(eta_diff), _ptr(u_logs), _ptr(half_var_tau),
+                                        _ptr(mu_mult), float(dq_scale), _ptr(active), int(active.shape[0]),
+                                        int(threads), int(bool(low_memory))))
+
+
+class DeviceState:
+    """Variational state + per-SNP inputs of one plan, resident in HBM across EM iterations."""
+
+    FIELDS = {
+        "std_beta": L.FIELD_STD_BETA, "u_logs": L.FIELD_U_LOGS,
+        "sqrt_half_var_tau": L.FIELD_SQRT_HALF_VAR_TAU, "half_var_tau": L.FIELD_SQRT_HALF_VAR_TAU,
+        "mu_mult": L.FIELD_MU_MULT, "log_null_pi": L.FIELD_LOG_NULL_PI, "var_gamma": L.FIELD_VAR_GAMMA,
+        "var_mu": L.FIELD_VAR_MU, "eta": L.FIELD_ETA, "q": L.FIELD_Q, "eta_diff": L.FIELD_ETA_DIFF,
+    }
+
+    def __init__(self, plan, float_precision="float32", model="spike_slab", width=1):
+        self.plan = plan
+        self.dtype = np.dtype(float_precision)
+        self.model = model
+        self.width = int(width)
+        kind = {"spike_slab": L.MODEL_SPIKE_SLAB, "mixture": L.MODEL_MIXTURE, "grid": L.MODEL_GRID}[model]
+        self._h = ctypes.c_void_p()
+        L.check(L.lib.viprs_state_create(ctypes.byref(self._h), plan.handle, _FLOAT_CODE[self.dtype], kind,
+                                         self.width))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            L.lib.viprs_state_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape(self, name):
+        m = self.plan.m
+        if self.model == "spike_slab" or name in ("std_beta", "log_null_pi"):
+            return (m,)
+        if self.model == "mixture":
+            return (m,) if name in ("eta", "q", "eta_diff") else (m, self.width)
+        return (m, self.width)
+
+    def upload(self, name, array):
+        shape = self._shape(name)
+        order = "F" if self.model == "grid" and len(shape) == 2 else "C"
+        if array.dtype != self.dtype:
+            raise ValueError(f"Buffer dtype mismatch for {name}: expected {self.dtype}, got {array.dtype}")
+        if tuple(array.shape) != shape:
+            raise ValueError(f"{name}: expected shape {shape}, got {array.shape}")
+        a = np.asarray(array, order=order)
+        if (order == "F" and not a.flags.f_contiguous) or (order == "C" and not a.flags.c_contiguous):
+            raise ValueError(f"ndarray is not {'Fortran' if order == 'F' else 'C'} contiguous ({name})")
+        L.check(L.lib.viprs_state_upload(self._h, self.FIELDS[name], _ptr(a)))
+
+    def download(self, name, out=None):
+        shape = self._shape(name)
+        order = "F" if self.model == "grid" and len(shape) == 2 else "C"
+        if out is None:
+            out = np.empty(shape, dtype=self.dtype, order=order)
+        L.check(L.lib.viprs_state_download(self._h, self.FIELDS[name], _ptr(out)))
+        return out
+
+    def reset(self, pi):
+        L.check(L.lib.viprs_state_reset(self._h, float(pi)))
+
+    def e_step(self, dq_scale=1.0, active_model_idx=None, sync=True):
+        if active_model_idx is not None:
+            active = np.ascontiguousarray(active_model_idx, dtype=np.int32)
+            L.check(L.lib.viprs_state_e_step(self._h, float(dq_scale), _ptr(active), int(active.shape[0]),
+                                             int(bool(sync))))
+        else:
+            L.check(L.lib.viprs_state_e_step(self._h, float(dq_scale), None, 0, int(bool(sync))))
+
+    def synchronize(self):
+        L.check(L.lib.viprs_state_synchronize(self._h))

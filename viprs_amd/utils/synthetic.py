@@ -1,0 +1,189 @@
+"""Synthetic LD blocks + summary statistics in the reference's array layout.
+
+The reference gets these arrays from magenpy (`LDMatrix.load()` -> ld_data / ld_indptr /
+leftmost_idx, VIPRS.py:167-172; `std_beta`, `n_per_snp`, BayesPRSModel.py:133-136); magenpy is
+not part of the reference tree, so benchmarks and tests use analytic AR(1) blocks instead:
+R[i, j] = rho^|i-j| inside a block (positive definite), nothing across blocks.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+SEED = 7209   # the reference's default seed (benchmarks/benchmark_e_step.py:249, bin/viprs_fit:996)
+
+
+def block_sizes(config, seed=SEED):
+    """Block-size lists of BASELINE.json's configs."""
+    rng = np.random.default_rng(seed)
+    if config in ("cfg1", "single_block"):
+        return np.array([500], dtype=np.int64)
+    if config in ("cfg2", "chr22"):
+        n, mu, sigma, lo, hi, total = 40, np.log(420.0), 0.5, 80, 2500, 19_000
+    elif config in ("cfg3", "genome"):
+        n, mu, sigma, lo, hi, total = 1700, np.log(560.0), 0.55, 50, 6000, 1_100_000
+    else:
+        raise ValueError(f"unknown config {config!r}")
+    s = np.clip(rng.lognormal(mu, sigma, n), lo, hi)
+    s = np.clip(np.round(s * (total / s.sum())), lo, hi).astype(np.int64)
+    return s
+
+
+@dataclass
+class SyntheticLD:
+    """LD arrays exactly as `cpp_e_step` takes them (e_step_cpp.pyx:91-93)."""
+    ld_left_bound: np.ndarray      # (m,)  int32
+    ld_indptr: np.ndarray          # (m+1,) int64 (or int32)
+    ld_data: np.ndarray            # (nnz,) float32 / int8 / ...
+    block_start: np.ndarray        # (n_blocks+1,) int64
+    rho: np.ndarray                # (n_blocks,) AR(1) coefficient per block
+    low_memory: bool
+    dq_scale: float = 1.0
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def m(self):
+        return int(self.ld_left_bound.shape[0])
+
+
+def _ar1_block(b, rho, dtype, quant_max):
+    k = np.arange(b)
+    pw = np.power(np.float64(rho), k)
+    if quant_max is None:
+        row = pw.astype(dtype)
+    else:
+        row = np.round(pw * quant_max).astype(dtype)      # magenpy-style symmetric int quantisation
+    return row[np.abs(k[:, None] - k[None, :])]
+
+
+def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8)):
+    """Block-diagonal AR(1) LD in symmetric (`low_memory=False`: every row of a block stores the whole
+    block, diagonal included) or upper-triangular form (`low_memory=True`: row j stores columns
+    j+1 .. block_end-1, left bound j+1) -- the two layouts e_step.hpp:389-392,423-440 consumes."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    rng = np.random.default_rng(seed + 1)
+    rho = rng.uniform(rho_range[0], rho_range[1], len(sizes))
+    ld_dtype = np.dtype(ld_dtype)
+    quant_max = None
+    dq_scale = 1.0
+    if np.issubdtype(ld_dtype, np.integer):
+        quant_max = np.iinfo(ld_dtype).max
+        dq_scale = 1.0 / quant_max                         # VIPRS.py:203-207
+    m = int(sizes.sum())
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    if low_memory:
+        nnz = int((sizes * (sizes - 1) // 2).sum())
+    else:
+        nnz = int((sizes * sizes).sum())
+    data = np.empty(nnz, dtype=ld_dtype)
+    lb = np.empty(m, dtype=np.int32)
+    rowlen = np.empty(m, dtype=np.int64)
+    off = 0
+    for bi, b in enumerate(sizes):
+        b = int(b)
+        s = int(starts[bi])
+        R = _ar1_block(b, rho[bi], ld_dtype, quant_max)
+        if low_memory:
+            iu = np.triu_indices(b, 1)
+            n = b * (b - 1) // 2
+            data[off:off + n] = R[iu]
+            lb[s:s + b] = np.arange(s + 1, s + b + 1, dtype=np.int32)
+            rowlen[s:s + b] = np.arange(b - 1, -1, -1)
+            off += n
+        else:
+            data[off:off + b * b] = R.ravel()
+            lb[s:s + b] = s
+            rowlen[s:s + b] = b
+            off += b * b
+    indptr = np.concatenate([[0], np.cumsum(rowlen)]).astype(indptr_dtype)
+    return SyntheticLD(lb, indptr, data, starts, rho, bool(low_memory), dq_scale)
+
+
+@dataclass
+class SyntheticSumstats:
+    std_beta: np.ndarray           # (m,) marginal standardized effects
+    n_per_snp: np.ndarray          # (m,) float64
+    beta_true: np.ndarray
+    n: float
+
+
+def make_sumstats(ld, n=1e5, h2=0.2, pi=0.01, seed=SEED, float_precision=np.float32):
+    """std_beta = R beta + e, e ~ N(0, R / N), beta spike-and-slab."""
+    rng = np.random.default_rng(seed + 2)
+    m = ld.m
+    causal = rng.random(m) < pi
+    n_causal = max(int(causal.sum()), 1)
+    beta = np.zeros(m)
+    beta[causal] = rng.normal(0.0, np.sqrt(h2 / n_causal), int(causal.sum()))
+    z = rng.standard_normal(m)
+    std_beta = np.empty(m)
+    for bi in range(len(ld.rho)):
+        s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+        b = e - s
+        rho = ld.rho[bi]
+        k = np.arange(b)
+        # R beta for sparse beta: sum of shifted geometric profiles
+        rb = np.zeros(b)
+        for c in np.nonzero(causal[s:e])[0]:
+            rb += beta[s + c] * np.power(rho, np.abs(k - c))
+        # AR(1) noise with covariance R
+        eps = np.empty(b)
+        zz = z[s:e]
+        eps[0] = zz[0]
+        sd = np.sqrt(1.0 - rho * rho)
+        for t in range(1, b):
+            eps[t] = rho * eps[t - 1] + sd * zz[t]
+        std_beta[s:e] = rb + eps / np.sqrt(n)
+    return SyntheticSumstats(std_beta.astype(float_precision), np.full(m, float(n)), beta, float(n))
+
+
+@dataclass
+class EStepInputs:
+    """Everything one `cpp_e_step` call takes besides the LD arrays."""
+    std_beta: np.ndarray
+    var_gamma: np.ndarray
+    var_mu: np.ndarray
+    eta: np.ndarray
+    q: np.ndarray
+    eta_diff: np.ndarray
+    u_logs: np.ndarray
+    sqrt_half_var_tau: np.ndarray
+    mu_mult: np.ndarray
+    pi: float
+    sigma_epsilon: float
+    tau_beta: float
+
+    def state_copy(self):
+        return {k: getattr(self, k).copy() for k in ("var_gamma", "var_mu", "eta", "q", "eta_diff")}
+
+
+def host_prep(n_per_snp, pi, sigma_epsilon, tau_beta, lambda_min=0.0, float_precision=np.float32):
+    """The per-iteration host prep of VIPRS.e_step (VIPRS.py:400-418), float64 -> float_precision."""
+    var_tau = n_per_snp * (1.0 + lambda_min) / sigma_epsilon + tau_beta
+    log_var_tau = np.log(var_tau)
+    mu_mult = (n_per_snp / (var_tau * sigma_epsilon)).astype(float_precision)
+    u_logs = (np.log(pi) - np.log(1.0 - pi) + 0.5 * (np.log(tau_beta) - log_var_tau)).astype(float_precision)
+    shvt = np.sqrt(0.5 * var_tau).astype(float_precision)
+    return var_tau, mu_mult, u_logs, shvt
+
+
+def make_inputs(ss, pi=0.01, sigma_epsilon=0.8, h2=0.2, float_precision=np.float32):
+    """Hyper-parameters pi=0.01, sigma_eps=0.8, tau_beta = M pi / h2 and the standard initial state
+    var_gamma = pi, var_mu = eta = q = eta_diff = 0 (VIPRS.py:344-358)."""
+    m = ss.std_beta.shape[0]
+    tau_beta = m * pi / h2
+    _, mu_mult, u_logs, shvt = host_prep(ss.n_per_snp, pi, sigma_epsilon, tau_beta, 0.0, float_precision)
+    T = np.dtype(float_precision)
+    return EStepInputs(
+        std_beta=ss.std_beta.astype(T), var_gamma=np.full(m, pi, dtype=T), var_mu=np.zeros(m, dtype=T),
+        eta=np.zeros(m, dtype=T), q=np.zeros(m, dtype=T), eta_diff=np.zeros(m, dtype=T),
+        u_logs=u_logs, sqrt_half_var_tau=shvt, mu_mult=mu_mult, pi=pi, sigma_epsilon=sigma_epsilon,
+        tau_beta=tau_beta)
+
+
+def make_problem(config="cfg1", low_memory=False, ld_dtype=np.float32, seed=SEED, sizes=None,
+                 indptr_dtype=np.int64, float_precision=np.float32):
+    sizes = block_sizes(config, seed) if sizes is None else np.asarray(sizes)
+    ld = make_ld(sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, indptr_dtype=indptr_dtype)
+    ss = make_sumstats(ld, seed=seed, float_precision=float_precision)
+    inp = make_inputs(ss, float_precision=float_precision)
+    return ld, ss, inp

@@ -1,0 +1,141 @@
+"""Drop-in replacements for the reference's Cython boundary ``viprs.model.vi.e_step_cpp``
+(viprs/model/vi/e_step_cpp.pyx:71-195): the same function names, positional signatures, in-place
+update contract and dtype/layout errors, executed by the HIP kernels of ``libviprs_hip.so``.
+
+The LD arrays are uploaded to the GPU the first time a given ``(ld_left_bound, ld_indptr,
+ld_data, low_memory)`` combination is seen and stay resident (``plan_for``); later calls move
+only the per-SNP vectors.  ``threads`` is accepted and ignored: results always follow the
+reference's ``threads=1`` semantics.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib as L
+from ..plan import LDPlan
+
+_PLAN_CACHE = OrderedDict()
+_PLAN_CACHE_SIZE = 32
+_DEFAULT_DEVICE = 0
+_DEFAULT_MATH = "exact"
+
+
+def set_default_device(device):
+    global _DEFAULT_DEVICE
+    _DEFAULT_DEVICE = int(device)
+
+
+def set_default_math_mode(mode):
+    """'exact' (bit-for-bit the reference's arithmetic) or 'fast' (hardware exp/rcp sigmoid)."""
+    global _DEFAULT_MATH
+    if mode not in ("exact", "fast"):
+        raise ValueError("math mode must be 'exact' or 'fast'")
+    _DEFAULT_MATH = mode
+    for plan, _ in _PLAN_CACHE.values():
+        plan.set_math_mode(mode)
+
+
+def clear_plan_cache():
+    for plan, _ in _PLAN_CACHE.values():
+        plan.close()
+    _PLAN_CACHE.clear()
+
+
+def plan_for(ld_left_bound, ld_indptr, ld_data, low_memory):
+    """The cached device plan for these LD arrays (identity of the buffers is the key; the arrays
+    are kept alive by the cache so the identity cannot be recycled)."""
+    key = (ld_left_bound.__array_interface__["data"][0], ld_left_bound.shape[0],
+           ld_indptr.__array_interface__["data"][0], ld_data.__array_interface__["data"][0],
+           ld_data.shape[0], str(ld_data.dtype), bool(low_memory), _DEFAULT_DEVICE)
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        _PLAN_CACHE.move_to_end(key)
+        return hit[0]
+    plan = LDPlan(ld_left_bound, ld_indptr, ld_data, low_memory, device=_DEFAULT_DEVICE, math_mode=_DEFAULT_MATH)
+    _PLAN_CACHE[key] = (plan, (ld_left_bound, ld_indptr, ld_data))
+    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        _, (old, _) = _PLAN_CACHE.popitem(last=False)
+        old.close()
+    return plan
+
+
+def check_blas_support():
+    """e_step_cpp.pyx:71-72.  No BLAS on the device path."""
+    return bool(L.lib.viprs_check_blas_support())
+
+
+def check_omp_support():
+    """e_step_cpp.pyx:75-76.  No OpenMP on the device path."""
+    return bool(L.lib.viprs_check_omp_support())
+
+
+def _floating(name, a, dtype, ndim=1, order="C"):
+    # the errors Cython's typed memoryviews raise for floating[::1] / [:, ::1] / [::1, :]
+    if not isinstance(a, np.ndarray):
+        raise TypeError(f"{name}: expected a numpy array")
+    if a.dtype != dtype:
+        raise ValueError(f"Buffer dtype mismatch, expected '{dtype}' but got '{a.dtype}' ({name})")
+    if a.ndim != ndim:
+        raise ValueError(f"Buffer has wrong number of dimensions (expected {ndim}, got {a.ndim}) ({name})")
+    if order == "C" and not a.flags.c_contiguous:
+        raise ValueError(f"ndarray is not C-contiguous ({name})")
+    if order == "F" and not a.flags.f_contiguous:
+        raise ValueError(f"ndarray is not Fortran contiguous ({name})")
+
+
+def _float_dtype(std_beta):
+    if not isinstance(std_beta, np.ndarray) or std_beta.dtype not in (np.float32, np.float64):
+        raise ValueError("Buffer dtype mismatch, expected float32/float64 (std_beta)")
+    return std_beta.dtype
+
+
+def cpp_e_step(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs,
+               sqrt_half_var_tau, mu_mult, dq_scale, threads, low_memory):
+    """e_step_cpp.pyx:91-122 -> e_step.hpp:343-442 (spike-and-slab E-step), on the GPU."""
+    T = _float_dtype(std_beta)
+    m = var_mu.shape[0] if isinstance(var_mu, np.ndarray) else -1
+    for name, a in (("std_beta", std_beta), ("var_gamma", var_gamma), ("var_mu", var_mu), ("eta", eta), ("q", q),
+                    ("eta_diff", eta_diff), ("u_logs", u_logs), ("sqrt_half_var_tau", sqrt_half_var_tau),
+                    ("mu_mult", mu_mult)):
+        _floating(name, a, T)
+        if a.shape[0] != m:
+            raise ValueError(f"{name}: expected {m} entries, got {a.shape[0]}")
+    plan = plan_for(ld_left_bound, ld_indptr, ld_data, low_memory)
+    if plan.m != m:
+        raise ValueError(f"LD arrays describe {plan.m} SNPs but the state vectors have {m}")
+    plan.e_step(std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs, sqrt_half_var_tau, mu_mult, dq_scale,
+                threads, low_memory)
+
+
+def cpp_e_step_mixture(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, eta, q, eta_diff,
+                       log_null_pi, u_logs, sqrt_half_var_tau, mu_mult, dq_scale, threads, low_memory):
+    """e_step_cpp.pyx:125-159 -> e_step.hpp:447-551 (sparse-mixture E-step), on the GPU."""
+    T = _float_dtype(std_beta)
+    for name, a in (("std_beta", std_beta), ("eta", eta), ("q", q), ("eta_diff", eta_diff),
+                    ("log_null_pi", log_null_pi)):
+        _floating(name, a, T)
+    for name, a in (("var_gamma", var_gamma), ("var_mu", var_mu), ("u_logs", u_logs),
+                    ("sqrt_half_var_tau", sqrt_half_var_tau), ("mu_mult", mu_mult)):
+        _floating(name, a, T, ndim=2, order="C")
+    plan = plan_for(ld_left_bound, ld_indptr, ld_data, low_memory)
+    if plan.m != var_mu.shape[0]:
+        raise ValueError(f"LD arrays describe {plan.m} SNPs but the state has {var_mu.shape[0]}")
+    plan.e_step_mixture(std_beta, var_gamma, var_mu, eta, q, eta_diff, log_null_pi, u_logs, sqrt_half_var_tau,
+                        mu_mult, dq_scale, threads, low_memory)
+
+
+def cpp_e_step_grid(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs,
+                    half_var_tau, mu_mult, dq_scale, active_model_idx, threads, low_memory):
+    """e_step_cpp.pyx:161-195 -> e_step.hpp:555-647 (grid of spike-and-slab models), on the GPU."""
+    T = _float_dtype(std_beta)
+    _floating("std_beta", std_beta, T)
+    for name, a in (("var_gamma", var_gamma), ("var_mu", var_mu), ("eta", eta), ("q", q), ("eta_diff", eta_diff),
+                    ("u_logs", u_logs), ("half_var_tau", half_var_tau), ("mu_mult", mu_mult)):
+        _floating(name, a, T, ndim=2, order="F")
+    if not isinstance(active_model_idx, np.ndarray) or active_model_idx.dtype != np.int32:
+        raise ValueError("Buffer dtype mismatch, expected 'int' (active_model_idx)")
+    plan = plan_for(ld_left_bound, ld_indptr, ld_data, low_memory)
+    if plan.m != var_mu.shape[0]:
+        raise ValueError(f"LD arrays describe {plan.m} SNPs but the state has {var_mu.shape[0]}")
+    plan.e_step_grid(std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs, half_var_tau, mu_mult, dq_scale,
+                     active_model_idx, threads, low_memory)
