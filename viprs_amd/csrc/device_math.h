@@ -58,8 +58,10 @@ __device__ __forceinline__ float expf_glibc_finish(double r, uint64_t t) {
 template <bool UNIFORM>
 __device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab) {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32;
-    if (x < -104.0f) return 0.0f;  // glibc: __math_uflowf below -0x1.9fe368p6; (float)y is 0 here
-    const double xd = (double)x;
+    // glibc returns 0 (__math_uflowf) below -0x1.9fe368p6; branch-free here because the per-lane
+    // flavour's ds_bpermute needs every lane of the wave active (inactive source lanes read as 0)
+    const bool uflow = x < -104.0f;
+    const double xd = (double)(uflow ? -104.0f : x);
     const double z = InvLn2N * xd;
     const double kd = rint(z);                 // == (z + 0x1.8p52) - 0x1.8p52 in round-to-nearest
     const double r = fma(InvLn2N, xd, -kd);
@@ -78,7 +80,8 @@ __device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab) {
     // the 64-bit add in glibc does (tab low word is untouched: 47 >= 32).
     thi += (int)((unsigned)ki << 15);
     const uint64_t t = ((uint64_t)(uint32_t)thi << 32) | (uint32_t)tlo;
-    return expf_glibc_finish(r, t);
+    const float y = expf_glibc_finish(r, t);
+    return uflow ? 0.0f : y;
 }
 
 // ---------------------------------------------------------------------------------------------
