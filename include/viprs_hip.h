@@ -168,6 +168,11 @@ int viprs_state_synchronize(viprs_state* state);
  * this plan, measured on the stream they were launched on.  `which`: 0 = all kernels of the
  * sweep, 1 = dominant (panel) kernel only.                                                    */
 int viprs_plan_last_kernel_ms(viprs_plan* plan, int which, double* ms);
+/* Every sweep records its HIP events into a ring of 256 entries.  `timing_reset` forgets them;
+ * `timing_history` returns the durations (ms) of the most recent min(capacity, 256, recorded)
+ * sweeps, oldest first.                                                                       */
+int viprs_plan_timing_reset(viprs_plan* plan);
+int viprs_plan_timing_history(viprs_plan* plan, int which, double* ms, int capacity, int* n);
 /* Number of SNPs of the last sweep that took the skip branch (e_step.hpp:410-413).            */
 int viprs_plan_last_skipped(viprs_plan* plan, int64_t* n_skipped);
 

@@ -71,6 +71,8 @@ _PROTOS = {
     "viprs_state_synchronize": (_i, [_vp]),
     "viprs_plan_last_kernel_ms": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "viprs_plan_last_skipped": (_i, [_vp, _pi64]),
+    "viprs_plan_timing_reset": (_i, [_vp]),
+    "viprs_plan_timing_history": (_i, [_vp, _i, ctypes.POINTER(_d), _i, ctypes.POINTER(_i)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

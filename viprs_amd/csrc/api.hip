@@ -106,8 +106,11 @@ struct viprs_plan {
     int max_dense = 0, max_ragged = 0;
     DevBuf<int32_t> d_counters;             // [0] dense queue head, [1] ragged queue head
     DevBuf<unsigned long long> d_skipped;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // sweep start/end, panel start/end
-    bool timed = false;
+    // HIP-event ring: per sweep {sweep start, sweep end, panel start, panel end}, recorded on
+    // the stream the kernels are launched on
+    static constexpr int kRing = 256;
+    std::vector<hipEvent_t> ev;             // 4 * kRing
+    int64_t sweeps = 0;                     // sweeps recorded since the last timing reset
     viprs_state* scratch = nullptr;         // state used by the one-shot host-buffer calls
 
     ~viprs_plan();
@@ -218,6 +221,7 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     P->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
+    P->ev.assign(4 * viprs_plan::kRing, nullptr);
     for (auto& e : P->ev) HIP_TRY(hipEventCreate(&e));
 
     // ---- schedule: dense blocks -> panel kernels, everything else -> generic kernel ----------
@@ -539,12 +543,13 @@ int run_spike_slab(viprs_state* S, double dq) {
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipMemsetAsync(P->d_counters.p, 0, 4 * sizeof(int32_t), P->stream));
     HIP_TRY(hipMemsetAsync(P->d_skipped.p, 0, sizeof(unsigned long long), P->stream));
-    HIP_TRY(hipEventRecord(P->ev[0], P->stream));
+    hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
+    HIP_TRY(hipEventRecord(ev[0], P->stream));
     int rc = VIPRS_OK;
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
         if (!P->dense_h.empty()) {
-            HIP_TRY(hipEventRecord(P->ev[2], P->stream));
+            HIP_TRY(hipEventRecord(ev[2], P->stream));
             switch (P->ld_dtype) {
                 case VIPRS_LD_F32: rc = launch_panel<float>(P, A); break;
                 case VIPRS_LD_I8: rc = launch_panel<int8_t>(P, A); break;
@@ -552,7 +557,7 @@ int run_spike_slab(viprs_state* S, double dq) {
                 default: rc = fail(VIPRS_EINVAL, "dense schedule with unsupported LD dtype"); break;
             }
             if (rc != VIPRS_OK) return rc;
-            HIP_TRY(hipEventRecord(P->ev[3], P->stream));
+            HIP_TRY(hipEventRecord(ev[3], P->stream));
         }
         if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A);
     } else {
@@ -561,8 +566,8 @@ int run_spike_slab(viprs_state* S, double dq) {
         return fail(VIPRS_EUNSUPPORTED, "float64 state requires a plan created for the generic path");
     }
     if (rc != VIPRS_OK) return rc;
-    HIP_TRY(hipEventRecord(P->ev[1], P->stream));
-    P->timed = true;
+    HIP_TRY(hipEventRecord(ev[1], P->stream));
+    P->sweeps++;
     return VIPRS_OK;
 }
 
@@ -627,20 +632,46 @@ int viprs_e_step_grid(viprs_plan*, int, int, const void*, void*, void*, void*, v
     return fail(VIPRS_EUNSUPPORTED, "viprs_e_step_grid: not implemented yet");
 }
 
-int viprs_plan_last_kernel_ms(viprs_plan* P, int which, double* ms) {
-    if (!P || !ms) return fail(VIPRS_EINVAL, "null argument");
-    if (!P->timed) return fail(VIPRS_EINVAL, "no timed sweep yet");
-    HIP_TRY(hipSetDevice(P->device));
+static int sweep_ms(viprs_plan* P, int64_t sweep, int which, double* ms) {
+    hipEvent_t* ev = P->ev.data() + 4 * (sweep % viprs_plan::kRing);
     float t = 0.f;
     if (which == 1) {
         if (P->dense_h.empty()) { *ms = 0.0; return VIPRS_OK; }
-        HIP_TRY(hipEventSynchronize(P->ev[3]));
-        HIP_TRY(hipEventElapsedTime(&t, P->ev[2], P->ev[3]));
+        HIP_TRY(hipEventSynchronize(ev[3]));
+        HIP_TRY(hipEventElapsedTime(&t, ev[2], ev[3]));
     } else {
-        HIP_TRY(hipEventSynchronize(P->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&t, P->ev[0], P->ev[1]));
+        HIP_TRY(hipEventSynchronize(ev[1]));
+        HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[1]));
     }
     *ms = t;
+    return VIPRS_OK;
+}
+
+int viprs_plan_last_kernel_ms(viprs_plan* P, int which, double* ms) {
+    if (!P || !ms) return fail(VIPRS_EINVAL, "null argument");
+    if (P->sweeps == 0) return fail(VIPRS_EINVAL, "no timed sweep yet");
+    HIP_TRY(hipSetDevice(P->device));
+    return sweep_ms(P, P->sweeps - 1, which, ms);
+}
+
+int viprs_plan_timing_reset(viprs_plan* P) {
+    if (!P) return fail(VIPRS_EINVAL, "null plan");
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    P->sweeps = 0;
+    return VIPRS_OK;
+}
+
+int viprs_plan_timing_history(viprs_plan* P, int which, double* ms, int capacity, int* n) {
+    if (!P || !ms || !n) return fail(VIPRS_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(P->device));
+    const int64_t have = std::min<int64_t>(P->sweeps, viprs_plan::kRing);
+    const int count = (int)std::min<int64_t>(have, capacity);
+    for (int i = 0; i < count; ++i) {
+        int rc = sweep_ms(P, P->sweeps - count + i, which, &ms[i]);
+        if (rc != VIPRS_OK) return rc;
+    }
+    *n = count;
     return VIPRS_OK;
 }
 

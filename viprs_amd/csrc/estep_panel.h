@@ -48,33 +48,50 @@ __device__ __forceinline__ float rl(float v, int lane) {
 }
 
 constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
-constexpr int kStripPrefetch = 8;    // row loads in flight per updater lane
+constexpr int kStripPrefetch = 16;   // row loads in flight per updater lane
 
 // LDS carve (floats): q[qcap] | a[2][64] | T[2][64*64]
 __host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
 
 // Trailing update of one 256-column strip by one wave: q[c..c+3] = fma(R[row][c..c+3], a_row, .)
-// for the `nrows` rows of a panel, in row order.
-template <typename U>
-__device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int nrows, float avec,
+// for the 64 rows of a panel, in row order, with kStripPrefetch row loads (16 B per lane each) in
+// flight per wave.  The row loop is rolled in groups of kStripPrefetch so that every load is
+// consumed exactly one group later (a fully unrolled loop lets hipcc sink the loads next to their
+// uses, leaving two in flight), and there is no runtime guard around any load (a guard makes hipcc
+// wait vmcnt(0) per row).  FULL = false (partial last panel of a block): rows past its end are
+// clamped to its last row; their a is 0, so fma(R, 0, q) == q leaves q untouched.
+template <typename U, bool FULL>
+__device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int last_row, float avec,
                                              float* __restrict__ lq_c) {
+    static_assert(kPanel % kStripPrefetch == 0, "panel must be a whole number of prefetch groups");
     float4 qv = *reinterpret_cast<float4*>(lq_c);
     float4 buf[kStripPrefetch];
 #pragma unroll
     for (int k = 0; k < kStripPrefetch; ++k)
-        if (k < nrows) buf[k] = load4<U>(rowp + (int64_t)k * stride);
+        buf[k] = load4<U>(rowp + (int64_t)(FULL ? k : min(k, last_row)) * stride);
+#pragma unroll 1
+    for (int g = 0; g < kPanel / kStripPrefetch - 1; ++g) {
 #pragma unroll
-    for (int k = 0; k < kPanel; ++k) {
-        if (k < nrows) {
-            const float4 v = buf[k % kStripPrefetch];
-            if (k + kStripPrefetch < kPanel && k + kStripPrefetch < nrows)
-                buf[k % kStripPrefetch] = load4<U>(rowp + (int64_t)(k + kStripPrefetch) * stride);
-            const float a = rl(avec, k);
+        for (int k = 0; k < kStripPrefetch; ++k) {
+            const float4 v = buf[k];
+            const int rn = kStripPrefetch * (g + 1) + k;
+            buf[k] = load4<U>(rowp + (int64_t)(FULL ? rn : min(rn, last_row)) * stride);
+            const float a = rl(avec, kStripPrefetch * g + k);
             qv.x = __builtin_fmaf(v.x, a, qv.x);
             qv.y = __builtin_fmaf(v.y, a, qv.y);
             qv.z = __builtin_fmaf(v.z, a, qv.z);
             qv.w = __builtin_fmaf(v.w, a, qv.w);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+#pragma unroll
+    for (int k = 0; k < kStripPrefetch; ++k) {
+        const float4 v = buf[k];
+        const float a = rl(avec, kPanel - kStripPrefetch + k);
+        qv.x = __builtin_fmaf(v.x, a, qv.x);
+        qv.y = __builtin_fmaf(v.y, a, qv.y);
+        qv.z = __builtin_fmaf(v.z, a, qv.z);
+        qv.w = __builtin_fmaf(v.w, a, qv.w);
     }
     *reinterpret_cast<float4*>(lq_c) = qv;
 }
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     tab.init();
     unsigned long long my_skipped = 0;
     const float eps = Eps<float>::value;
+    const float dq = A.dq;
 
     for (;;) {
         if (tid == 0) s_blk = atomicAdd(A.counter, 1);
@@ -130,12 +148,16 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const float ulog = live ? A.u_logs[j] : 0.0f;
                     const float eta_old = live ? A.eta[j] : 0.0f;
 
-                    // diagonal tile rows, streamed kChainPrefetch rows ahead
+                    // diagonal tile rows, streamed kChainPrefetch rows ahead.  All 64 steps always
+                    // run, straight-line (no runtime guards around loads, see strip_update): rows
+                    // past a partial last panel are clamped and their steps forced onto the skip
+                    // path (a = 0 leaves every q untouched).
+                    const int last = nrows - 1;
                     const U* __restrict__ dptr = base + (int64_t)r0 * stride + r0 + lane;
                     float drow[kPanel];
 #pragma unroll
                     for (int k = 0; k < kChainPrefetch; ++k)
-                        if (k < nrows) drow[k] = static_cast<float>(dptr[(int64_t)k * stride]);
+                        drow[k] = static_cast<float>(dptr[(int64_t)min(k, last) * stride]);
 
                     float qc = lq[r0 + lane];
                     if (p > 0) {
@@ -148,20 +170,18 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
 #pragma unroll
                     for (int jj = 0; jj < kPanel; ++jj) {
-                        if (jj < nrows) {
-                            if (jj + kChainPrefetch < kPanel && jj + kChainPrefetch < nrows)
-                                drow[jj + kChainPrefetch] =
-                                    static_cast<float>(dptr[(int64_t)(jj + kChainPrefetch) * stride]);
-                            const float qj = rl(qc, jj);
-                            float mu, gamma, d;
-                            snp_update<EXACT, true>(rl(mm, jj), rl(beta, jj), rl(sv, jj), rl(ulog, jj),
-                                                    rl(eta_old, jj), qj, tab, mu, gamma, d);
-                            const bool skip = fabsf(d) < eps;
-                            const float a = skip ? 0.0f : A.dq * d;
-                            qc = __builtin_fmaf(drow[jj], a, qc);
-                            if (!UPPER) qc = (lane == jj && !skip) ? qc - d : qc;
-                            qcap_v = (lane == jj) ? qj : qcap_v;
-                        }
+                        if (jj + kChainPrefetch < kPanel)
+                            drow[jj + kChainPrefetch] =
+                                static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
+                        const float qj = rl(qc, jj);
+                        float mu, gamma, d;
+                        snp_update<EXACT, true>(rl(mm, jj), rl(beta, jj), rl(sv, jj), rl(ulog, jj),
+                                                rl(eta_old, jj), qj, tab, mu, gamma, d);
+                        const bool skip = (fabsf(d) < eps) || (jj > last);
+                        const float a = skip ? 0.0f : dq * d;
+                        qc = __builtin_fmaf(drow[jj], a, qc);
+                        if (!UPPER) qc = (lane == jj && !skip) ? qc - d : qc;
+                        qcap_v = (lane == jj) ? qj : qcap_v;
                     }
 
                     // lane-parallel replay of the 64 updates (same operations, same inputs ->
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         }
                     }
                     my_skipped += __popcll(__ballot(live && skip));
-                    a_prev = (live && !skip) ? A.dq * d : 0.0f;
+                    a_prev = (live && !skip) ? dq * d : 0.0f;
                     la[(p & 1) * kPanel + lane] = a_prev;
                     lq[r0 + lane] = qc;
                 }
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                 if (p > 0) {
                     const int pp = p - 1;                       // panel whose a-vector is applied
                     const int rr0 = pp * kPanel;
-                    const int nrows = min(kPanel, b - rr0);
+                    const int last_row = min(kPanel, b - rr0) - 1;
                     const float avec = la[(pp & 1) * kPanel + lane];
                     if (__ballot(avec != 0.0f)) {
                         const int nstrips = (bpad + kStrip - 1) / kStrip;
@@ -209,8 +229,12 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                             const int cp = c >> 6;
                             bool active = (c < b) && (cp != pp) && (cp != p);
                             if (UPPER) active = active && (cp > p);
-                            if (active)
-                                strip_update<U>(base + (int64_t)rr0 * stride + c, stride, nrows, avec, lq + c);
+                            if (active) {
+                                if (last_row == kPanel - 1)
+                                    strip_update<U, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                else
+                                    strip_update<U, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                            }
                         }
                     }
                 }

@@ -123,6 +123,17 @@ class LDPlan:
         L.check(L.lib.viprs_plan_last_kernel_ms(self.handle, int(which), ctypes.byref(ms)))
         return ms.value
 
+    def timing_reset(self):
+        L.check(L.lib.viprs_plan_timing_reset(self.handle))
+
+    def timing_history(self, which=0, capacity=256):
+        """HIP-event durations (ms) of the most recent sweeps, oldest first (which: 0 = whole sweep,
+        1 = panel kernel(s) only)."""
+        buf = (ctypes.c_double * capacity)()
+        n = ctypes.c_int(0)
+        L.check(L.lib.viprs_plan_timing_history(self.handle, int(which), buf, capacity, ctypes.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
     def last_skipped(self):
         n = ctypes.c_int64(0)
         L.check(L.lib.viprs_plan_last_skipped(self.handle, ctypes.byref(n)))

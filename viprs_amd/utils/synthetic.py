@@ -45,14 +45,26 @@ class SyntheticLD:
         return int(self.ld_left_bound.shape[0])
 
 
-def _ar1_block(b, rho, dtype, quant_max):
-    k = np.arange(b)
-    pw = np.power(np.float64(rho), k)
+def _ar1_row(b, rho, dtype, quant_max):
+    pw = np.power(np.float64(rho), np.arange(b))
     if quant_max is None:
-        row = pw.astype(dtype)
+        return pw.astype(dtype)
+    return np.round(pw * quant_max).astype(dtype)          # magenpy-style symmetric int quantisation
+
+
+def _fill_block(data, off, b, row, low_memory):
+    """Write one AR(1) block (R[i, j] = row[|i - j|]) into `data` starting at `off`, row by row with
+    contiguous copies (numpy releases the GIL for them, so blocks are filled by a thread pool)."""
+    if low_memory:
+        o = off
+        for r in range(b - 1):                              # row r holds R[r, r+1:] = row[1 : b-r]
+            data[o:o + b - 1 - r] = row[1:b - r]
+            o += b - 1 - r
     else:
-        row = np.round(pw * quant_max).astype(dtype)      # magenpy-style symmetric int quantisation
-    return row[np.abs(k[:, None] - k[None, :])]
+        vals = np.concatenate([row[::-1], row[1:]])         # R[r, :] = vals[b-1-r : 2b-1-r]
+        dst = data[off:off + b * b].reshape(b, b)
+        for r in range(b):
+            dst[r] = vals[b - 1 - r:2 * b - 1 - r]
 
 
 def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8)):
@@ -78,22 +90,32 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
     lb = np.empty(m, dtype=np.int32)
     rowlen = np.empty(m, dtype=np.int64)
     off = 0
+    jobs = []
     for bi, b in enumerate(sizes):
         b = int(b)
         s = int(starts[bi])
-        R = _ar1_block(b, rho[bi], ld_dtype, quant_max)
+        jobs.append((off, b, bi))
         if low_memory:
-            iu = np.triu_indices(b, 1)
-            n = b * (b - 1) // 2
-            data[off:off + n] = R[iu]
             lb[s:s + b] = np.arange(s + 1, s + b + 1, dtype=np.int32)
             rowlen[s:s + b] = np.arange(b - 1, -1, -1)
-            off += n
+            off += b * (b - 1) // 2
         else:
-            data[off:off + b * b] = R.ravel()
             lb[s:s + b] = s
             rowlen[s:s + b] = b
             off += b * b
+
+    def _job(j):
+        o, b, bi = j
+        _fill_block(data, o, b, _ar1_row(b, rho[bi], ld_dtype, quant_max), low_memory)
+
+    if nnz > (1 << 24):
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            list(ex.map(_job, sorted(jobs, key=lambda j: -j[1])))
+    else:
+        for j in jobs:
+            _job(j)
     indptr = np.concatenate([[0], np.cumsum(rowlen)]).astype(indptr_dtype)
     return SyntheticLD(lb, indptr, data, starts, rho, bool(low_memory), dq_scale)
 
