@@ -52,11 +52,17 @@ __device__ __forceinline__ float expf_glibc_finish(double r, uint64_t t) {
     return (float)y;
 }
 
+// Table lookup flavours.
+//   kLookupPerLane : every lane looks up its own index (two ds_bpermute; all 64 lanes active).
+//   kLookupLane    : only lane `sel` (wave-uniform) needs a correct result -- the serial chain,
+//                    where lane j carries SNP j and the other lanes compute don't-care values.
+//                    The index is read from lane `sel` and the entry fetched with two v_readlane,
+//                    which keeps the LDS crossbar off the chain.
+enum { kLookupPerLane = 0, kLookupLane = 1 };
+
 // x <= 0 is all the E-step needs (sigmoid / softmax arguments are -|x| or u - max(u)).
-// UNIFORM: every lane of the wave passes the same x (the serial chain is computed redundantly
-// by all 64 lanes), so the table index is wave-uniform.
-template <bool UNIFORM>
-__device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab) {
+template <int LOOKUP>
+__device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab, int sel = 0) {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32;
     // glibc returns 0 (__math_uflowf) below -0x1.9fe368p6; branch-free here because the per-lane
     // flavour's ds_bpermute needs every lane of the wave active (inactive source lanes read as 0)
@@ -68,8 +74,8 @@ __device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab) {
     const int ki = (int)kd;                    // |kd| < 2^13
     const int idx = ki & 31;
     int tlo, thi;
-    if (UNIFORM) {
-        const int sidx = __builtin_amdgcn_readfirstlane(idx);
+    if (LOOKUP == kLookupLane) {
+        const int sidx = __builtin_amdgcn_readlane(idx, sel);
         tlo = __builtin_amdgcn_readlane(tab.lo, sidx);
         thi = __builtin_amdgcn_readlane(tab.hi, sidx);
     } else {
@@ -88,12 +94,27 @@ __device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab) {
 // sigmoid<T> (e_step.hpp:245-261).  With T = float the literal `1.` there is a double, so the add
 // and the divide happen in double and the quotient is rounded to float once.
 // ---------------------------------------------------------------------------------------------
-template <bool UNIFORM>
-__device__ __forceinline__ float sigmoid_exact(float x, const ExpTab& tab) {
-    const float e = expf_glibc_nonpos<UNIFORM>(-fabsf(x), tab);
-    const double ed = (double)e;
-    const double num = (x < 0.0f) ? ed : 1.0;
-    return (float)(num / (1.0 + ed));
+// num / den for den in [1, 2], 0 <= num <= 1: the Newton-Raphson sequence hipcc itself emits for
+// an IEEE double divide (v_rcp_f64, two refinement steps, one residual correction) without the
+// v_div_scale / v_div_fmas / v_div_fixup instructions, which only rescale operands near the
+// exponent limits and patch inf/nan/0 -- none of which can occur for these ranges, so the quotient
+// is the same correctly rounded double.  (viprs_selftest checks it against `/` on the device.)
+__device__ __forceinline__ double div_unit_range(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q0 = num * r;
+    const double rem = __builtin_fma(-den, q0, num);
+    return __builtin_fma(rem, r, q0);
+}
+
+template <int LOOKUP>
+__device__ __forceinline__ float sigmoid_exact(float x, const ExpTab& tab, int sel = 0) {
+    const float e = expf_glibc_nonpos<LOOKUP>(-fabsf(x), tab, sel);
+    const float numf = (x < 0.0f) ? e : 1.0f;
+    return (float)div_unit_range((double)numf, 1.0 + (double)e);
 }
 
 // Hardware-transcendental variant (VIPRS_MATH_FAST): v_exp_f32 with a compensated x*log2(e)
@@ -131,22 +152,22 @@ template <> __device__ __forceinline__ double abs_t<double>(double a) { return f
 
 // One spike-and-slab posterior update (e_step.hpp:401-408) from the current q_j.
 //   mu = fma(mm, beta, -(mm*q)); u = s*mu; gamma = sigmoid(fma(u,u,ulog)); d = fma(gamma, mu, -eta)
-template <bool EXACT, bool UNIFORM>
+template <bool EXACT, int LOOKUP>
 __device__ __forceinline__ void snp_update(float mm, float beta, float s, float ulog, float eta_old,
                                            float qj, const ExpTab& tab, float& mu, float& gamma,
-                                           float& d) {
+                                           float& d, int sel = 0) {
     const float p = mm * qj;
     mu = __builtin_fmaf(mm, beta, -p);
     const float u = s * mu;
     const float x = __builtin_fmaf(u, u, ulog);
-    gamma = EXACT ? sigmoid_exact<UNIFORM>(x, tab) : sigmoid_fast(x);
+    gamma = EXACT ? sigmoid_exact<LOOKUP>(x, tab, sel) : sigmoid_fast(x);
     d = __builtin_fmaf(gamma, mu, -eta_old);
 }
 
-template <bool EXACT, bool UNIFORM>
+template <bool EXACT, int LOOKUP>
 __device__ __forceinline__ void snp_update(double mm, double beta, double s, double ulog,
                                            double eta_old, double qj, const ExpTab&, double& mu,
-                                           double& gamma, double& d) {
+                                           double& gamma, double& d, int = 0) {
     const double p = mm * qj;
     mu = __builtin_fma(mm, beta, -p);
     const double u = s * mu;

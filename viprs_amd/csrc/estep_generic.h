@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kGenericThreads) void estep_generic_kernel(EStepArg
             const int wstart = A.lb[j] - (int)s0;          // window start, component-local
             const T qj = qv[jj];
             T mu, gamma, d;
-            snp_update<EXACT, true>(A.mu_mult[j], A.std_beta[j], A.shvt[j], A.u_logs[j], A.eta[j], qj,
+            snp_update<EXACT, kLookupPerLane>(A.mu_mult[j], A.std_beta[j], A.shvt[j], A.u_logs[j], A.eta[j], qj,
                                     tab, mu, gamma, d);
             const bool skip = abs_t<T>(d) < eps;           // e_step.hpp:410
             if (!skip) {

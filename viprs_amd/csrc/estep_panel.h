@@ -167,27 +167,36 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
                     }
 
+                    // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own
+                    // q[j]); every lane executes the update arithmetic on its own values, but at
+                    // step j only lane j's result is meaningful: its scaled eta_diff is broadcast
+                    // (one v_readlane) and applied to the whole panel through row j of the
+                    // diagonal tile.  The wave is issue-bound here (one wave per chain), so the
+                    // step is written for instruction count: no input broadcasts, no branches.
                     float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
 #pragma unroll
                     for (int jj = 0; jj < kPanel; ++jj) {
                         if (jj + kChainPrefetch < kPanel)
                             drow[jj + kChainPrefetch] =
                                 static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
-                        const float qj = rl(qc, jj);
                         float mu, gamma, d;
-                        snp_update<EXACT, true>(rl(mm, jj), rl(beta, jj), rl(sv, jj), rl(ulog, jj),
-                                                rl(eta_old, jj), qj, tab, mu, gamma, d);
-                        const bool skip = (fabsf(d) < eps) || (jj > last);
-                        const float a = skip ? 0.0f : dq * d;
-                        qc = __builtin_fmaf(drow[jj], a, qc);
-                        if (!UPPER) qc = (lane == jj && !skip) ? qc - d : qc;
-                        qcap_v = (lane == jj) ? qj : qcap_v;
+                        snp_update<EXACT, kLookupLane>(mm, beta, sv, ulog, eta_old, qc, tab, mu, gamma, d, jj);
+                        // dead lanes (past a partial last panel) are forced onto the skip path
+                        const bool upd = !(fabsf(d) < eps) && live;
+                        const float a_lane = upd ? dq * d : 0.0f;
+                        // (keeps hipcc from hoisting 64 loop-invariant lane masks and spilling them)
+                        int l = lane;
+                        asm volatile("" : "+v"(l));
+                        const bool me = (l == jj);
+                        qcap_v = me ? qc : qcap_v;
+                        qc = __builtin_fmaf(drow[jj], rl(a_lane, jj), qc);
+                        if (!UPPER) qc = (me && upd) ? qc - d : qc;
                     }
 
                     // lane-parallel replay of the 64 updates (same operations, same inputs ->
                     // same bits) to produce the per-SNP outputs without serialising the stores
                     float mu, gamma, d;
-                    snp_update<EXACT, false>(mm, beta, sv, ulog, eta_old, qcap_v, tab, mu, gamma, d);
+                    snp_update<EXACT, kLookupPerLane>(mm, beta, sv, ulog, eta_old, qcap_v, tab, mu, gamma, d);
                     const bool skip = fabsf(d) < eps;
                     if (live) {
                         if (!skip) {
