@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -44,6 +45,12 @@ size_t ld_elem_size(int ld_dtype) {
     }
 }
 size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0); }
+
+// workgroup-size classes of the panel kernel (waves per workgroup; wave 0 is the chain)
+static int kLargeBlock = 1 << 30, kMediumBlock = 1536;   // (class 0 unused by default)
+constexpr int kClassWaves[3] = {16, 8, 4};
+constexpr int kEpiWaves = 4;
+constexpr int kLowerWaves = 4;
 
 template <typename V> struct DevBuf {
     V* p = nullptr;
@@ -95,8 +102,19 @@ struct viprs_plan {
     hipStream_t stream = nullptr;
     std::vector<Block> blocks;              // SNP order
     std::vector<BlockDesc> dense_h, ragged_h;  // schedule order (descending cost)
+    // dense blocks are served by panel kernels of three workgroup sizes (more updater waves =
+    // more row loads in flight = a larger share of HBM bandwidth for the larger blocks); class c
+    // covers dense_h[class_begin[c] .. class_begin[c+1])
+    int class_begin[4] = {0, 0, 0, 0};
     DevBuf<BlockDesc> d_dense, d_ragged;
+    hipStream_t class_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     DevBuf<EpiItem> d_epi;
+    DevBuf<LowerItem> d_lower;              // symmetric form: per-class lists of (block, strip)
+    int lower_begin[4] = {0, 0, 0, 0};
+    DevBuf<int32_t> d_admit;                // admission thresholds of the small-block class
+    int admit_grid = 0;
+    double admit_factor = 1.5;
     int64_t n_epi = 0;
     DevBuf<int32_t> d_lb;
     DevBuf<int64_t> d_ip;
@@ -137,6 +155,9 @@ struct viprs_state {
 viprs_plan::~viprs_plan() {
     delete scratch;
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (auto& e : ev_join) if (e) (void)hipEventDestroy(e);
+    for (auto& st : class_stream) if (st) (void)hipStreamDestroy(st);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -207,6 +228,9 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
 
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
+    if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
+    if (const char* f = getenv("VIPRS_LARGE_BLOCK")) kLargeBlock = atoi(f);
+    if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) kMediumBlock = atoi(f);
     P->low_memory = low_memory != 0;
     P->ld_dtype = ld_dtype;
     P->device = device;
@@ -221,6 +245,9 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     P->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
+    for (auto& st : P->class_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+    for (auto& e : P->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     P->ev.assign(4 * viprs_plan::kRing, nullptr);
     for (auto& e : P->ev) HIP_TRY(hipEventCreate(&e));
 
@@ -254,9 +281,18 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     };
     std::sort(P->dense_h.begin(), P->dense_h.end(), by_cost);
     std::sort(P->ragged_h.begin(), P->ragged_h.end(), by_cost);
+    {   // descending order: [large | medium | small]
+        int i = 0, n = (int)P->dense_h.size();
+        P->class_begin[0] = 0;
+        while (i < n && P->dense_h[i].size >= kLargeBlock) ++i;
+        P->class_begin[1] = i;
+        while (i < n && P->dense_h[i].size >= kMediumBlock) ++i;
+        P->class_begin[2] = i;
+        P->class_begin[3] = n;
+    }
 
     // ---- upload -------------------------------------------------------------------------------
-    HIP_TRY(P->d_counters.alloc(4));
+    HIP_TRY(P->d_counters.alloc(16));
     HIP_TRY(P->d_skipped.alloc(1));
     HIP_TRY(hipMemset(P->d_skipped.p, 0, sizeof(unsigned long long)));
     if (m > 0) {
@@ -292,6 +328,29 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
+        if (!P->low_memory) {
+            // deferred lower-left updates: one item per (block, 256-column strip) that has rows
+            // below it; per size class, descending row count
+            std::vector<LowerItem> items;
+            for (int c = 0; c < 3; ++c) {
+                P->lower_begin[c] = (int)items.size();
+                std::vector<std::pair<int, LowerItem>> cls;
+                for (int i = P->class_begin[c]; i < P->class_begin[c + 1]; ++i) {
+                    const int b = P->dense_h[i].size;
+                    for (int st = 0; st * kLowerStrip < b; ++st) {
+                        const int row_begin = (st * (kLowerStrip / kPanel) + 1) * kPanel;
+                        if (row_begin < b) cls.push_back({b - row_begin, LowerItem{(int32_t)(i - P->class_begin[c]), st}});
+                    }
+                }
+                std::stable_sort(cls.begin(), cls.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+                for (auto& e : cls) items.push_back(e.second);
+            }
+            P->lower_begin[3] = (int)items.size();
+            if (!items.empty()) {
+                HIP_TRY(P->d_lower.alloc(items.size()));
+                HIP_TRY(hipMemcpy(P->d_lower.p, items.data(), sizeof(LowerItem) * items.size(), hipMemcpyHostToDevice));
+            }
+        }
         if (P->low_memory) {
             std::vector<EpiItem> items;
             for (size_t i = 0; i < P->dense_h.size(); ++i)
@@ -440,7 +499,6 @@ int viprs_state_synchronize(viprs_state* S) {
 // ---- kernel dispatch ----------------------------------------------------------------------------
 namespace {
 
-constexpr int kPanelWaves = 4;
 
 template <typename T>
 EStepArgs<T> make_args(viprs_state* S, double dq) {
@@ -507,32 +565,91 @@ int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A) {
     }
 }
 
-template <typename U>
-int launch_panel(viprs_plan* P, EStepArgs<float> A) {
-    A.blocks = P->d_dense.p;
-    A.n_blocks = (int)P->dense_h.size();
-    A.counter = P->d_counters.p;
-    const int qcap = (P->max_dense + kPanel - 1) / kPanel * kPanel + kStrip;
+template <typename U, int NW>
+int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t stream) {
+    const int begin = P->class_begin[cls], end = P->class_begin[cls + 1];
+    if (end <= begin) return VIPRS_OK;
+    A.blocks = P->d_dense.p + begin;
+    A.n_blocks = end - begin;
+    A.counter = P->d_counters.p + 4 + cls;
+    const int max_b = P->dense_h[begin].size;      // descending order
+    const int qcap = (max_b + kPanel - 1) / kPanel * kPanel + kStrip;
     const size_t shmem = (size_t)panel_lds_floats(qcap) * sizeof(float);
     const bool exact = P->math_mode == VIPRS_MATH_EXACT;
     const bool upper = P->low_memory != 0;
     const void* kfn = nullptr;
-#define PK(UP, EX) (const void*)estep_panel_kernel<U, UP, EX, kPanelWaves>
-    if (upper) kfn = exact ? PK(true, true) : PK(true, false);
-    else kfn = exact ? PK(false, true) : PK(false, false);
+#define PK(SY, EX) (const void*)estep_panel_kernel<U, SY, EX, NW>
+    if (upper) kfn = exact ? PK(false, true) : PK(false, false);
+    else kfn = exact ? PK(true, true) : PK(true, false);
 #undef PK
     if (shmem > 160 * 1024) return fail(VIPRS_EUNSUPPORTED, "LD block too large for the LDS-resident panel kernel");
     if (shmem > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPanelWaves * 64, shmem));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NW * 64, shmem));
     per_cu = std::max(1, per_cu);
     const int grid = std::min<int>(A.n_blocks, P->n_cu * per_cu);
+    A.admit = nullptr;
+    if (cls == 2 && P->admit_factor > 0.0) {
+        if (P->admit_grid != grid) {
+            // Concurrency needed to keep HBM busy while the head is at a block of b SNPs:
+            // a workgroup streams 64 rows x b columns per chain phase (~10 us), i.e. about
+            // kRatePerSnp * b bytes/s; need ~kHbmRate in total.  The larger classes (their own
+            // kernels, never gated) are credited with their demand.
+            const double kRatePerSnp = 64.0 * 4.0 / 10.5e-6, kHbmRate = 5.5e12;
+            double big_demand = 0.0;
+            for (int i = 0; i < begin; ++i) big_demand += std::min(9.0e10, kRatePerSnp * P->dense_h[i].size);
+            std::vector<int32_t> th((size_t)grid, 0);
+            int r = 0;
+            for (int n = 0; n < A.n_blocks && r < grid; ++n) {
+                const double b = P->dense_h[begin + n].size;
+                // the big-class kernels drain while the small class advances; credit them linearly
+                const double credit = big_demand * std::max(0.0, 1.0 - 2.0 * n / (double)A.n_blocks);
+                double need = P->admit_factor * std::max(0.0, kHbmRate - credit) / (kRatePerSnp * b);
+                int allowed = (int)std::min<double>(grid, std::max(64.0, need));
+                while (r < allowed) th[(size_t)r++] = n;
+            }
+            while (r < grid) th[(size_t)r++] = A.n_blocks;
+            HIP_TRY(P->d_admit.alloc((size_t)grid));
+            HIP_TRY(hipMemcpy(P->d_admit.p, th.data(), sizeof(int32_t) * (size_t)grid, hipMemcpyHostToDevice));
+            P->admit_grid = grid;
+        }
+        A.admit = P->d_admit.p;
+    }
     void* params[] = {(void*)&A, (void*)&qcap};
-    HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(kPanelWaves * 64), params, shmem, P->stream));
-    if (upper && P->n_epi > 0) {
-        const int eg = (int)((P->n_epi + kPanelWaves - 1) / kPanelWaves);
-        estep_upper_epilogue_kernel<U, kPanelWaves><<<eg, kPanelWaves * 64, 0, P->stream>>>(A, P->d_epi.p, (int)P->n_epi);
+    HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(NW * 64), params, shmem, stream));
+    if (!upper) {
+        // deferred lower-left updates of this class, right behind its panel kernel
+        const int lb = P->lower_begin[cls], ln = P->lower_begin[cls + 1] - lb;
+        if (ln > 0) {
+            const int lgrid = std::min((ln + kLowerWaves - 1) / kLowerWaves, P->n_cu * 8);
+            estep_sym_lower_kernel<U, kLowerWaves><<<lgrid, kLowerWaves * 64, 0, stream>>>(
+                A, P->d_lower.p + lb, ln, P->d_counters.p + 8 + cls);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return VIPRS_OK;
+}
+
+// Panel kernels of the three size classes run concurrently on their own streams (forked from /
+// joined back into the plan's stream with events); the upper-triangular second pass follows.
+template <typename U>
+int launch_panel(viprs_plan* P, EStepArgs<float> A) {
+    HIP_TRY(hipEventRecord(P->ev_fork, P->stream));
+    int rc;
+    for (int c = 0; c < 3; ++c) HIP_TRY(hipStreamWaitEvent(P->class_stream[c], P->ev_fork, 0));
+    if ((rc = launch_panel_class<U, kClassWaves[0]>(P, A, 0, P->class_stream[0])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[1]>(P, A, 1, P->class_stream[1])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[2]>(P, A, 2, P->class_stream[2])) != VIPRS_OK) return rc;
+    for (int c = 0; c < 3; ++c) {
+        HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
+        HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join[c], 0));
+    }
+    if (P->low_memory && P->n_epi > 0) {
+        A.blocks = P->d_dense.p;
+        A.n_blocks = (int)P->dense_h.size();
+        const int eg = (int)((P->n_epi + kEpiWaves - 1) / kEpiWaves);
+        estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, P->stream>>>(A, P->d_epi.p, (int)P->n_epi);
         HIP_TRY(hipGetLastError());
     }
     return VIPRS_OK;
@@ -541,7 +658,7 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A) {
 int run_spike_slab(viprs_state* S, double dq) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    HIP_TRY(hipMemsetAsync(P->d_counters.p, 0, 4 * sizeof(int32_t), P->stream));
+    HIP_TRY(hipMemsetAsync(P->d_counters.p, 0, 16 * sizeof(int32_t), P->stream));
     HIP_TRY(hipMemsetAsync(P->d_skipped.p, 0, sizeof(unsigned long long), P->stream));
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     HIP_TRY(hipEventRecord(ev[0], P->stream));

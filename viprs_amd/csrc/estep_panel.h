@@ -11,16 +11,21 @@
 //                        chain redundantly, lane i owns q[p*64 + i], the diagonal-tile rows are
 //                        streamed from HBM 16 rows ahead of their use.
 //   waves 1.. ("updaters") while the chain solves panel p they apply a_{p-1} -- the trailing
-//                        rank-64 update -- to every other column of the block: each lane owns 4
+//                        rank-64 update -- to every column RIGHT of panel p: each lane owns 4
 //                        columns, walks the 64 rows of panel p-1 in order (one coalesced 16-byte
 //                        load per lane per row) and performs q[c] = fma(R[j][c], a_j, q[c]);
 //                        they also stage tile R[p, p+1] into LDS for the chain's next phase.
 //
-// Per q-entry the sequence of fma operations is exactly the reference's (row j before row j+1),
-// so with VIPRS_MATH_EXACT the block's outputs are bit-identical to e_step.hpp in symmetric mode.
-// In upper-triangular mode (low_memory) only columns right of the diagonal are touched here and
-// the reference's second pass (update_q_factor, e_step.hpp:331-337) runs as its own fully
-// parallel kernel (estep_upper_epilogue_kernel below).
+// Only the part of the sweep that the serial chain depends on runs here: the updates of columns
+// LEFT of the current panel (q of SNPs already visited) are not needed again in this sweep, so
+// they are deferred to a second, fully parallel kernel:
+//   symmetric form   estep_sym_lower_kernel: column c receives rows (panel(c)+1)*64 .. b-1 in row
+//                    order, q[c] = fma(R[j][c], dq*eta_diff[j], q[c]) -- the same fma chain per
+//                    q-entry as the reference's row-by-row axpy, so results stay bit-identical;
+//   upper-tri form   estep_upper_epilogue_kernel: the reference's own second pass
+//                    (update_q_factor, e_step.hpp:331-337).
+// This halves the bytes a single workgroup (= one CU, ~50 GB/s from HBM) must pull for a large
+// block and makes the other half perfectly balanced over the chip.
 #pragma once
 #include "device_math.h"
 #include "kernels_common.h"
@@ -96,7 +101,7 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
     *reinterpret_cast<float4*>(lq_c) = qv;
 }
 
-template <typename U, bool UPPER, bool EXACT, int NW>
+template <typename U, bool SYM, bool EXACT, int NW>
 __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A, int qcap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lq = smem;
@@ -113,6 +118,20 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     unsigned long long my_skipped = 0;
     const float eps = Eps<float>::value;
     const float dq = A.dq;
+
+    // Admission control (optional; thresholds computed by the host).  Blocks are queued in
+    // descending size; workgroup r starts pulling work only once the queue head has reached
+    // admit[r].  The head only moves forward and workgroup 0 is never gated: no deadlock.
+    if (A.admit != nullptr) {
+        const int th = A.admit[blockIdx.x];
+        if (th > 0) {
+            if (tid == 0) {
+                while (__hip_atomic_load(A.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < th)
+                    __builtin_amdgcn_s_sleep(64);
+            }
+            __syncthreads();
+        }
+    }
 
     for (;;) {
         if (tid == 0) s_blk = atomicAdd(A.counter, 1);
@@ -134,19 +153,42 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
 
         float a_prev = 0.0f;   // chain wave: lane j = dq * eta_diff of SNP j of the previous panel
 
-        for (int p = 0; p <= np; ++p) {
+        // ---- chain wave: inputs and first diagonal-tile rows of the NEXT panel, fetched under the
+        //      current panel's serial updates so that no HBM latency sits between two panels
+        float n_mm = 0.0f, n_beta = 0.0f, n_sv = 0.0f, n_ulog = 0.0f, n_eta = 0.0f;
+        float dnext[kChainPrefetch];
+        if (wave == 0) {
+            const bool live0 = lane < b;
+            const int64_t j0 = s0 + (live0 ? lane : 0);
+            n_mm = live0 ? A.mu_mult[j0] : 0.0f;
+            n_beta = live0 ? A.std_beta[j0] : 0.0f;
+            n_sv = live0 ? A.shvt[j0] : 0.0f;
+            n_ulog = live0 ? A.u_logs[j0] : 0.0f;
+            n_eta = live0 ? A.eta[j0] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < kChainPrefetch; ++k)
+                dnext[k] = static_cast<float>(base[(int64_t)min(k, b - 1) * stride + lane]);
+        }
+
+        for (int p = 0; p < np; ++p) {
             if (wave == 0) {
                 // ================================ chain ======================================
-                if (p < np) {
+                {
                     const int r0 = p * kPanel;
                     const int nrows = min(kPanel, b - r0);
                     const int64_t j = s0 + r0 + lane;
                     const bool live = lane < nrows;
-                    const float mm = live ? A.mu_mult[j] : 0.0f;
-                    const float beta = live ? A.std_beta[j] : 0.0f;
-                    const float sv = live ? A.shvt[j] : 0.0f;
-                    const float ulog = live ? A.u_logs[j] : 0.0f;
-                    const float eta_old = live ? A.eta[j] : 0.0f;
+                    const float mm = n_mm, beta = n_beta, sv = n_sv, ulog = n_ulog, eta_old = n_eta;
+                    {   // next panel's inputs (consumed one phase later)
+                        const int rn = r0 + kPanel + lane;
+                        const bool ln = rn < b;
+                        const int64_t jn = s0 + (ln ? rn : 0);
+                        n_mm = ln ? A.mu_mult[jn] : 0.0f;
+                        n_beta = ln ? A.std_beta[jn] : 0.0f;
+                        n_sv = ln ? A.shvt[jn] : 0.0f;
+                        n_ulog = ln ? A.u_logs[jn] : 0.0f;
+                        n_eta = ln ? A.eta[jn] : 0.0f;
+                    }
 
                     // diagonal tile rows, streamed kChainPrefetch rows ahead.  All 64 steps always
                     // run, straight-line (no runtime guards around loads, see strip_update): rows
@@ -156,8 +198,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const U* __restrict__ dptr = base + (int64_t)r0 * stride + r0 + lane;
                     float drow[kPanel];
 #pragma unroll
-                    for (int k = 0; k < kChainPrefetch; ++k)
-                        drow[k] = static_cast<float>(dptr[(int64_t)min(k, last) * stride]);
+                    for (int k = 0; k < kChainPrefetch; ++k) drow[k] = dnext[k];
+                    // first rows of the next panel's diagonal tile (clamped to the block when there
+                    // is no next panel: loaded, never used)
+                    const int rn0 = min(r0 + kPanel, bpad - kPanel);
+                    const U* __restrict__ nptr = base + (int64_t)rn0 * stride + rn0 + lane;
 
                     float qc = lq[r0 + lane];
                     if (p > 0) {
@@ -179,6 +224,9 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         if (jj + kChainPrefetch < kPanel)
                             drow[jj + kChainPrefetch] =
                                 static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
+                        else
+                            dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
+                                nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
                         float mu, gamma, d;
                         snp_update<EXACT, kLookupLane>(mm, beta, sv, ulog, eta_old, qc, tab, mu, gamma, d, jj);
                         // dead lanes (past a partial last panel) are forced onto the skip path
@@ -190,7 +238,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         const bool me = (l == jj);
                         qcap_v = me ? qc : qcap_v;
                         qc = __builtin_fmaf(drow[jj], rl(a_lane, jj), qc);
-                        if (!UPPER) qc = (me && upd) ? qc - d : qc;
+                        if (SYM) qc = (me && upd) ? qc - d : qc;   // e_step.hpp:427 (diagonal entry of the symmetric form)
                     }
 
                     // lane-parallel replay of the 64 updates (same operations, same inputs ->
@@ -236,8 +284,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         for (int s = uw; s < nstrips; s += NW - 1) {
                             const int c = s * kStrip + 4 * lane;
                             const int cp = c >> 6;
-                            bool active = (c < b) && (cp != pp) && (cp != p);
-                            if (UPPER) active = active && (cp > p);
+                            const bool active = (c < b) && (cp > p);   // right of the chain's panels only
                             if (active) {
                                 if (last_row == kPanel - 1)
                                     strip_update<U, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
@@ -254,6 +301,90 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
         __syncthreads();
     }
     if (lane == 0 && my_skipped) atomicAdd(A.skipped, my_skipped);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric form, deferred lower-left updates: for column c of a block, apply rows
+// (panel(c)+1)*64 .. b-1 in row order: q[c] = fma(R[j][c], dq * eta_diff[j], q[c]).
+// (eta_diff[j] == 0 for SNPs that took the skip branch, which makes their rows exact no-ops,
+// as in the reference where the axpy is not executed.)  One wave owns 256 columns (4 per lane,
+// one 16-byte load per lane per row), items come from a work queue in descending row count.
+// ---------------------------------------------------------------------------------------------
+struct LowerItem { int32_t blk; int32_t strip; };
+
+constexpr int kLowerCols = 2;                       // columns per lane
+constexpr int kLowerStrip = 64 * kLowerCols;        // columns per wave (whole panels)
+constexpr int kLowerPrefetch = 32;                  // row loads in flight per lane
+
+template <typename U> struct LdVec2;
+template <> struct LdVec2<float> {
+    static __device__ __forceinline__ float2 load(const float* p) { return *reinterpret_cast<const float2*>(p); }
+};
+template <> struct LdVec2<int8_t> {
+    static __device__ __forceinline__ float2 load(const int8_t* p) {
+        const short w = *reinterpret_cast<const short*>(p);
+        return make_float2((float)(int8_t)(w), (float)(int8_t)(w >> 8));
+    }
+};
+template <> struct LdVec2<int16_t> {
+    static __device__ __forceinline__ float2 load(const int16_t* p) {
+        const int w = *reinterpret_cast<const int*>(p);
+        return make_float2((float)(int16_t)(w), (float)(int16_t)(w >> 16));
+    }
+};
+
+template <typename U, int NW>
+__global__ __launch_bounds__(NW * 64) void estep_sym_lower_kernel(EStepArgs<float> A, const LowerItem* items,
+                                                                  int n_items, int32_t* counter) {
+    const int lane = threadIdx.x & 63;
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const float dq = A.dq;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const LowerItem it = items[item];
+        const BlockDesc bd = A.blocks[it.blk];
+        const int b = bd.size, stride = bd.stride;
+        const int64_t s0 = bd.start;
+        const U* __restrict__ base = ldd + bd.ld_off;
+        const int c = it.strip * kLowerStrip + kLowerCols * lane;
+        const int cc = min(c, stride - kLowerCols);        // lanes past the block read padding (zeros)
+        const int cp = c >> 6;
+        const bool active = c < b;
+        float2 qv = make_float2(0.f, 0.f);
+        if (active) {
+            qv.x = A.q[s0 + c];
+            if (c + 1 < b) qv.y = A.q[s0 + c + 1];
+        }
+        const int row_begin = (it.strip * (kLowerStrip / kPanel) + 1) * kPanel;   // first row any lane needs
+        const U* __restrict__ colp = base + cc;
+        float2 buf[kLowerPrefetch];
+#pragma unroll
+        for (int k = 0; k < kLowerPrefetch; ++k)
+            buf[k] = LdVec2<U>::load(colp + (int64_t)min(row_begin + k, b - 1) * stride);
+        for (int r0 = row_begin; r0 < b; r0 += kLowerPrefetch) {
+            // a-values of this row group, lane k = row r0 + k
+            const int rk = r0 + (lane & (kLowerPrefetch - 1));
+            const float av = (rk < b) ? dq * A.eta_diff[s0 + rk] : 0.0f;
+            const bool mine = (r0 >> 6) > cp;              // rows of a later panel than this lane's columns
+#pragma unroll
+            for (int k = 0; k < kLowerPrefetch; ++k) {
+                const float2 v = buf[k];
+                buf[k] = LdVec2<U>::load(colp + (int64_t)min(r0 + kLowerPrefetch + k, b - 1) * stride);
+                float a = rl(av, k);
+                a = mine ? a : 0.0f;
+                qv.x = __builtin_fmaf(v.x, a, qv.x);
+                qv.y = __builtin_fmaf(v.y, a, qv.y);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (active) {
+            A.q[s0 + c] = qv.x;
+            if (c + 1 < b) A.q[s0 + c + 1] = qv.y;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

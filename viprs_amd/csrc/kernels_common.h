@@ -23,6 +23,7 @@ struct EStepArgs {
     const BlockDesc* blocks;     // schedule order (descending cost)
     int32_t n_blocks;
     int32_t* counter;            // work-queue head (zeroed before every launch)
+    const int32_t* admit;        // per-workgroup admission threshold on the queue head (may be null)
     unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
     // raw LD as the caller laid it out (generic kernel)
     const int32_t* lb;
