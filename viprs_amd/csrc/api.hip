@@ -118,6 +118,8 @@ struct viprs_plan {
     int64_t n_epi = 0;
     DevBuf<int32_t> d_lb;
     DevBuf<int64_t> d_ip;
+    DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
+    DevBuf<int64_t> d_rowstart_dense;       // row starts inside the repacked dense buffer (generic kernels)
     DevBuf<char> d_ld_raw;                  // kept only when ragged blocks exist
     DevBuf<char> d_ld_dense;
     int64_t dense_elems = 0;
@@ -140,6 +142,7 @@ struct viprs_state {
     int model_kind = VIPRS_MODEL_SPIKE_SLAB;
     int width = 1;
     DevBuf<char> f[VIPRS_FIELD_COUNT];
+    DevBuf<int32_t> d_active;               // grid: active model indices of the current call
     size_t field_elems(int field) const {
         const size_t m = (size_t)plan->m;
         switch (field) {
@@ -300,6 +303,20 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         HIP_TRY(P->d_ip.alloc((size_t)m + 1));
         HIP_TRY(hipMemcpy(P->d_lb.p, lb, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(P->d_ip.p, ip64.data(), sizeof(int64_t) * ((size_t)m + 1), hipMemcpyHostToDevice));
+        std::vector<int32_t> rowlen((size_t)m);
+        for (int64_t j = 0; j < m; ++j) rowlen[(size_t)j] = (int32_t)(ip64[(size_t)j + 1] - ip64[(size_t)j]);
+        HIP_TRY(P->d_rowlen.alloc((size_t)m));
+        HIP_TRY(hipMemcpy(P->d_rowlen.p, rowlen.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice));
+        if (!P->dense_h.empty()) {
+            // element (row r, column c) of a repacked block sits at ld_off + r*stride + c; the row's
+            // window starts at column 0 (symmetric) or r + 1 (upper-triangular)
+            std::vector<int64_t> rs((size_t)m, 0);
+            for (const BlockDesc& d : P->dense_h)
+                for (int r = 0; r < d.size; ++r)
+                    rs[(size_t)d.start + r] = d.ld_off + (int64_t)r * d.stride + (P->low_memory ? r + 1 : 0);
+            HIP_TRY(P->d_rowstart_dense.alloc((size_t)m));
+            HIP_TRY(hipMemcpy(P->d_rowstart_dense.p, rs.data(), sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice));
+        }
     }
     if (P->nnz > 0) {
         HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es));
@@ -506,8 +523,9 @@ EStepArgs<T> make_args(viprs_state* S, double dq) {
     EStepArgs<T> A{};
     A.skipped = P->d_skipped.p;
     A.lb = P->d_lb.p;
-    A.ip = P->d_ip.p;
-    A.ld_raw = P->d_ld_raw.p;
+    A.rowstart = P->d_ip.p;
+    A.rowlen = P->d_rowlen.p;
+    A.ld_rows = P->d_ld_raw.p;
     A.ld_dense = P->d_ld_dense.p;
     A.std_beta = (const T*)S->f[VIPRS_FIELD_STD_BETA].p;
     A.u_logs = (const T*)S->f[VIPRS_FIELD_U_LOGS].p;
@@ -526,41 +544,60 @@ EStepArgs<T> make_args(viprs_state* S, double dq) {
     return A;
 }
 
+enum { kGenSpikeSlab = 0, kGenMixture = 1, kGenGrid = 2 };
+
+// Generic kernels over one block list: `dense` = the repacked dense blocks (addressed through
+// d_rowstart_dense), otherwise the ragged blocks in the caller's own layout.
 template <typename T, typename U>
-int launch_generic(viprs_plan* P, EStepArgs<T> A) {
-    A.blocks = P->d_ragged.p;
-    A.n_blocks = (int)P->ragged_h.size();
-    A.counter = P->d_counters.p + 1;
-    const size_t need = 2 * (size_t)P->max_ragged * sizeof(T);
+int launch_generic(viprs_plan* P, EStepArgs<T> A, int model, bool dense) {
+    const std::vector<BlockDesc>& list = dense ? P->dense_h : P->ragged_h;
+    if (list.empty()) return VIPRS_OK;
+    A.blocks = dense ? P->d_dense.p : P->d_ragged.p;
+    A.n_blocks = (int)list.size();
+    A.counter = P->d_counters.p + (dense ? 2 : 1);
+    if (dense) {
+        A.rowstart = P->d_rowstart_dense.p;
+        A.ld_rows = P->d_ld_dense.p;
+    }
+    const int max_b = dense ? P->max_dense : P->max_ragged;
+    const size_t need = 2 * (size_t)max_b * sizeof(T);
     const bool in_lds = need <= 128 * 1024;
     const size_t shmem = in_lds ? need : 0;
     const int grid = std::min<int>(A.n_blocks, P->n_cu * 2);
     const bool exact = P->math_mode == VIPRS_MATH_EXACT;
-#define GEN_LAUNCH(EX, INL)                                                                                   \
+#define GEN_LAUNCH(KFN, SH)                                                                                   \
     do {                                                                                                      \
-        auto kfn = estep_generic_kernel<T, U, EX, INL>;                                                       \
-        if (shmem > 48 * 1024)                                                                                \
-            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-        kfn<<<grid, kGenericThreads, shmem, P->stream>>>(A);                                                  \
+        auto kfn = KFN;                                                                                       \
+        if ((SH) > 48 * 1024)                                                                                 \
+            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SH))); \
+        kfn<<<grid, kGenericThreads, (SH), P->stream>>>(A);                                                   \
     } while (0)
-    if (exact && in_lds) GEN_LAUNCH(true, true);
-    else if (exact) GEN_LAUNCH(true, false);
-    else if (in_lds) GEN_LAUNCH(false, true);
-    else GEN_LAUNCH(false, false);
+    if (model == kGenSpikeSlab) {
+        if (exact && in_lds) GEN_LAUNCH((estep_generic_kernel<T, U, true, true>), shmem);
+        else if (exact) GEN_LAUNCH((estep_generic_kernel<T, U, true, false>), shmem);
+        else if (in_lds) GEN_LAUNCH((estep_generic_kernel<T, U, false, true>), shmem);
+        else GEN_LAUNCH((estep_generic_kernel<T, U, false, false>), shmem);
+    } else if (model == kGenMixture) {
+        if (A.width > kMaxMixtureK) return fail(VIPRS_EUNSUPPORTED, "mixture: K > 64 is not supported");
+        if (in_lds) GEN_LAUNCH((estep_mixture_generic_kernel<T, U, true>), shmem);
+        else GEN_LAUNCH((estep_mixture_generic_kernel<T, U, false>), shmem);
+    } else {
+        GEN_LAUNCH((estep_grid_generic_kernel<T, U>), (size_t)0);
+    }
 #undef GEN_LAUNCH
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
 }
 
 template <typename T>
-int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A) {
+int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A, int model, bool dense) {
     switch (P->ld_dtype) {
-        case VIPRS_LD_I8: return launch_generic<T, int8_t>(P, A);
-        case VIPRS_LD_I16: return launch_generic<T, int16_t>(P, A);
-        case VIPRS_LD_I32: return launch_generic<T, int32_t>(P, A);
-        case VIPRS_LD_I64: return launch_generic<T, int64_t>(P, A);
-        case VIPRS_LD_F32: return launch_generic<T, float>(P, A);
-        case VIPRS_LD_F64: return launch_generic<T, double>(P, A);
+        case VIPRS_LD_I8: return launch_generic<T, int8_t>(P, A, model, dense);
+        case VIPRS_LD_I16: return launch_generic<T, int16_t>(P, A, model, dense);
+        case VIPRS_LD_I32: return launch_generic<T, int32_t>(P, A, model, dense);
+        case VIPRS_LD_I64: return launch_generic<T, int64_t>(P, A, model, dense);
+        case VIPRS_LD_F32: return launch_generic<T, float>(P, A, model, dense);
+        case VIPRS_LD_F64: return launch_generic<T, double>(P, A, model, dense);
         default: return fail(VIPRS_EINVAL, "bad LD dtype");
     }
 }
@@ -676,13 +713,43 @@ int run_spike_slab(viprs_state* S, double dq) {
             if (rc != VIPRS_OK) return rc;
             HIP_TRY(hipEventRecord(ev[3], P->stream));
         }
-        if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A);
+        if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A, kGenSpikeSlab, false);
     } else {
-        // float64 state: every block takes the generic kernel (dense_h is empty by construction
-        // only for non-panel LD dtypes, so route dense blocks through the generic path as well)
-        return fail(VIPRS_EUNSUPPORTED, "float64 state requires a plan created for the generic path");
+        // float64 state: the panel kernels specialise float; every block takes the generic kernel
+        EStepArgs<double> A = make_args<double>(S, dq);
+        rc = launch_generic_u<double>(P, A, kGenSpikeSlab, true);
+        if (rc == VIPRS_OK) rc = launch_generic_u<double>(P, A, kGenSpikeSlab, false);
     }
     if (rc != VIPRS_OK) return rc;
+    HIP_TRY(hipEventRecord(ev[1], P->stream));
+    P->sweeps++;
+    return VIPRS_OK;
+}
+
+// mixture / grid: generic kernels over every block (dense blocks through the repacked layout)
+int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_active, int n_active) {
+    viprs_plan* P = S->plan;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipMemsetAsync(P->d_counters.p, 0, 16 * sizeof(int32_t), P->stream));
+    hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
+    HIP_TRY(hipEventRecord(ev[0], P->stream));
+    HIP_TRY(hipEventRecord(ev[2], P->stream));
+    int rc;
+    if (S->float_dtype == VIPRS_F32) {
+        EStepArgs<float> A = make_args<float>(S, dq);
+        A.active = d_active;
+        A.n_active = n_active;
+        rc = launch_generic_u<float>(P, A, model, true);
+        if (rc == VIPRS_OK) rc = launch_generic_u<float>(P, A, model, false);
+    } else {
+        EStepArgs<double> A = make_args<double>(S, dq);
+        A.active = d_active;
+        A.n_active = n_active;
+        rc = launch_generic_u<double>(P, A, model, true);
+        if (rc == VIPRS_OK) rc = launch_generic_u<double>(P, A, model, false);
+    }
+    if (rc != VIPRS_OK) return rc;
+    HIP_TRY(hipEventRecord(ev[3], P->stream));
     HIP_TRY(hipEventRecord(ev[1], P->stream));
     P->sweeps++;
     return VIPRS_OK;
@@ -694,11 +761,30 @@ extern "C" {
 
 int viprs_state_e_step(viprs_state* S, double dq_scale, const int32_t* active, int n_active, int sync) {
     if (!S) return fail(VIPRS_EINVAL, "null state");
-    (void)active; (void)n_active;
     int rc;
     switch (S->model_kind) {
         case VIPRS_MODEL_SPIKE_SLAB: rc = run_spike_slab(S, dq_scale); break;
-        default: return fail(VIPRS_EUNSUPPORTED, "model kind not implemented yet");
+        case VIPRS_MODEL_MIXTURE: rc = run_generic_model(S, dq_scale, kGenMixture, nullptr, 0); break;
+        case VIPRS_MODEL_GRID: {
+            std::vector<int32_t> all;
+            if (!active) {                                    // default: every model is active
+                all.resize((size_t)S->width);
+                for (int g = 0; g < S->width; ++g) all[(size_t)g] = g;
+                active = all.data();
+                n_active = S->width;
+            }
+            for (int i = 0; i < n_active; ++i)
+                if (active[i] < 0 || active[i] >= S->width) return fail(VIPRS_EINVAL, "active_model_idx out of range");
+            if (n_active == 0) return VIPRS_OK;
+            HIP_TRY(hipSetDevice(S->plan->device));
+            if (S->d_active.n < (size_t)n_active) HIP_TRY(S->d_active.alloc((size_t)std::max(n_active, S->width)));
+            HIP_TRY(hipMemcpyAsync(S->d_active.p, active, sizeof(int32_t) * (size_t)n_active, hipMemcpyHostToDevice,
+                                   S->plan->stream));
+            HIP_TRY(hipStreamSynchronize(S->plan->stream));   // `active` may be a temporary
+            rc = run_generic_model(S, dq_scale, kGenGrid, S->d_active.p, n_active);
+            break;
+        }
+        default: return fail(VIPRS_EINVAL, "bad model kind");
     }
     if (rc != VIPRS_OK) return rc;
     if (sync) HIP_TRY(hipStreamSynchronize(S->plan->stream));
@@ -739,14 +825,80 @@ int viprs_e_step(viprs_plan* P, int float_dtype, const void* std_beta, void* var
     return VIPRS_OK;
 }
 
-int viprs_e_step_mixture(viprs_plan*, int, int, const void*, void*, void*, void*, void*, void*, const void*,
-                         const void*, const void*, const void*, double, int, int) {
-    return fail(VIPRS_EUNSUPPORTED, "viprs_e_step_mixture: not implemented yet");
+static int scratch_state(viprs_plan* P, int float_dtype, int model_kind, int width, viprs_state** out) {
+    viprs_state* S = P->scratch;
+    if (!S || S->float_dtype != float_dtype || S->model_kind != model_kind || S->width != width) {
+        delete P->scratch;
+        P->scratch = nullptr;
+        int rc = viprs_state_create(&P->scratch, P, float_dtype, model_kind, width);
+        if (rc != VIPRS_OK) return rc;
+    }
+    *out = P->scratch;
+    return VIPRS_OK;
 }
 
-int viprs_e_step_grid(viprs_plan*, int, int, const void*, void*, void*, void*, void*, void*, const void*,
-                      const void*, const void*, double, const int32_t*, int, int, int) {
-    return fail(VIPRS_EUNSUPPORTED, "viprs_e_step_grid: not implemented yet");
+static int one_shot(viprs_state* S, const void* const* ins, const int* in_fields, int n_in, void* const* outs,
+                    const int* out_fields, int n_out, double dq, const int32_t* active, int n_active) {
+    viprs_plan* P = S->plan;
+    const size_t fs = float_size(S->float_dtype);
+    HIP_TRY(hipSetDevice(P->device));
+    for (int i = 0; i < n_in; ++i) {
+        const size_t bytes = S->field_elems(in_fields[i]) * fs;
+        if (bytes == 0) continue;
+        if (!ins[i]) return fail(VIPRS_EINVAL, "null buffer");
+        HIP_TRY(hipMemcpyAsync(S->f[in_fields[i]].p, ins[i], bytes, hipMemcpyHostToDevice, P->stream));
+    }
+    int rc = viprs_state_e_step(S, dq, active, n_active, 0);
+    if (rc != VIPRS_OK) return rc;
+    for (int i = 0; i < n_out; ++i) {
+        const size_t bytes = S->field_elems(out_fields[i]) * fs;
+        HIP_TRY(hipMemcpyAsync(outs[i], S->f[out_fields[i]].p, bytes, hipMemcpyDeviceToHost, P->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return VIPRS_OK;
+}
+
+int viprs_e_step_mixture(viprs_plan* P, int float_dtype, int K, const void* std_beta, void* var_gamma, void* var_mu,
+                         void* eta, void* q, void* eta_diff, const void* log_null_pi, const void* u_logs,
+                         const void* shvt, const void* mu_mult, double dq_scale, int threads, int low_memory) {
+    (void)threads;
+    if (!P) return fail(VIPRS_EINVAL, "null plan");
+    if ((low_memory != 0) != (P->low_memory != 0))
+        return fail(VIPRS_EINVAL, "low_memory differs from the value the plan was created with");
+    if (K < 1) return fail(VIPRS_EINVAL, "K must be >= 1");
+    if (P->m == 0) return VIPRS_OK;
+    viprs_state* S = nullptr;
+    int rc = scratch_state(P, float_dtype, VIPRS_MODEL_MIXTURE, K, &S);
+    if (rc != VIPRS_OK) return rc;
+    const void* ins[] = {std_beta, log_null_pi, u_logs, shvt, mu_mult, var_gamma, var_mu, eta, q, eta_diff};
+    const int in_fields[] = {VIPRS_FIELD_STD_BETA, VIPRS_FIELD_LOG_NULL_PI, VIPRS_FIELD_U_LOGS,
+                             VIPRS_FIELD_SQRT_HALF_VAR_TAU, VIPRS_FIELD_MU_MULT, VIPRS_FIELD_VAR_GAMMA,
+                             VIPRS_FIELD_VAR_MU, VIPRS_FIELD_ETA, VIPRS_FIELD_Q, VIPRS_FIELD_ETA_DIFF};
+    void* outs[] = {var_gamma, var_mu, eta, q, eta_diff};
+    const int out_fields[] = {VIPRS_FIELD_VAR_GAMMA, VIPRS_FIELD_VAR_MU, VIPRS_FIELD_ETA, VIPRS_FIELD_Q, VIPRS_FIELD_ETA_DIFF};
+    return one_shot(S, ins, in_fields, 10, outs, out_fields, 5, dq_scale, nullptr, 0);
+}
+
+int viprs_e_step_grid(viprs_plan* P, int float_dtype, int G, const void* std_beta, void* var_gamma, void* var_mu,
+                      void* eta, void* q, void* eta_diff, const void* u_logs, const void* half_var_tau,
+                      const void* mu_mult, double dq_scale, const int32_t* active_model_idx, int n_active, int threads,
+                      int low_memory) {
+    (void)threads;
+    if (!P) return fail(VIPRS_EINVAL, "null plan");
+    if ((low_memory != 0) != (P->low_memory != 0))
+        return fail(VIPRS_EINVAL, "low_memory differs from the value the plan was created with");
+    if (G < 1) return fail(VIPRS_EINVAL, "G must be >= 1");
+    if (n_active < 0 || (n_active > 0 && !active_model_idx)) return fail(VIPRS_EINVAL, "bad active_model_idx");
+    if (P->m == 0 || n_active == 0) return VIPRS_OK;
+    viprs_state* S = nullptr;
+    int rc = scratch_state(P, float_dtype, VIPRS_MODEL_GRID, G, &S);
+    if (rc != VIPRS_OK) return rc;
+    const void* ins[] = {std_beta, u_logs, half_var_tau, mu_mult, var_gamma, var_mu, eta, q, eta_diff};
+    const int in_fields[] = {VIPRS_FIELD_STD_BETA, VIPRS_FIELD_U_LOGS, VIPRS_FIELD_SQRT_HALF_VAR_TAU, VIPRS_FIELD_MU_MULT,
+                             VIPRS_FIELD_VAR_GAMMA, VIPRS_FIELD_VAR_MU, VIPRS_FIELD_ETA, VIPRS_FIELD_Q, VIPRS_FIELD_ETA_DIFF};
+    void* outs[] = {var_gamma, var_mu, eta, q, eta_diff};
+    const int out_fields[] = {VIPRS_FIELD_VAR_GAMMA, VIPRS_FIELD_VAR_MU, VIPRS_FIELD_ETA, VIPRS_FIELD_Q, VIPRS_FIELD_ETA_DIFF};
+    return one_shot(S, ins, in_fields, 9, outs, out_fields, 5, dq_scale, active_model_idx, n_active);
 }
 
 static int sweep_ms(viprs_plan* P, int64_t sweep, int which, double* ms) {

@@ -25,10 +25,13 @@ struct EStepArgs {
     int32_t* counter;            // work-queue head (zeroed before every launch)
     const int32_t* admit;        // per-workgroup admission threshold on the queue head (may be null)
     unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
-    // raw LD as the caller laid it out (generic kernel)
+    // row addressing for the generic kernels: row j holds rowlen[j] elements starting at element
+    // rowstart[j] of ld_rows, covering columns lb[j] .. lb[j] + rowlen[j] - 1.  (Either the caller's
+    // own concatenated layout or the repacked dense blocks, see api.hip.)
     const int32_t* lb;
-    const int64_t* ip;
-    const void* ld_raw;
+    const int64_t* rowstart;
+    const int32_t* rowlen;
+    const void* ld_rows;
     // repacked dense blocks (panel kernels)
     const void* ld_dense;
     // per-SNP vectors

@@ -49,7 +49,9 @@ def _ar1_row(b, rho, dtype, quant_max):
     pw = np.power(np.float64(rho), np.arange(b))
     if quant_max is None:
         return pw.astype(dtype)
-    return np.round(pw * quant_max).astype(dtype)          # magenpy-style symmetric int quantisation
+    # magenpy-style symmetric int quantisation (the scale is capped at 2^52 so that the int32/int64
+    # storage types of the Cython boundary stay exactly representable in the float64 intermediate)
+    return np.round(pw * min(float(quant_max), 2.0 ** 30 if dtype == np.int32 else 2.0 ** 52)).astype(dtype)
 
 
 def _fill_block(data, off, b, row, low_memory):
