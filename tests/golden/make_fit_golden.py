@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/fit_*.npz by importing the REFERENCE's own Python layer (VIPRS.fit(),
+e_step(), m_step(), elbo(); VIPRSMix) from /root/reference in the authoring container.
+
+The reference cannot be imported as shipped here because (i) its compiled extension
+`viprs.model.vi.e_step_cpp` is not built in the read-only tree and (ii) its data layer `magenpy`
+(un-vendored PyPI dependency, 0.2.0) is not installed.  This script therefore registers, IN MEMORY
+ONLY (nothing is written anywhere):
+  * `viprs.model.vi.e_step_cpp` -> thin forwarders to oracle/_ref/libviprs_ref.so, i.e. the
+    reference's own e_step.hpp compiled where it lies (same kernels the Cython module wraps);
+  * a minimal `magenpy` namespace: the `GWADataLoader` class object (isinstance check only),
+    `utils.compute_utils.is_numeric`, `stats.h2.ldsc.simple_ldsc` (raises: theta_0 is always given).
+The data loader handed to the reference is a plain array-backed object (tests/golden/_refdata.py
+semantics are restated below); hyper-parameters start from a fixed theta_0, so no RNG enters.
+
+Only the resulting ARRAYS are committed (inputs + per-iteration history + final posterior); neither
+reference source nor these stubs travel with the fixtures.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O                      # noqa: E402
+from viprs_amd.utils import synthetic as syn        # noqa: E402
+
+
+def install_stubs():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    mg = mod("magenpy")
+
+    class GWADataLoader:      # isinstance() target only
+        pass
+
+    mg.GWADataLoader = GWADataLoader
+    mod("magenpy.utils")
+    cu = mod("magenpy.utils.compute_utils")
+    cu.is_numeric = lambda x: isinstance(x, (int, float, np.number, np.ndarray))
+    mod("magenpy.stats")
+    mod("magenpy.stats.h2")
+    ldsc = mod("magenpy.stats.h2.ldsc")
+
+    def simple_ldsc(*a, **k):
+        raise RuntimeError("simple_ldsc is not available in the golden generator")
+    ldsc.simple_ldsc = simple_ldsc
+    mgu = mod("magenpy.utils.system_utils")
+    mgu.makedir = lambda *a, **k: None
+    mp = mod("magenpy.utils.model_utils")
+    mp.merge_snp_tables = lambda *a, **k: None
+
+    es = mod("viprs.model.vi.e_step_cpp")
+    es.cpp_e_step = lambda *a: O.cpp_e_step(*a, kind="reference")
+    es.cpp_e_step_mixture = lambda *a: O.cpp_e_step_mixture(*a, kind="reference")
+    es.cpp_e_step_grid = lambda *a: O.cpp_e_step_grid(*a, kind="reference")
+    es.check_blas_support = O.check_blas_support
+    es.check_omp_support = O.check_omp_support
+    return GWADataLoader
+
+
+def make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed):
+    """Array-backed loader with the attributes VIPRS.__init__/BayesPRSModel.__init__ read
+    (VIPRS.py:153-191, BayesPRSModel.py:59-142)."""
+    lds, sss, inputs = {}, {}, {}
+    for ci, (chrom, sizes) in enumerate(chrom_sizes.items()):
+        ld_sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci)
+        ld_up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci)
+        ss = syn.make_sumstats(ld_sym, seed=seed + ci)
+
+        class LOP:
+            def __init__(self, l):
+                self.ld_data, self.ld_indptr, self.leftmost_idx = l.ld_data, l.ld_indptr, l.ld_left_bound
+
+        class LDM:
+            stored_dtype = np.dtype(ld_dtype)
+
+            def __init__(self, s, u):
+                self._s, self._u = s, u
+
+            def load(self, return_symmetric=False, dtype=None):
+                l = self._s if return_symmetric else self._u
+                if dtype is not None and np.dtype(dtype) != l.ld_data.dtype:
+                    # dequantise at load, as magenpy does when dequantize_on_the_fly=False
+                    scale = l.dq_scale
+                    l = syn.SyntheticLD(l.ld_left_bound, l.ld_indptr, (l.ld_data * scale).astype(dtype),
+                                        l.block_start, l.rho, l.low_memory, 1.0)
+                return LOP(l)
+
+            def get_lambda_min(self, min_max_ratio=1e-3):
+                return 0.0
+
+        class SS:
+            def __init__(self, s):
+                self.n_per_snp = s.n_per_snp
+                self._b = s.std_beta
+
+            def get_snp_pseudo_corr(self):
+                return self._b
+
+        lds[chrom], sss[chrom] = LDM(ld_sym, ld_up), SS(ss)
+        inputs[chrom] = (ld_sym, ld_up, ss)
+
+    gdl = GWADataLoader()
+    gdl.ld, gdl.sumstats_table, gdl.genotype = lds, sss, None
+    gdl.shapes = {c: int(sum(s)) for c, s in chrom_sizes.items()}
+    gdl.m = int(sum(gdl.shapes.values()))
+    gdl.n = 1e5
+    gdl.get_ld_matrices = lambda: lds
+    return gdl, inputs
+
+
+def main():
+    assert O.have_reference()
+    GWADataLoader = install_stubs()
+    sys.path.insert(0, "/root/reference")
+    import viprs                                    # the reference, imported where it lies
+    from viprs.model.VIPRS import VIPRS
+    from viprs.model.VIPRSMix import VIPRSMix
+    print("reference viprs", viprs.__version__)
+
+    cases = [
+        ("fit_ss_1chr_upper", VIPRS, {22: [300, 250, 350]}, dict(low_memory=True), {}),
+        ("fit_ss_1chr_sym", VIPRS, {22: [300, 250, 350]}, dict(low_memory=False), {}),
+        ("fit_ss_2chr_upper", VIPRS, {21: [200, 180], 22: [150, 330]}, dict(low_memory=True), {}),
+        ("fit_ss_fixed_sigma", VIPRS, {22: [400, 260]}, dict(low_memory=True, fix_params={"sigma_epsilon": 0.85}), {}),
+        ("fit_mix_k4_upper", VIPRSMix, {22: [300, 250, 350]}, dict(low_memory=True, K=4), {}),
+    ]
+    for name, cls, chrom_sizes, kw, fit_kw in cases:
+        gdl, inputs = make_loader(GWADataLoader, chrom_sizes, np.float32, seed=301)
+        theta_0 = {"pi": 0.01, "sigma_epsilon": 0.8}
+        if "K" in kw:                                   # no RNG: explicit mixing proportions
+            theta_0 = {"pis": 0.01 * np.array([0.4, 0.3, 0.2, 0.1]), "sigma_epsilon": 0.8}
+        model = cls(gdl, **kw)
+        model.fit(max_iter=60, theta_0=dict(theta_0), disable_pbar=True, **fit_kw)
+        out = dict(theta0_pi=0.01, theta0_sigma_epsilon=0.8, n=gdl.n, low_memory=kw.get("low_memory", True),
+                   K=kw.get("K", 0), theta0_pis=np.asarray(theta_0.get("pis", [])), fix_sigma_epsilon=kw.get("fix_params", {}).get("sigma_epsilon", np.nan),
+                   chroms=np.array(sorted(chrom_sizes)),
+                   elbo_history=np.array(model.history["ELBO"], dtype=np.float64),
+                   nit=model.optim_result.nit, success=bool(model.optim_result.success),
+                   message=str(model.optim_result.message),
+                   final_pi=np.asarray(model.pi, dtype=np.float64), final_tau_beta=np.asarray(model.tau_beta, dtype=np.float64),
+                   final_sigma_epsilon=np.float64(model.sigma_epsilon), final_sigma_g=np.float64(model._sigma_g))
+        for c in sorted(chrom_sizes):
+            ld_sym, ld_up, ss = inputs[c]
+            out[f"sizes_{c}"] = np.array(chrom_sizes[c])
+            out[f"std_beta_{c}"] = ss.std_beta
+            out[f"n_per_snp_{c}"] = ss.n_per_snp
+            out[f"rho_{c}"] = ld_sym.rho
+            out[f"pip_{c}"] = model.pip[c]
+            out[f"post_mean_beta_{c}"] = model.post_mean_beta[c]
+            out[f"post_var_beta_{c}"] = model.post_var_beta[c]
+            out[f"q_{c}"] = model.q[c]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "nit", model.optim_result.nit, model.optim_result.message, "ELBO", model.history["ELBO"][-1],
+              "pi", model.pi, "sig_eps", model.sigma_epsilon)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""EM loop (`VIPRS.fit / e_step / m_step / elbo`, `VIPRSMix`): trajectories against fixtures captured
+from the reference's own Python layer (tests/golden/make_fit_golden.py).
+
+CPU: the host logic is driven with the oracle's kernels through the `e_step_fn` test hook.
+GPU: the same trajectories with the HIP E-step (the product path).
+world_size-2 gloo: chromosomes sharded over two ranks, one float64 all-reduce per iteration."""
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
+from viprs_amd.utils import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FIT = sorted(glob.glob(os.path.join(HERE, "golden", "fit_*.npz")))
+
+
+def loader_from_fixture(fx):
+    ld, ss = {}, {}
+    for c in fx["chroms"]:
+        c = int(c)
+        sizes, rho = fx[f"sizes_{c}"], fx[f"rho_{c}"]
+        sym = syn.make_ld(sizes, low_memory=False, rho=rho)
+        up = syn.make_ld(sizes, low_memory=True, rho=rho)
+        ld[c] = LDArrays(symmetric=(sym.ld_left_bound, sym.ld_indptr, sym.ld_data),
+                         upper=(up.ld_left_bound, up.ld_indptr, up.ld_data))
+        ss[c] = SumstatsArrays(fx[f"std_beta_{c}"], fx[f"n_per_snp_{c}"])
+    return ArrayDataLoader(ld, ss, n=float(fx["n"]))
+
+
+def build_model(fx, comm=None, e_step="oracle"):
+    from viprs_amd.model import VIPRS, VIPRSMix
+    K = int(fx["K"])
+    kw = dict(low_memory=bool(fx["low_memory"]), comm=comm)
+    if not np.isnan(float(fx["fix_sigma_epsilon"])):
+        kw["fix_params"] = {"sigma_epsilon": float(fx["fix_sigma_epsilon"])}
+    if e_step == "oracle":
+        kw["e_step_fn"] = O.cpp_e_step_mixture if K else O.cpp_e_step
+    gdl = loader_from_fixture(fx)
+    if K:
+        model, theta = VIPRSMix(gdl, K=K, **kw), {"pis": fx["theta0_pis"], "sigma_epsilon": float(fx["theta0_sigma_epsilon"])}
+    else:
+        model, theta = VIPRS(gdl, **kw), {"pi": float(fx["theta0_pi"]), "sigma_epsilon": float(fx["theta0_sigma_epsilon"])}
+    return model, theta
+
+
+def check_against_fixture(model, fx, local_only=False):
+    h = np.array(model.history["ELBO"])
+    ref = fx["elbo_history"]
+    assert len(h) == len(ref), f"{len(h)} ELBO entries, reference has {len(ref)}"
+    np.testing.assert_allclose(h, ref, rtol=2e-7, atol=0.05)
+    assert model.optim_result.nit == int(fx["nit"])
+    assert model.optim_result.success == bool(fx["success"])
+    assert model.optim_result.message == str(fx["message"])
+    np.testing.assert_allclose(np.asarray(model.pi, dtype=np.float64), fx["final_pi"], rtol=2e-4)
+    np.testing.assert_allclose(np.asarray(model.tau_beta, dtype=np.float64), fx["final_tau_beta"], rtol=2e-4)
+    np.testing.assert_allclose(float(model.sigma_epsilon), float(fx["final_sigma_epsilon"]), rtol=1e-5)
+    np.testing.assert_allclose(float(model._sigma_g), float(fx["final_sigma_g"]), rtol=1e-4)
+    for c in model.chromosomes:
+        np.testing.assert_allclose(model.pip[c], fx[f"pip_{c}"], rtol=2e-3, atol=2e-6)
+        np.testing.assert_allclose(model.post_mean_beta[c], fx[f"post_mean_beta_{c}"], rtol=2e-3, atol=2e-7)
+        np.testing.assert_allclose(model.q[c], fx[f"q_{c}"], rtol=2e-3, atol=2e-6)
+
+
+def test_fit_fixtures_present():
+    assert len(FIT) >= 5
+
+
+@pytest.mark.parametrize("path", FIT, ids=[os.path.basename(p)[:-4] for p in FIT])
+def test_fit_trajectory_cpu_host_logic(path):
+    fx = np.load(path)
+    model, theta = build_model(fx, e_step="oracle")
+    model.fit(max_iter=60, theta_0=theta)
+    check_against_fixture(model, fx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIT, ids=[os.path.basename(p)[:-4] for p in FIT])
+def test_fit_trajectory_hip(gpu, path):
+    fx = np.load(path)
+    model, theta = build_model(fx, e_step="hip")
+    model.fit(max_iter=60, theta_0=theta)
+    check_against_fixture(model, fx)
+
+
+def test_continued_fit_and_warm_start():
+    fx = np.load(os.path.join(HERE, "golden", "fit_ss_1chr_upper.npz"))
+    model, theta = build_model(fx)
+    model.fit(max_iter=4, theta_0=dict(theta))
+    n1 = len(model.history["ELBO"])
+    model.fit(max_iter=56, continued=True)
+    assert len(model.history["ELBO"]) > n1
+    np.testing.assert_allclose(model.history["ELBO"][-1], fx["elbo_history"][-1], rtol=2e-7)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch.distributed as dist
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+from tests.test_fit import build_model, check_against_fixture
+from viprs_amd.parallel import TorchDistComm
+fx = np.load({path!r})
+comm = TorchDistComm()
+model, theta = build_model(fx, comm=comm)
+assert len(model.chromosomes) == 1 and model._n_chroms_total == 2      # one chromosome per rank
+model.fit(max_iter=60, theta_0=theta)
+check_against_fixture(model, fx)
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", sys.argv[1])
+"""
+
+
+def test_two_rank_gloo_fit_matches_single_process(tmp_path):
+    """Chromosomes sharded over 2 ranks (gloo on CPU); hyper-parameters / ELBO follow from ONE
+    all-reduce of the partial sums per iteration and reproduce the single-process reference run."""
+    path = os.path.join(HERE, "golden", "fit_ss_2chr_upper.npz")
+    script = tmp_path / "worker.py"
+    port = 29500 + (os.getpid() % 2000)
+    script.write_text(_WORKER.format(root=ROOT, port=port, path=path))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]

@@ -1,0 +1,89 @@
+"""Array-backed stand-ins for the slice of magenpy's data layer that the E-step path touches.
+
+The reference reads its inputs from a magenpy ``GWADataLoader`` (an un-vendored dependency):
+``gdl.get_ld_matrices()[c].load(return_symmetric=..., dtype=...)`` -> ``.ld_data / .ld_indptr /
+.leftmost_idx`` (VIPRS.py:153-172), ``gdl.sumstats_table[c].n_per_snp`` and
+``.get_snp_pseudo_corr()`` (BayesPRSModel.py:133-136), ``gdl.shapes``, ``gdl.m``, ``gdl.n``.
+``viprs_amd.model.VIPRS`` is duck-typed on exactly those attributes, so a real magenpy loader
+works unchanged; these classes provide the same surface over plain NumPy arrays.
+"""
+import numpy as np
+
+
+class LDArrays:
+    """LD of one chromosome in the contiguous-window layout.  Holds the
+    symmetric and/or the upper-triangular form; ``load`` hands out the one asked for."""
+
+    def __init__(self, symmetric=None, upper=None, stored_dtype=None, dq_scale=1.0, lambda_min=0.0):
+        if symmetric is None and upper is None:
+            raise ValueError("need at least one LD form")
+        self._forms = {True: symmetric, False: upper}      # key: return_symmetric
+        any_form = symmetric if symmetric is not None else upper
+        self.stored_dtype = np.dtype(stored_dtype if stored_dtype is not None else any_form[2].dtype)
+        self.dq_scale = float(dq_scale)
+        self._lambda_min = lambda_min
+
+    class _Loaded:
+        def __init__(self, lb, ip, data):
+            self.leftmost_idx, self.ld_indptr, self.ld_data = lb, ip, data
+
+    def load(self, return_symmetric=False, dtype=None):
+        form = self._forms[bool(return_symmetric)]
+        if form is None:
+            raise ValueError(f"LD form return_symmetric={return_symmetric} was not provided")
+        lb, ip, data = form
+        if dtype is not None and np.dtype(dtype) != data.dtype:
+            # dequantise at load time, as magenpy does when the caller asks for a float dtype
+            data = (data * self.dq_scale).astype(dtype) if np.issubdtype(data.dtype, np.integer) \
+                else data.astype(dtype)
+        return LDArrays._Loaded(lb, ip, data)
+
+    def get_lambda_min(self, min_max_ratio=1e-3):
+        return self._lambda_min
+
+
+class SumstatsArrays:
+    def __init__(self, std_beta, n_per_snp):
+        self._std_beta = np.asarray(std_beta)
+        self.n_per_snp = np.asarray(n_per_snp, dtype=np.float64)
+
+    def get_snp_pseudo_corr(self):
+        return self._std_beta
+
+
+class ArrayDataLoader:
+    """Minimal ``GWADataLoader`` look-alike: ``ld`` / ``sumstats_table`` dicts keyed by chromosome."""
+
+    def __init__(self, ld, sumstats, n=None):
+        self.ld = dict(ld)
+        self.sumstats_table = dict(sumstats)
+        self.genotype = None
+        self.shapes = {c: int(s.n_per_snp.shape[0]) for c, s in self.sumstats_table.items()}
+        self.n = float(n) if n is not None else float(max(s.n_per_snp.max() for s in self.sumstats_table.values()))
+
+    @property
+    def chromosomes(self):
+        return sorted(self.shapes)
+
+    @property
+    def m(self):
+        return int(sum(self.shapes.values()))
+
+    def get_ld_matrices(self):
+        return self.ld
+
+    @classmethod
+    def synthetic(cls, chrom_sizes, ld_dtype=np.float32, seed=7209, n=1e5, forms=("symmetric", "upper")):
+        """AR(1) block LD + simulated summary statistics (viprs_amd.utils.synthetic) per chromosome."""
+        from .utils import synthetic as syn
+        ld, ss = {}, {}
+        for ci, (chrom, sizes) in enumerate(chrom_sizes.items()):
+            sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci)
+            up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci) if "upper" in forms else None
+            s = syn.make_sumstats(sym, n=n, seed=seed + ci)
+            ld[chrom] = LDArrays(
+                symmetric=(sym.ld_left_bound, sym.ld_indptr, sym.ld_data) if "symmetric" in forms else None,
+                upper=(up.ld_left_bound, up.ld_indptr, up.ld_data) if up is not None else None,
+                stored_dtype=ld_dtype, dq_scale=sym.dq_scale)
+            ss[chrom] = SumstatsArrays(s.std_beta, s.n_per_snp)
+        return cls(ld, ss, n=n)

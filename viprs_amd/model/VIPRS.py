@@ -1,0 +1,460 @@
+"""``VIPRS`` -- variational EM for the spike-and-slab PRS model with the E-step on MI355X.
+
+Keeps the constructor, ``fit()``, ``e_step()``, ``m_step()``, ``elbo()`` surface and the
+dict-of-arrays attributes of the reference class (viprs/model/VIPRS.py) so that code written
+against it keeps working, but is organised around the GPU:
+
+* ``__init__`` uploads every chromosome's LD once (``LDPlan`` = the reference's "load LD matrices to
+  memory", VIPRS.py:151-172) and keeps the variational state in HBM (``DeviceState``);
+* ``e_step()`` does the O(m) host prep of VIPRS.py:400-418, launches the HIP sweep of every
+  chromosome (each on its own stream) and mirrors the state back into the NumPy attributes;
+* ``m_step()`` / ``elbo()`` are written over one vector of per-rank partial sums, so that with
+  several GPUs (chromosomes sharded over ranks) the only communication per EM iteration is ONE small
+  float64 all-reduce (viprs_amd.parallel).
+
+There is no CPU fallback: without ``libviprs_hip.so`` and a GPU the E-step raises.  (``e_step_fn``
+lets the CPU test-suite drive this host logic with the oracle's kernels; it is never set by the
+package itself.)
+"""
+import logging
+
+import numpy as np
+
+from ..parallel import LocalComm, assign_chromosomes
+from ..utils.optim import ConditionStreak, OptimizeResult
+
+logger = logging.getLogger(__name__)
+
+_DOUBLE_RES = np.finfo(np.float64).resolution      # clip for gamma in the ELBO (VIPRS.py:509-518)
+
+
+def _is_numeric(x):
+    return isinstance(x, (int, float, np.number, np.ndarray))
+
+
+class VIPRS:
+
+    def __init__(self, gdl, fix_params=None, tracked_params=None, lambda_min=None, float_precision="float32",
+                 order="F", low_memory=True, dequantize_on_the_fly=False, threads=1,
+                 device=None, comm=None, math_mode="exact", e_step_fn=None):
+        """Same arguments as the reference (VIPRS.py:68-77) plus:
+
+        :param device: HIP device index (default: ``comm.rank`` modulo the visible devices).
+        :param comm: ``viprs_amd.parallel`` communicator; chromosomes are sharded over its ranks.
+        :param math_mode: 'exact' (bit-for-bit the reference's arithmetic) or 'fast'.
+        :param e_step_fn: test hook -- a callable with ``cpp_e_step``'s positional signature that
+            replaces the HIP kernels (used by the CPU tests with the oracle).
+        """
+        if gdl.genotype is None and (gdl.ld is None or gdl.sumstats_table is None):
+            raise AssertionError("The data loader must contain summary statistics and LD matrices.")
+        self.gdl = gdl
+        self.float_precision = float_precision
+        self._T = np.dtype(float_precision)
+        self.float_eps = np.finfo(self._T).eps
+        self.comm = comm if comm is not None else LocalComm()
+        self.threads = threads
+        self.fix_params = fix_params or {}
+        self.tracked_params = tracked_params or []
+        self.order = order
+        self.low_memory = low_memory
+        self.math_mode = math_mode
+        self._e_step_fn = e_step_fn
+
+        # ---- which chromosomes live on this rank -----------------------------------------------
+        self._all_shapes = dict(gdl.shapes)
+        ld_mats = gdl.get_ld_matrices()
+        costs = {c: float(self._all_shapes[c]) ** 2 for c in self._all_shapes}
+        self._owner = assign_chromosomes(costs, self.comm.world_size)
+        self.shapes = {c: s for c, s in self._all_shapes.items() if self._owner[c] == self.comm.rank}
+        self._n_chroms_total = len(self._all_shapes)
+
+        # ---- inputs (BayesPRSModel.py:118-142) --------------------------------------------------
+        self.n_per_snp = {c: gdl.sumstats_table[c].n_per_snp for c in self.shapes}
+        self.std_beta = {c: gdl.sumstats_table[c].get_snp_pseudo_corr().astype(self._T) for c in self.shapes}
+        self._sample_size = max(float(np.max(s.n_per_snp)) for s in gdl.sumstats_table.values())
+
+        # ---- LD: load, then make it device-resident (VIPRS.py:151-191) -------------------------
+        self.ld_data, self.ld_indptr, self.ld_left_bound = {}, {}, {}
+        self.lambda_min = 0.0
+        for c in self.chromosomes:
+            ld_mat = ld_mats[c]
+            if dequantize_on_the_fly and np.issubdtype(ld_mat.stored_dtype, np.integer):
+                dtype = ld_mat.stored_dtype
+            else:
+                dtype = float_precision
+                dequantize_on_the_fly = False
+            lop = ld_mat.load(return_symmetric=not low_memory, dtype=dtype)
+            self.ld_data[c], self.ld_indptr[c], self.ld_left_bound[c] = lop.ld_data, lop.ld_indptr, lop.leftmost_idx
+            if lambda_min is None:
+                self.lambda_min = 0.0
+            elif _is_numeric(lambda_min):
+                self.lambda_min = lambda_min
+            else:                                                    # 'infer'
+                self.lambda_min = ld_mat.get_lambda_min(min_max_ratio=1e-3)
+        self.dequantize_on_the_fly = dequantize_on_the_fly
+        if dequantize_on_the_fly and self.chromosomes:
+            self.dequantize_scale = 1.0 / np.iinfo(self.ld_data[self.chromosomes[0]].dtype).max   # :203-207
+        else:
+            self.dequantize_scale = 1.0
+
+        self._plans, self._dstate = {}, {}
+        if e_step_fn is None:
+            from ..plan import DeviceState, LDPlan
+            from .. import _lib
+            ndev = _lib.device_count()
+            if ndev < 1:
+                raise RuntimeError("VIPRS needs a HIP device: the E-step has no CPU fallback")
+            self.device = int(device) if device is not None else self.comm.rank % ndev
+            for c in self.chromosomes:
+                self._plans[c] = LDPlan(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], low_memory,
+                                        device=self.device, math_mode=math_mode)
+                self._dstate[c] = self._make_device_state(self._plans[c])
+                self._dstate[c].upload("std_beta", self.std_beta[c])
+
+        # ---- model state -------------------------------------------------------------------------
+        self.var_gamma, self.var_mu, self.var_tau, self._log_var_tau = {}, {}, {}, {}
+        self.eta, self.zeta, self.eta_diff, self.q = {}, {}, {}, {}
+        self.sigma_epsilon = self.tau_beta = self.pi = self._sigma_g = None
+        self.pip = self.post_mean_beta = self.post_var_beta = None
+        self.optim_result = OptimizeResult()
+        self.history = {}
+        self._sums = None
+        self._sums_valid = False
+        self._max_eta_diff = 0.0
+
+    # ---- sizes ------------------------------------------------------------------------------------
+    @property
+    def chromosomes(self):
+        return sorted(self.shapes.keys())
+
+    @property
+    def m(self):
+        return int(self.gdl.m)
+
+    n_snps = m
+
+    @property
+    def n(self):
+        return self._sample_size
+
+    def _shape(self, c):
+        return self.shapes[c]
+
+    def _make_device_state(self, plan):
+        from ..plan import DeviceState
+        return DeviceState(plan, self.float_precision, "spike_slab")
+
+    # ---- initialisation (VIPRS.py:213-359) -------------------------------------------------------
+    def initialize(self, theta_0=None, param_0=None):
+        self.initialize_theta(theta_0)
+        self.initialize_variational_parameters(param_0)
+        self.init_optim_meta()
+
+    def init_optim_meta(self):
+        self.history = {"ELBO": []}
+        for t in self.tracked_params:
+            self.history[t if isinstance(t, str) else t.__name__] = []
+        self.optim_result.reset()
+
+    def _merge_theta(self, theta_0):
+        if theta_0 is not None and self.fix_params is not None:
+            theta_0.update(self.fix_params)
+        elif self.fix_params is not None:
+            theta_0 = self.fix_params
+        elif theta_0 is None:
+            theta_0 = {}
+        return theta_0
+
+    def _cast_theta(self):
+        t = self._T.type
+        self.sigma_epsilon, self.pi, self.lambda_min = t(self.sigma_epsilon), t(self.pi), t(self.lambda_min)
+        self._sigma_g = t(0.0)
+
+    def initialize_theta(self, theta_0=None):
+        th = self._merge_theta(theta_0)
+        if "pi" in th:
+            self.pi = th["pi"]
+        else:                                                      # VIPRS.py:260-265
+            self.pi = np.random.uniform(low=max(10.0 / self.n_snps, 1e-5), high=min(0.2, 1e4 / self.n_snps))
+        if "sigma_epsilon" in th:                                  # :301-310
+            self.sigma_epsilon = th["sigma_epsilon"]
+            self.tau_beta = th["tau_beta"] if "tau_beta" in th else \
+                (self.pi * self.n_snps) / np.maximum(0.01, 1.0 - self.sigma_epsilon)
+        elif "tau_beta" in th:                                     # :295-300
+            self.tau_beta = th["tau_beta"]
+            self.sigma_epsilon = np.clip(1.0 - self.pi * self.n_snps / self.tau_beta, 1e-4, 1.0 - 1e-4)
+        else:                                                      # :279-292 (no simple_ldsc without magenpy)
+            h2 = np.random.uniform(low=0.01, high=0.1)
+            self.sigma_epsilon = 1.0 - h2
+            self.tau_beta = self.pi * self.n_snps / max(h2, 0.01)
+        self._cast_theta()
+
+    def get_pi(self, chrom=None):
+        return self.pi[chrom] if (chrom is not None and isinstance(self.pi, dict)) else self.pi
+
+    def get_tau_beta(self, chrom=None):
+        return self.tau_beta[chrom] if (chrom is not None and isinstance(self.tau_beta, dict)) else self.tau_beta
+
+    def get_null_pi(self, chrom=None):
+        return 1.0 - self.get_pi(chrom)
+
+    def get_sigma_epsilon(self):
+        return self.sigma_epsilon
+
+    def initialize_variational_parameters(self, param_0=None):
+        p0 = param_0 or {}
+        T = self._T
+        self.var_mu, self.var_tau, self.var_gamma = {}, {}, {}
+        for c in self.chromosomes:
+            shp = self._shape(c)
+            self.var_tau[c] = p0["tau"][c] if "tau" in p0 else (self.n_per_snp[c] / self.sigma_epsilon) + self.tau_beta
+            self.var_mu[c] = p0["mu"][c].astype(T, order=self.order) if "mu" in p0 else np.zeros(shp, T, order=self.order)
+            if "gamma" in p0:
+                self.var_gamma[c] = p0["gamma"][c].astype(T, order=self.order)
+            else:
+                self.var_gamma[c] = (self.get_pi(c) * np.ones(shp, dtype=T, order=self.order)).astype(T, order=self.order)
+        self.eta = self.compute_eta()
+        self.zeta = self.compute_zeta()
+        self.eta_diff = {c: np.zeros_like(e, dtype=T) for c, e in self.eta.items()}
+        self.q = {c: np.zeros_like(e, dtype=T) for c, e in self.eta.items()}
+        self._log_var_tau = {c: np.log(self.var_tau[c]) for c in self.var_tau}
+        self._sums_valid = False
+        self._push_state()
+
+    def set_fixed_params(self, fix_params):
+        assert isinstance(fix_params, dict)
+        self.fix_params.update(fix_params)
+        t = self._T.type
+        for k, v in fix_params.items():
+            if k in ("sigma_epsilon", "tau_beta", "pi", "lambda_min"):
+                setattr(self, k, t(v))
+
+    # ---- device mirror ------------------------------------------------------------------------------
+    _STATE = ("var_gamma", "var_mu", "eta", "q", "eta_diff")
+
+    def _push_state(self):
+        for c, ds in self._dstate.items():
+            for name in self._STATE:
+                ds.upload(name, np.ascontiguousarray(getattr(self, name)[c]))
+
+    def _pull_state(self):
+        for c, ds in self._dstate.items():
+            for name in self._STATE:
+                ds.download(name, out=getattr(self, name)[c])
+
+    # ---- E-step -------------------------------------------------------------------------------------
+    def _prep(self, c):
+        """Host prep of VIPRS.py:396-418 (float64, cast to the state precision at the end)."""
+        tau_beta, pi = self.get_tau_beta(c), self.get_pi(c)
+        self.var_tau[c] = (self.n_per_snp[c] * (1.0 + self.lambda_min) / self.sigma_epsilon) + tau_beta
+        np.log(self.var_tau[c], out=self._log_var_tau[c])
+        T = self._T
+        mu_mult = (self.n_per_snp[c] / (self.var_tau[c] * self.sigma_epsilon)).astype(T)
+        u_logs = (np.log(pi) - np.log(1.0 - pi) + 0.5 * (np.log(tau_beta) - self._log_var_tau[c])).astype(T)
+        shvt = np.sqrt(0.5 * self.var_tau[c]).astype(T)
+        return u_logs, shvt, mu_mult
+
+    def e_step(self):
+        """One coordinate-ascent sweep over every LD block of every local chromosome."""
+        if self._e_step_fn is not None:
+            for c in self.chromosomes:
+                u_logs, shvt, mu_mult = self._prep(c)
+                self._e_step_fn(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], self.std_beta[c],
+                                self.var_gamma[c], self.var_mu[c], self.eta[c], self.q[c], self.eta_diff[c],
+                                u_logs, shvt, mu_mult, self.dequantize_scale, self.threads, self.low_memory)
+        else:
+            for c in self.chromosomes:               # launch everything (one stream per chromosome) ...
+                u_logs, shvt, mu_mult = self._prep(c)
+                ds = self._dstate[c]
+                ds.upload("u_logs", u_logs)
+                ds.upload("sqrt_half_var_tau", shvt)
+                ds.upload("mu_mult", mu_mult)
+                ds.e_step(self.dequantize_scale, sync=False)
+            self._pull_state()                       # ... then mirror the state back (syncs each stream)
+        self.zeta = self.compute_zeta()
+        self._sums_valid = False
+
+    # ---- posterior summaries (VIPRS.py:875-907) ---------------------------------------------------
+    def compute_pip(self):
+        return self.var_gamma.copy()
+
+    def compute_eta(self):
+        return {c: g * self.var_mu[c] for c, g in self.var_gamma.items()}
+
+    def compute_zeta(self):
+        return {c: np.multiply(g, self.var_mu[c].astype(np.float64) ** 2 + 1.0 / self.var_tau[c].astype(np.float64))
+                for c, g in self.var_gamma.items()}
+
+    def update_posterior_moments(self):
+        self.pip = self.compute_pip()
+        self.post_mean_beta = {c: e.copy() for c, e in self.eta.items()}
+        self.post_var_beta = {c: z - self.eta[c] ** 2 for c, z in self.zeta.items()}
+
+    # ---- partial sums: everything the M-step, the ELBO and the stopping rules need ------------------
+    def _partial_sums(self):
+        """Per-rank sums over the local SNPs; summed over ranks by one all-reduce.
+
+        layout: [0] sum_c mean(gamma_c)   [1] sum zeta            [2] sum((1+lambda) zeta + q eta)
+                [3] sum_c std_beta_c.eta_c [4] sum eta^2           [5..8] ELBO sums
+                (max|eta_diff| travels in a separate max-reduction)"""
+        lam = self.lambda_min
+        s = np.zeros(9, dtype=np.float64)
+        for c in self.chromosomes:
+            g, z = self.var_gamma[c], self.zeta[c]
+            s[0] += np.mean(g, axis=0)                                   # update_pi: mean of per-chromosome means
+            s[1] += z.sum()
+            s[2] += np.sum((1.0 + lam) * z + np.multiply(self.q[c], self.eta[c]), axis=0)
+            s[3] += self.std_beta[c].dot(self.eta[c])
+            s[4] += (self.eta[c].astype(np.float64) ** 2).sum()
+            gc = np.clip(g.astype(np.float64), _DOUBLE_RES, 1.0 - _DOUBLE_RES)
+            ng = np.clip(1.0 - g.astype(np.float64), _DOUBLE_RES, 1.0 - _DOUBLE_RES)
+            s[5] += (gc * np.log(gc)).sum()
+            s[6] += (ng * np.log(ng)).sum()
+            s[7] += gc.sum()
+            s[8] += ng.sum()
+        extra = np.zeros(1)
+        for c in self.chromosomes:
+            extra[0] += (np.clip(self.var_gamma[c].astype(np.float64), _DOUBLE_RES, 1 - _DOUBLE_RES)
+                         * self._log_var_tau[c]).sum()
+        return np.concatenate([s, extra])
+
+    def _reduce(self, force=False):
+        if self._sums is not None and self._sums_valid and not force:
+            return self._sums
+        self._sums_valid = True
+        self._sums = self.comm.allreduce_sum(self._partial_sums())
+        local_max = max([float(np.max(np.abs(d))) for d in self.eta_diff.values()] or [0.0])
+        self._max_eta_diff = float(self.comm.allreduce_max(np.array([local_max]))[0])
+        return self._sums
+
+    # ---- M-step (VIPRS.py:426-484) -----------------------------------------------------------------
+    def m_step(self):
+        s = self._reduce()
+        T = self._T.type
+        if "pi" not in self.fix_params:
+            self.pi = T(s[0] / self._n_chroms_total)                                  # :434
+        if "tau_beta" not in self.fix_params:
+            self.tau_beta = self.pi * self.n_snps / s[1]                              # :444
+        self._sigma_g = s[2]                                                           # :454-457
+        if "sigma_epsilon" not in self.fix_params:
+            self.sigma_epsilon = 1.0 + T(-2.0 * s[3]) + self._sigma_g                  # :466-471
+
+    def update_pi(self):
+        self._reduce()
+        if "pi" not in self.fix_params:
+            self.pi = self._T.type(self._sums[0] / self._n_chroms_total)
+
+    # ---- objective (VIPRS.py:497-581) ----------------------------------------------------------------
+    def elbo(self, sum_axis=None):
+        s = self._sums if self._sums is not None else self._reduce()
+        pi, null_pi, tau_beta = self.pi, self.get_null_pi(), self.tau_beta
+        e = -np.log(2.0 * np.pi * self.sigma_epsilon)
+        if "sigma_epsilon" not in self.fix_params:
+            e -= 1.0
+        else:
+            e -= (1.0 / self.sigma_epsilon) * (1.0 - 2.0 * s[3] + self._sigma_g)
+        e *= 0.5 * self.n
+        e -= s[5] - np.log(pi) * s[7]
+        e -= s[6] - np.log(null_pi) * s[8]
+        e += 0.5 * ((1.0 + np.log(tau_beta)) * s[7] - s[9])
+        e -= 0.5 * tau_beta * s[1]
+        return float(e)
+
+    objective = elbo
+
+    def mse(self, sum_axis=None):                                                      # :689-704
+        s = self._sums
+        return 1.0 - 2.0 * s[3] + (self._sigma_g - s[1] + s[4])
+
+    def get_heritability(self):
+        return self._sigma_g / (self._sigma_g + self.sigma_epsilon)
+
+    def get_proportion_causal(self):
+        return self.pi
+
+    def update_theta_history(self):
+        self._reduce()
+        self.history["ELBO"].append(self.elbo())
+        for t in self.tracked_params:
+            if t == "pi":
+                self.history["pi"].append(self.get_proportion_causal())
+            elif t == "heritability":
+                self.history["heritability"].append(self.get_heritability())
+            elif t == "sigma_epsilon":
+                self.history["sigma_epsilon"].append(self.sigma_epsilon)
+            elif t == "tau_beta":
+                self.history["tau_beta"].append(self.tau_beta)
+            elif t == "sigma_g":
+                self.history["sigma_g"].append(self._sigma_g)
+            elif t == "max_eta_diff":
+                self.history["max_eta_diff"].append(self._max_eta_diff)
+            elif callable(t):
+                self.history[t.__name__].append(t(self))
+
+    # ---- EM loop (VIPRS.py:909-1124): same stopping rules, evaluated on the reduced sums ------------
+    def fit(self, max_iter=1000, theta_0=None, param_0=None, continued=False, disable_pbar=True, min_iter=3,
+            f_abs_tol=1e-6, x_abs_tol=1e-6, patience=10, **kwargs):
+        if not continued:
+            self.initialize(theta_0, param_0)
+            first = 1
+            self.update_theta_history()
+            prev_elbo = -np.inf
+        else:
+            first = len(self.history["ELBO"]) + 1
+            self._reduce()
+            self.optim_result.update(self.elbo(), increment=False)
+            prev_elbo = self.elbo()
+        prev_sigma_g = self._sigma_g
+        plateau, dropping = ConditionStreak(), ConditionStreak()
+        res = self.optim_result
+
+        for i in range(first, first + max_iter):
+            if res.stop_iteration:
+                break
+            self.e_step()
+            self.m_step()
+            self.update_theta_history()
+            max_eta_diff = self._max_eta_diff                                          # :997
+            elbo = self.history["ELBO"][-1]
+            plateau.update((i > min_iter) and np.isclose(self._sigma_g, prev_sigma_g, atol=x_abs_tol, rtol=0.0)
+                           and max_eta_diff < x_abs_tol * 10, i)                       # :1003-1008
+            dropping.update((elbo < prev_elbo) and not np.isclose(elbo, prev_elbo, atol=1e3 * f_abs_tol, rtol=1e-4), i)
+
+            stop = None                                                                # (success, message)
+            if self.mse() < 0.0:                                                       # :1025-1044
+                if "sigma_epsilon" not in self.fix_params:
+                    logger.info("Iteration %d | MSE is negative; restarting with sigma_epsilon fixed.", i)
+                    self.initialize_theta(theta_0)
+                    self.initialize_variational_parameters(param_0)
+                    self.fix_params["sigma_epsilon"] = self.sigma_epsilon = 0.95
+                    continue
+                stop = (False, f"The MSE is negative ({self.mse():.6f}).")
+            elif not np.isfinite(elbo):
+                stop = (False, "Objective (ELBO) is undefined.")
+            elif self.sigma_epsilon < 0.0:
+                stop = (False, "Residual variance estimate is negative.")
+            elif self.get_heritability() > 1.0 or self.get_heritability() < 0.0:
+                stop = (False, "Estimated heritability is out of bounds.")
+            elif (i > min_iter) and np.isclose(prev_elbo, elbo, atol=f_abs_tol, rtol=0.0):
+                stop = (True, "Objective (ELBO) converged successfully.")
+            elif (i > min_iter) and max_eta_diff < x_abs_tol:
+                stop = (True, "Variational parameters converged successfully.")
+            elif plateau.counter > patience:
+                stop = (True, "LD-weighted variational parameters converged successfully.")
+            elif dropping.counter > patience:
+                stop = (False, "The objective (ELBO) is decreasing.")
+
+            if stop is None:
+                res.update(elbo)
+            else:
+                res.update(elbo, stop_iteration=True, success=stop[0], message=stop[1])
+            prev_elbo, prev_sigma_g = elbo, self._sigma_g
+
+        self.update_posterior_moments()
+        if not res.stop_iteration:
+            res.update(self.elbo(), stop_iteration=True, success=False, increment=False,
+                       message="Maximum iterations reached without convergence.\n"
+                               "You may need to run the model for more iterations.")
+        if not res.success:
+            logger.warning("\t%s", res.message)
+        return self

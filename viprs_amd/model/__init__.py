@@ -1,0 +1,4 @@
+from .VIPRS import VIPRS
+from .VIPRSMix import VIPRSMix
+
+__all__ = ["VIPRS", "VIPRSMix"]

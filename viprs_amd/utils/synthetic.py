@@ -69,13 +69,14 @@ def _fill_block(data, off, b, row, low_memory):
             dst[r] = vals[b - 1 - r:2 * b - 1 - r]
 
 
-def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8)):
+def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8),
+            rho=None):
     """Block-diagonal AR(1) LD in symmetric (`low_memory=False`: every row of a block stores the whole
     block, diagonal included) or upper-triangular form (`low_memory=True`: row j stores columns
     j+1 .. block_end-1, left bound j+1) -- the two layouts e_step.hpp:389-392,423-440 consumes."""
     sizes = np.asarray(sizes, dtype=np.int64)
     rng = np.random.default_rng(seed + 1)
-    rho = rng.uniform(rho_range[0], rho_range[1], len(sizes))
+    rho = rng.uniform(rho_range[0], rho_range[1], len(sizes)) if rho is None else np.asarray(rho, dtype=np.float64)
     ld_dtype = np.dtype(ld_dtype)
     quant_max = None
     dq_scale = 1.0
