@@ -14,7 +14,8 @@ def _problem(sizes, low_memory, ld_dtype=np.float32, seed=11):
 
 
 @pytest.mark.parametrize("low_memory", [False, True])
-@pytest.mark.parametrize("sizes", [[500], [37, 128, 300], [1, 2, 63, 64, 65, 129, 700], [1500, 90]])
+@pytest.mark.parametrize("sizes", [[500], [37, 128, 300], [1, 2, 63, 64, 65, 129, 700], [1500, 90],
+                                   [1700, 90], [2300, 1601, 1536, 1537, 40]])   # >= 1536: multi-CU teams
 def test_first_sweep_matches_oracle(gpu, sizes, low_memory):
     ld, ss, inp = _problem(sizes, low_memory)
     st0 = inp.state_copy()

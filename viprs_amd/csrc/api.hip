@@ -47,10 +47,12 @@ size_t ld_elem_size(int ld_dtype) {
 size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0); }
 
 // workgroup-size classes of the panel kernel (waves per workgroup; wave 0 is the chain)
-static int kLargeBlock = 1 << 30, kMediumBlock = 1536;   // (class 0 unused by default)
-constexpr int kClassWaves[3] = {16, 8, 4};
+// Every class uses 4-wave workgroups (1 chain + 3 updaters) so that a team member needs exactly
+// the same CU resources as a small-block workgroup; larger blocks get more CUs, not bigger groups.
+static int kLargeBlock = 2304, kMediumBlock = 1280;
+constexpr int kClassWaves[3] = {4, 4, 4};
+constexpr int kClassTeam[3] = {8, 4, 1};    // workgroups (CUs) sharing one block of the class
 constexpr int kEpiWaves = 4;
-constexpr int kLowerWaves = 4;
 
 template <typename V> struct DevBuf {
     V* p = nullptr;
@@ -82,10 +84,22 @@ __global__ void repack_dense_kernel(const U* __restrict__ src, const int64_t* __
     }
 }
 
+// device-side re-initialisation to the standard start (VIPRS.py:344-358) in ONE launch
 template <typename T>
-__global__ void fill_kernel(T* p, T v, int64_t n) {
+__global__ void reset_state_kernel(T* var_gamma, T* var_mu, int64_t n_wide, T* eta, T* q, T* eta_diff, int64_t n_vec,
+                                   T pi) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i < n_wide) { var_gamma[i] = pi; var_mu[i] = (T)0; }
+    if (i < n_vec) { eta[i] = (T)0; q[i] = (T)0; eta_diff[i] = (T)0; }
+}
+
+// zeroes the work-queue heads, the skip counter and the team hand-off granules in ONE launch
+__global__ void sweep_prologue_kernel(int32_t* counters, int n_counters, unsigned long long* skipped,
+                                      unsigned long long* granules, int64_t n_granules) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_counters) counters[i] = 0;
+    if (i == 0) *skipped = 0ull;
+    for (int64_t k = i; k < n_granules; k += (int64_t)gridDim.x * blockDim.x) granules[k] = 0ull;
 }
 
 }  // namespace
@@ -110,8 +124,9 @@ struct viprs_plan {
     hipStream_t class_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     DevBuf<EpiItem> d_epi;
-    DevBuf<LowerItem> d_lower;              // symmetric form: per-class lists of (block, strip)
-    int lower_begin[4] = {0, 0, 0, 0};
+    DevBuf<unsigned long long> d_granules;  // team hand-off granules (one row of 64 per panel of a team block)
+    int64_t n_granule_rows = 0;
+    DevBuf<int32_t> d_error;
     DevBuf<int32_t> d_admit;                // admission thresholds of the small-block class
     int admit_grid = 0;
     double admit_factor = 1.5;
@@ -143,6 +158,7 @@ struct viprs_state {
     int width = 1;
     DevBuf<char> f[VIPRS_FIELD_COUNT];
     DevBuf<int32_t> d_active;               // grid: active model indices of the current call
+    DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
     size_t field_elems(int field) const {
         const size_t m = (size_t)plan->m;
         switch (field) {
@@ -165,6 +181,8 @@ viprs_plan::~viprs_plan() {
 }
 
 // ------------------------------------------------------------------------------------------------
+static int check_device_error(viprs_plan* P);
+
 extern "C" {
 
 const char* viprs_last_error(void) { return g_err.c_str(); }
@@ -248,7 +266,13 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     P->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
-    for (auto& st : P->class_stream) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    {   // team classes get the highest stream priority: their workgroups must become co-resident quickly
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        for (int c = 0; c < 3; ++c)
+            HIP_TRY(hipStreamCreateWithPriority(&P->class_stream[c], hipStreamNonBlocking,
+                                                kClassTeam[c] > 1 ? prio_hi : prio_lo));
+    }
     HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
     for (auto& e : P->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     P->ev.assign(4 * viprs_plan::kRing, nullptr);
@@ -265,6 +289,7 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         d.kind = b.kind;
         d.stride = 0;
         d.ld_off = 0;
+        d.gr_off = 0;
         const bool dense = panel_ld && (b.kind == VIPRS_BLOCK_DENSE_SYM || b.kind == VIPRS_BLOCK_DENSE_UPPER);
         if (dense) {
             d.stride = (d.size + kPanel - 1) / kPanel * kPanel;
@@ -292,10 +317,19 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         while (i < n && P->dense_h[i].size >= kMediumBlock) ++i;
         P->class_begin[2] = i;
         P->class_begin[3] = n;
+        // hand-off granules for the blocks served by teams (classes 0 and 1)
+        int64_t rows = 0;
+        for (int k = 0; k < P->class_begin[2]; ++k) {
+            P->dense_h[(size_t)k].gr_off = rows;
+            rows += (P->dense_h[(size_t)k].size + kPanel - 1) / kPanel;
+        }
+        P->n_granule_rows = rows;
     }
 
     // ---- upload -------------------------------------------------------------------------------
     HIP_TRY(P->d_counters.alloc(16));
+    HIP_TRY(P->d_error.alloc(1));
+    HIP_TRY(hipMemset(P->d_error.p, 0, sizeof(int32_t)));
     HIP_TRY(P->d_skipped.alloc(1));
     HIP_TRY(hipMemset(P->d_skipped.p, 0, sizeof(unsigned long long)));
     if (m > 0) {
@@ -322,6 +356,7 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es));
         HIP_TRY(hipMemcpy(P->d_ld_raw.p, ld_data, (size_t)P->nnz * es, hipMemcpyHostToDevice));
     }
+    if (P->n_granule_rows > 0) HIP_TRY(P->d_granules.alloc((size_t)P->n_granule_rows * kPanel));
     if (!P->dense_h.empty()) {
         HIP_TRY(P->d_dense.alloc(P->dense_h.size()));
         HIP_TRY(hipMemcpy(P->d_dense.p, P->dense_h.data(), sizeof(BlockDesc) * P->dense_h.size(), hipMemcpyHostToDevice));
@@ -345,29 +380,6 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
-        if (!P->low_memory) {
-            // deferred lower-left updates: one item per (block, 256-column strip) that has rows
-            // below it; per size class, descending row count
-            std::vector<LowerItem> items;
-            for (int c = 0; c < 3; ++c) {
-                P->lower_begin[c] = (int)items.size();
-                std::vector<std::pair<int, LowerItem>> cls;
-                for (int i = P->class_begin[c]; i < P->class_begin[c + 1]; ++i) {
-                    const int b = P->dense_h[i].size;
-                    for (int st = 0; st * kLowerStrip < b; ++st) {
-                        const int row_begin = (st * (kLowerStrip / kPanel) + 1) * kPanel;
-                        if (row_begin < b) cls.push_back({b - row_begin, LowerItem{(int32_t)(i - P->class_begin[c]), st}});
-                    }
-                }
-                std::stable_sort(cls.begin(), cls.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
-                for (auto& e : cls) items.push_back(e.second);
-            }
-            P->lower_begin[3] = (int)items.size();
-            if (!items.empty()) {
-                HIP_TRY(P->d_lower.alloc(items.size()));
-                HIP_TRY(hipMemcpy(P->d_lower.p, items.data(), sizeof(LowerItem) * items.size(), hipMemcpyHostToDevice));
-            }
-        }
         if (P->low_memory) {
             std::vector<EpiItem> items;
             for (size_t i = 0; i < P->dense_h.size(); ++i)
@@ -445,6 +457,10 @@ int viprs_state_create(viprs_state** out, viprs_plan* plan, int float_dtype, int
     S->float_dtype = float_dtype;
     S->model_kind = model_kind;
     S->width = width;
+    if (plan->n_granule_rows > 0 && model_kind == VIPRS_MODEL_SPIKE_SLAB) {
+        HIP_TRY(S->eta_out.alloc((size_t)plan->m * float_size(float_dtype)));
+        HIP_TRY(S->q_out.alloc((size_t)plan->m * float_size(float_dtype)));
+    }
     for (int k = 0; k < VIPRS_FIELD_COUNT; ++k) {
         const size_t bytes = S->field_elems(k) * float_size(float_dtype);
         HIP_TRY(S->f[k].alloc(bytes));
@@ -480,35 +496,52 @@ int viprs_state_download(viprs_state* S, int field, void* host) {
     HIP_TRY(hipSetDevice(S->plan->device));
     HIP_TRY(hipMemcpyAsync(host, S->f[field].p, bytes, hipMemcpyDeviceToHost, S->plan->stream));
     HIP_TRY(hipStreamSynchronize(S->plan->stream));
-    return VIPRS_OK;
+    return check_device_error(S->plan);
 }
 
 int viprs_state_reset(viprs_state* S, double pi) {
     if (!S) return fail(VIPRS_EINVAL, "null state");
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    const size_t fs = float_size(S->float_dtype);
-    for (int k : {VIPRS_FIELD_VAR_MU, VIPRS_FIELD_ETA, VIPRS_FIELD_Q, VIPRS_FIELD_ETA_DIFF}) {
-        const size_t bytes = S->field_elems(k) * fs;
-        if (bytes) HIP_TRY(hipMemsetAsync(S->f[k].p, 0, bytes, P->stream));
-    }
-    const int64_t n = (int64_t)S->field_elems(VIPRS_FIELD_VAR_GAMMA);
-    if (n) {
-        const unsigned grid = (unsigned)((n + 255) / 256);
-        if (S->float_dtype == VIPRS_F32)
-            fill_kernel<float><<<grid, 256, 0, P->stream>>>((float*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (float)pi, n);
-        else
-            fill_kernel<double><<<grid, 256, 0, P->stream>>>((double*)S->f[VIPRS_FIELD_VAR_GAMMA].p, pi, n);
-        HIP_TRY(hipGetLastError());
+    const int64_t n_wide = (int64_t)S->field_elems(VIPRS_FIELD_VAR_GAMMA);
+    const int64_t n_vec = (int64_t)S->field_elems(VIPRS_FIELD_ETA);
+    const int64_t n = std::max(n_wide, n_vec);
+    if (n == 0) return VIPRS_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (S->float_dtype == VIPRS_F32)
+        reset_state_kernel<float><<<grid, 256, 0, P->stream>>>(
+            (float*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (float*)S->f[VIPRS_FIELD_VAR_MU].p, n_wide,
+            (float*)S->f[VIPRS_FIELD_ETA].p, (float*)S->f[VIPRS_FIELD_Q].p, (float*)S->f[VIPRS_FIELD_ETA_DIFF].p, n_vec,
+            (float)pi);
+    else
+        reset_state_kernel<double><<<grid, 256, 0, P->stream>>>(
+            (double*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (double*)S->f[VIPRS_FIELD_VAR_MU].p, n_wide,
+            (double*)S->f[VIPRS_FIELD_ETA].p, (double*)S->f[VIPRS_FIELD_Q].p, (double*)S->f[VIPRS_FIELD_ETA_DIFF].p, n_vec,
+            pi);
+    HIP_TRY(hipGetLastError());
+    return VIPRS_OK;
+}
+
+}  // extern "C"
+
+// after a synchronisation point: did a team hand-off give up (bounded spin)?
+static int check_device_error(viprs_plan* P) {
+    int32_t e = 0;
+    HIP_TRY(hipMemcpy(&e, P->d_error.p, sizeof(e), hipMemcpyDeviceToHost));
+    if (e != 0) {
+        HIP_TRY(hipMemset(P->d_error.p, 0, sizeof(e)));
+        return fail(VIPRS_EDEVICE, "E-step kernel: a team hand-off timed out (results of this sweep are invalid)");
     }
     return VIPRS_OK;
 }
+
+extern "C" {
 
 int viprs_state_synchronize(viprs_state* S) {
     if (!S) return fail(VIPRS_EINVAL, "null state");
     HIP_TRY(hipSetDevice(S->plan->device));
     HIP_TRY(hipStreamSynchronize(S->plan->stream));
-    return VIPRS_OK;
+    return check_device_error(S->plan);
 }
 
 }  // extern "C"
@@ -537,6 +570,10 @@ EStepArgs<T> make_args(viprs_state* S, double dq) {
     A.eta = (T*)S->f[VIPRS_FIELD_ETA].p;
     A.q = (T*)S->f[VIPRS_FIELD_Q].p;
     A.eta_diff = (T*)S->f[VIPRS_FIELD_ETA_DIFF].p;
+    A.eta_out = (T*)S->eta_out.p;
+    A.q_out = (T*)S->q_out.p;
+    A.granules = P->d_granules.p;
+    A.error = P->d_error.p;
     A.dq = (T)dq;
     A.low_memory = P->low_memory;
     A.width = S->width;
@@ -602,7 +639,7 @@ int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A, int model, bool dense
     }
 }
 
-template <typename U, int NW>
+template <typename U, int NW, int TS>
 int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t stream) {
     const int begin = P->class_begin[cls], end = P->class_begin[cls + 1];
     if (end <= begin) return VIPRS_OK;
@@ -615,7 +652,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     const bool exact = P->math_mode == VIPRS_MATH_EXACT;
     const bool upper = P->low_memory != 0;
     const void* kfn = nullptr;
-#define PK(SY, EX) (const void*)estep_panel_kernel<U, SY, EX, NW>
+#define PK(SY, EX) (const void*)estep_panel_kernel<U, SY, EX, NW, TS>
     if (upper) kfn = exact ? PK(false, true) : PK(false, false);
     else kfn = exact ? PK(true, true) : PK(true, false);
 #undef PK
@@ -625,7 +662,24 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NW * 64, shmem));
     per_cu = std::max(1, per_cu);
-    const int grid = std::min<int>(A.n_blocks, P->n_cu * per_cu);
+    int grid = std::min<int>(A.n_blocks, P->n_cu * per_cu);
+    if (TS == 1) {
+        // leave room for the team workgroups of the larger classes: they must all become resident
+        // while this class's persistent workgroups hold their slots
+        int reserved = 0;
+        for (int c = 0; c < 3; ++c) {
+            const int nb = P->class_begin[c + 1] - P->class_begin[c];
+            if (kClassTeam[c] > 1 && nb > 0)
+                reserved += std::max(1, std::min(nb, P->n_cu / kClassTeam[c])) * kClassTeam[c];
+        }
+        grid = std::min<int>(A.n_blocks, std::max(P->n_cu / 2, P->n_cu * per_cu - reserved));
+    }
+    if (TS > 1) {
+        // teams of TS workgroups, statically assigned blocks; the whole grid must be able to be
+        // resident at once (at most one workgroup per CU is assumed)
+        A.n_teams = std::max(1, std::min<int>(A.n_blocks, P->n_cu / TS));
+        grid = A.n_teams * TS;
+    }
     A.admit = nullptr;
     if (cls == 2 && P->admit_factor > 0.0) {
         if (P->admit_grid != grid) {
@@ -655,15 +709,9 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     }
     void* params[] = {(void*)&A, (void*)&qcap};
     HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(NW * 64), params, shmem, stream));
-    if (!upper) {
-        // deferred lower-left updates of this class, right behind its panel kernel
-        const int lb = P->lower_begin[cls], ln = P->lower_begin[cls + 1] - lb;
-        if (ln > 0) {
-            const int lgrid = std::min((ln + kLowerWaves - 1) / kLowerWaves, P->n_cu * 8);
-            estep_sym_lower_kernel<U, kLowerWaves><<<lgrid, kLowerWaves * 64, 0, stream>>>(
-                A, P->d_lower.p + lb, ln, P->d_counters.p + 8 + cls);
-            HIP_TRY(hipGetLastError());
-        }
+    if (TS > 1) {
+        commit_team_kernel<<<A.n_blocks, 256, 0, stream>>>(A);
+        HIP_TRY(hipGetLastError());
     }
     return VIPRS_OK;
 }
@@ -675,9 +723,9 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A) {
     HIP_TRY(hipEventRecord(P->ev_fork, P->stream));
     int rc;
     for (int c = 0; c < 3; ++c) HIP_TRY(hipStreamWaitEvent(P->class_stream[c], P->ev_fork, 0));
-    if ((rc = launch_panel_class<U, kClassWaves[0]>(P, A, 0, P->class_stream[0])) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[1]>(P, A, 1, P->class_stream[1])) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[2]>(P, A, 2, P->class_stream[2])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[0], kClassTeam[0]>(P, A, 0, P->class_stream[0])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[1], kClassTeam[1]>(P, A, 1, P->class_stream[1])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[2], kClassTeam[2]>(P, A, 2, P->class_stream[2])) != VIPRS_OK) return rc;
     for (int c = 0; c < 3; ++c) {
         HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
         HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join[c], 0));
@@ -695,8 +743,12 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A) {
 int run_spike_slab(viprs_state* S, double dq) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    HIP_TRY(hipMemsetAsync(P->d_counters.p, 0, 16 * sizeof(int32_t), P->stream));
-    HIP_TRY(hipMemsetAsync(P->d_skipped.p, 0, sizeof(unsigned long long), P->stream));
+    {
+        const int64_t ng = P->n_granule_rows * kPanel;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
+        sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, ng);
+        HIP_TRY(hipGetLastError());
+    }
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     HIP_TRY(hipEventRecord(ev[0], P->stream));
     int rc = VIPRS_OK;
@@ -730,7 +782,8 @@ int run_spike_slab(viprs_state* S, double dq) {
 int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_active, int n_active) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    HIP_TRY(hipMemsetAsync(P->d_counters.p, 0, 16 * sizeof(int32_t), P->stream));
+    sweep_prologue_kernel<<<1, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, 0);
+    HIP_TRY(hipGetLastError());
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     HIP_TRY(hipEventRecord(ev[0], P->stream));
     HIP_TRY(hipEventRecord(ev[2], P->stream));
@@ -822,7 +875,7 @@ int viprs_e_step(viprs_plan* P, int float_dtype, const void* std_beta, void* var
     for (int i = 0; i < 5; ++i)
         HIP_TRY(hipMemcpyAsync(outs[i], S->f[out_fields[i]].p, bytes, hipMemcpyDeviceToHost, P->stream));
     HIP_TRY(hipStreamSynchronize(P->stream));
-    return VIPRS_OK;
+    return check_device_error(P);
 }
 
 static int scratch_state(viprs_plan* P, int float_dtype, int model_kind, int width, viprs_state** out) {

@@ -16,16 +16,13 @@
 //                        load per lane per row) and performs q[c] = fma(R[j][c], a_j, q[c]);
 //                        they also stage tile R[p, p+1] into LDS for the chain's next phase.
 //
-// Only the part of the sweep that the serial chain depends on runs here: the updates of columns
-// LEFT of the current panel (q of SNPs already visited) are not needed again in this sweep, so
-// they are deferred to a second, fully parallel kernel:
-//   symmetric form   estep_sym_lower_kernel: column c receives rows (panel(c)+1)*64 .. b-1 in row
-//                    order, q[c] = fma(R[j][c], dq*eta_diff[j], q[c]) -- the same fma chain per
-//                    q-entry as the reference's row-by-row axpy, so results stay bit-identical;
-//   upper-tri form   estep_upper_epilogue_kernel: the reference's own second pass
-//                    (update_q_factor, e_step.hpp:331-337).
-// This halves the bytes a single workgroup (= one CU, ~50 GB/s from HBM) must pull for a large
-// block and makes the other half perfectly balanced over the chip.
+// Symmetric form: columns LEFT of the current panel (q of SNPs already visited) keep receiving the
+// later rows as well (they are what the next sweep starts from); upper-triangular form: the
+// reference's second pass (update_q_factor, e_step.hpp:331-337) runs as its own fully parallel
+// kernel (estep_upper_epilogue_kernel below).
+//
+// Large blocks (a single CU pulls only ~50 GB/s from HBM) are shared by a TEAM of TS workgroups on
+// TS CUs: see the comment at `team` in the kernel.
 #pragma once
 #include "device_math.h"
 #include "kernels_common.h"
@@ -101,7 +98,7 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
     *reinterpret_cast<float4*>(lq_c) = qv;
 }
 
-template <typename U, bool SYM, bool EXACT, int NW>
+template <typename U, bool SYM, bool EXACT, int NW, int TS>
 __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A, int qcap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lq = smem;
@@ -133,16 +130,34 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
         }
     }
 
+    // Teams (TS > 1): TS workgroups on TS different CUs share one large block.  Every member runs
+    // the (deterministic) serial chain itself, so no a-vector ever has to be communicated; the
+    // trailing updates are split by column strip (strip s belongs to member s % TS), and the owner of
+    // a strip hands the q values of each of its panels to the other members once, just before the
+    // chain reaches it, through 8-byte {tag, value} granules in global memory (one relaxed
+    // agent-scope atomic store / load per lane; the data is the flag, so no fence is needed).
+    // Blocks are assigned to teams statically (team t: blocks t, t + n_teams, ...).
+    const int team = (TS > 1) ? (int)blockIdx.x / TS : 0;
+    const int member = (TS > 1) ? (int)blockIdx.x % TS : 0;
+    int team_iter = 0;
+
     for (;;) {
-        if (tid == 0) s_blk = atomicAdd(A.counter, 1);
-        __syncthreads();
-        const int blk = s_blk;
-        __syncthreads();
+        int blk;
+        if (TS > 1) {
+            blk = team + team_iter * A.n_teams;
+            ++team_iter;
+        } else {
+            if (tid == 0) s_blk = atomicAdd(A.counter, 1);
+            __syncthreads();
+            blk = s_blk;
+            __syncthreads();
+        }
         if (blk >= A.n_blocks) break;
 
         const BlockDesc bd = A.blocks[blk];
         const int64_t s0 = bd.start;
         const int b = bd.size;
+        unsigned long long* __restrict__ gran = (TS > 1) ? A.granules + bd.gr_off * kPanel : nullptr;
         const int stride = bd.stride;
         const U* __restrict__ base = ldd + bd.ld_off;
         const int np = (b + kPanel - 1) / kPanel;
@@ -170,10 +185,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                 dnext[k] = static_cast<float>(base[(int64_t)min(k, b - 1) * stride + lane]);
         }
 
-        for (int p = 0; p < np; ++p) {
+        // symmetric form: one extra phase applies the last panel's a-vector to the columns left of it
+        for (int p = 0; p < np + (SYM ? 1 : 0); ++p) {
             if (wave == 0) {
                 // ================================ chain ======================================
-                {
+                if (p < np) {
                     const int r0 = p * kPanel;
                     const int nrows = min(kPanel, b - r0);
                     const int64_t j = s0 + r0 + lane;
@@ -205,6 +221,22 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const U* __restrict__ nptr = base + (int64_t)rn0 * stride + rn0 + lane;
 
                     float qc = lq[r0 + lane];
+                    if (TS > 1 && p >= 2 && ((p >> 2) % TS) != member) {
+                        // panel p lives in another member's strip: take its q (all trailing updates
+                        // a_0 .. a_{p-2} applied) from the owner's granules, tag = p + 1
+                        unsigned long long g = 0;
+                        for (unsigned spins = 0;; ++spins) {
+                            g = __hip_atomic_load(gran + (int64_t)p * kPanel + lane, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                            if (__all((unsigned)(g >> 32) == (unsigned)(p + 1))) break;
+                            if (spins > (1u << 22)) {          // ~seconds: give up loudly, never hang
+                                if (lane == 0) atomicExch(A.error, 1);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        qc = __uint_as_float((unsigned)g);
+                    }
                     if (p > 0) {
                         // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
                         const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
@@ -246,15 +278,16 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     float mu, gamma, d;
                     snp_update<EXACT, kLookupPerLane>(mm, beta, sv, ulog, eta_old, qcap_v, tab, mu, gamma, d);
                     const bool skip = fabsf(d) < eps;
-                    if (live) {
+                    if (live && member == 0) {
                         if (!skip) {
                             A.var_mu[j] = mu;
                             A.var_gamma[j] = gamma;
                             A.eta_diff[j] = d;
-                            A.eta[j] = eta_old + d;
+                            if (TS == 1) A.eta[j] = eta_old + d;
                         } else {
                             A.eta_diff[j] = 0.0f;
                         }
+                        if (TS > 1) A.eta_out[j] = skip ? eta_old : eta_old + d;
                     }
                     my_skipped += __popcll(__ballot(live && skip));
                     a_prev = (live && !skip) ? dq * d : 0.0f;
@@ -279,111 +312,62 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const int rr0 = pp * kPanel;
                     const int last_row = min(kPanel, b - rr0) - 1;
                     const float avec = la[(pp & 1) * kPanel + lane];
-                    if (__ballot(avec != 0.0f)) {
-                        const int nstrips = (bpad + kStrip - 1) / kStrip;
-                        for (int s = uw; s < nstrips; s += NW - 1) {
-                            const int c = s * kStrip + 4 * lane;
-                            const int cp = c >> 6;
-                            const bool active = (c < b) && (cp > p);   // right of the chain's panels only
-                            if (active) {
-                                if (last_row == kPanel - 1)
-                                    strip_update<U, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
-                                else
-                                    strip_update<U, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
-                            }
+                    const int nstrips = (bpad + kStrip - 1) / kStrip;
+                    const bool any_a = __ballot(avec != 0.0f) != 0;
+                    // strips of this member are dealt round-robin to its updater waves; the strip
+                    // that holds panel p+1 goes first so that its q can be handed over early
+                    const int s_pri = (p + 1) >> 2;
+                    const int n_mine = (nstrips - member + TS - 1) / TS;       // strips member, member+TS, ...
+                    for (int k = uw; k < n_mine; k += NW - 1) {
+                        int st = member + k * TS;
+                        if (TS > 1) {
+                            // rotate so that the priority strip (if this member owns it) is slot 0
+                            const int k_pri = (s_pri % TS == member) ? (s_pri - member) / TS : 0;
+                            st = member + ((k + k_pri) % n_mine) * TS;
+                        }
+                        const int c = st * kStrip + 4 * lane;
+                        const int cp = c >> 6;
+                        // symmetric form: every column except the chain's two panels (left of the
+                        // chain = SNPs already visited, their q keeps accumulating for the next
+                        // sweep); upper-triangular form: right of the chain only (the rest is the
+                        // reference's second pass, estep_upper_epilogue_kernel)
+                        const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
+                        if (any_a && active) {
+                            if (last_row == kPanel - 1)
+                                strip_update<U, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                            else
+                                strip_update<U, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                        }
+                        if (TS > 1 && st == s_pri && p + 1 < np && p + 1 >= 2) {
+                            // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
+                            __builtin_amdgcn_wave_barrier();
+                            const float v = lq[(p + 1) * kPanel + lane];
+                            const unsigned long long g =
+                                ((unsigned long long)(unsigned)(p + 2) << 32) | (unsigned long long)__float_as_uint(v);
+                            __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                 }
             }
             __syncthreads();
         }
-        for (int i = tid; i < b; i += NW * 64) A.q[s0 + i] = lq[i];
+        {   // teams: every member owns the final q of its own strips
+            float* __restrict__ qdst = (TS > 1) ? A.q_out : A.q;
+            for (int i = tid; i < b; i += NW * 64)
+                if (TS == 1 || ((i / kStrip) % TS) == member) qdst[s0 + i] = lq[i];
+        }
         __syncthreads();
     }
-    if (lane == 0 && my_skipped) atomicAdd(A.skipped, my_skipped);
+    if (lane == 0 && my_skipped && member == 0) atomicAdd(A.skipped, my_skipped);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Symmetric form, deferred lower-left updates: for column c of a block, apply rows
-// (panel(c)+1)*64 .. b-1 in row order: q[c] = fma(R[j][c], dq * eta_diff[j], q[c]).
-// (eta_diff[j] == 0 for SNPs that took the skip branch, which makes their rows exact no-ops,
-// as in the reference where the axpy is not executed.)  One wave owns 256 columns (4 per lane,
-// one 16-byte load per lane per row), items come from a work queue in descending row count.
-// ---------------------------------------------------------------------------------------------
-struct LowerItem { int32_t blk; int32_t strip; };
-
-constexpr int kLowerCols = 2;                       // columns per lane
-constexpr int kLowerStrip = 64 * kLowerCols;        // columns per wave (whole panels)
-constexpr int kLowerPrefetch = 32;                  // row loads in flight per lane
-
-template <typename U> struct LdVec2;
-template <> struct LdVec2<float> {
-    static __device__ __forceinline__ float2 load(const float* p) { return *reinterpret_cast<const float2*>(p); }
-};
-template <> struct LdVec2<int8_t> {
-    static __device__ __forceinline__ float2 load(const int8_t* p) {
-        const short w = *reinterpret_cast<const short*>(p);
-        return make_float2((float)(int8_t)(w), (float)(int8_t)(w >> 8));
-    }
-};
-template <> struct LdVec2<int16_t> {
-    static __device__ __forceinline__ float2 load(const int16_t* p) {
-        const int w = *reinterpret_cast<const int*>(p);
-        return make_float2((float)(int16_t)(w), (float)(int16_t)(w >> 16));
-    }
-};
-
-template <typename U, int NW>
-__global__ __launch_bounds__(NW * 64) void estep_sym_lower_kernel(EStepArgs<float> A, const LowerItem* items,
-                                                                  int n_items, int32_t* counter) {
-    const int lane = threadIdx.x & 63;
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
-    const float dq = A.dq;
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const LowerItem it = items[item];
-        const BlockDesc bd = A.blocks[it.blk];
-        const int b = bd.size, stride = bd.stride;
-        const int64_t s0 = bd.start;
-        const U* __restrict__ base = ldd + bd.ld_off;
-        const int c = it.strip * kLowerStrip + kLowerCols * lane;
-        const int cc = min(c, stride - kLowerCols);        // lanes past the block read padding (zeros)
-        const int cp = c >> 6;
-        const bool active = c < b;
-        float2 qv = make_float2(0.f, 0.f);
-        if (active) {
-            qv.x = A.q[s0 + c];
-            if (c + 1 < b) qv.y = A.q[s0 + c + 1];
-        }
-        const int row_begin = (it.strip * (kLowerStrip / kPanel) + 1) * kPanel;   // first row any lane needs
-        const U* __restrict__ colp = base + cc;
-        float2 buf[kLowerPrefetch];
-#pragma unroll
-        for (int k = 0; k < kLowerPrefetch; ++k)
-            buf[k] = LdVec2<U>::load(colp + (int64_t)min(row_begin + k, b - 1) * stride);
-        for (int r0 = row_begin; r0 < b; r0 += kLowerPrefetch) {
-            // a-values of this row group, lane k = row r0 + k
-            const int rk = r0 + (lane & (kLowerPrefetch - 1));
-            const float av = (rk < b) ? dq * A.eta_diff[s0 + rk] : 0.0f;
-            const bool mine = (r0 >> 6) > cp;              // rows of a later panel than this lane's columns
-#pragma unroll
-            for (int k = 0; k < kLowerPrefetch; ++k) {
-                const float2 v = buf[k];
-                buf[k] = LdVec2<U>::load(colp + (int64_t)min(r0 + kLowerPrefetch + k, b - 1) * stride);
-                float a = rl(av, k);
-                a = mine ? a : 0.0f;
-                qv.x = __builtin_fmaf(v.x, a, qv.x);
-                qv.y = __builtin_fmaf(v.y, a, qv.y);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (active) {
-            A.q[s0 + c] = qv.x;
-            if (c + 1 < b) A.q[s0 + c + 1] = qv.y;
-        }
+// Copies the team kernels' eta / q outputs into place (runs behind the team kernel on its stream).
+__global__ void commit_team_kernel(EStepArgs<float> A) {
+    const BlockDesc bd = A.blocks[blockIdx.x];
+    for (int i = threadIdx.x; i < bd.size; i += blockDim.x) {
+        A.eta[bd.start + i] = A.eta_out[bd.start + i];
+        A.q[bd.start + i] = A.q_out[bd.start + i];
     }
 }
 

@@ -15,6 +15,7 @@ struct BlockDesc {
     int32_t stride;     // row stride (elements) of the repacked dense block (multiple of 64)
     int32_t kind;       // viprs_block_kind
     int64_t ld_off;     // element offset of the repacked block inside the dense LD buffer
+    int64_t gr_off;     // team kernels: first granule row (one row of 64 granules per panel) of this block
 };
 
 // Per-call argument pack for the spike-and-slab kernels (T = state float type).
@@ -24,6 +25,9 @@ struct EStepArgs {
     int32_t n_blocks;
     int32_t* counter;            // work-queue head (zeroed before every launch)
     const int32_t* admit;        // per-workgroup admission threshold on the queue head (may be null)
+    unsigned long long* granules; // team kernels: {tag, value} hand-off granules (zeroed before every launch)
+    int32_t* error;              // set to non-zero when a bounded spin gives up
+    int32_t n_teams;             // team kernels: number of teams in the launch
     unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
     // row addressing for the generic kernels: row j holds rowlen[j] elements starting at element
     // rowstart[j] of ld_rows, covering columns lb[j] .. lb[j] + rowlen[j] - 1.  (Either the caller's
@@ -45,6 +49,8 @@ struct EStepArgs {
     T* eta;
     T* q;
     T* eta_diff;
+    T* eta_out;           // team kernels: eta / q are in-out, but other members of a team still read the old
+    T* q_out;             //   values, so member 0 writes here and commit_team_kernel copies into place
     T dq;
     int32_t low_memory;
     int32_t width;        // K (mixture) / G (grid); 1 otherwise
