@@ -51,7 +51,8 @@ size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0);
 // the same CU resources as a small-block workgroup; larger blocks get more CUs, not bigger groups.
 static int kLargeBlock = 2304, kMediumBlock = 1280;
 constexpr int kClassWaves[3] = {4, 4, 4};
-constexpr int kClassTeam[3] = {8, 4, 1};    // workgroups (CUs) sharing one block of the class
+static int kClassTeam[3] = {8, 3, 1};       // workgroups (CUs) sharing one block of the class (0/1: teams)
+constexpr int kClassCols[3] = {2, 4, 4};    // columns per updater lane: narrower strips = more streaming waves per block
 constexpr int kEpiWaves = 4;
 
 template <typename V> struct DevBuf {
@@ -252,6 +253,8 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
     if (const char* f = getenv("VIPRS_LARGE_BLOCK")) kLargeBlock = atoi(f);
     if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) kMediumBlock = atoi(f);
+    if (const char* f = getenv("VIPRS_TEAM0")) kClassTeam[0] = std::max(1, atoi(f));
+    if (const char* f = getenv("VIPRS_TEAM1")) kClassTeam[1] = std::max(1, atoi(f));
     P->low_memory = low_memory != 0;
     P->ld_dtype = ld_dtype;
     P->device = device;
@@ -271,7 +274,7 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         for (int c = 0; c < 3; ++c)
             HIP_TRY(hipStreamCreateWithPriority(&P->class_stream[c], hipStreamNonBlocking,
-                                                kClassTeam[c] > 1 ? prio_hi : prio_lo));
+                                                c < 2 ? prio_hi : prio_lo));
     }
     HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
     for (auto& e : P->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -384,6 +387,10 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
             std::vector<EpiItem> items;
             for (size_t i = 0; i < P->dense_h.size(); ++i)
                 for (int r0 = 0; r0 < P->dense_h[i].size; r0 += kPanel) items.push_back({(int32_t)i, r0});
+            // longest rows first (the item cost is the number of columns right of its rows)
+            std::stable_sort(items.begin(), items.end(), [&](const EpiItem& x, const EpiItem& y) {
+                return P->dense_h[(size_t)x.blk].size - x.row0 > P->dense_h[(size_t)y.blk].size - y.row0;
+            });
             P->n_epi = (int64_t)items.size();
             HIP_TRY(P->d_epi.alloc(items.size()));
             HIP_TRY(hipMemcpy(P->d_epi.p, items.data(), sizeof(EpiItem) * items.size(), hipMemcpyHostToDevice));
@@ -639,7 +646,7 @@ int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A, int model, bool dense
     }
 }
 
-template <typename U, int NW, int TS>
+template <typename U, int NW, bool TEAM, int CPL>
 int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t stream) {
     const int begin = P->class_begin[cls], end = P->class_begin[cls + 1];
     if (end <= begin) return VIPRS_OK;
@@ -652,7 +659,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     const bool exact = P->math_mode == VIPRS_MATH_EXACT;
     const bool upper = P->low_memory != 0;
     const void* kfn = nullptr;
-#define PK(SY, EX) (const void*)estep_panel_kernel<U, SY, EX, NW, TS>
+#define PK(SY, EX) (const void*)estep_panel_kernel<U, SY, EX, NW, TEAM, CPL>
     if (upper) kfn = exact ? PK(false, true) : PK(false, false);
     else kfn = exact ? PK(true, true) : PK(true, false);
 #undef PK
@@ -663,18 +670,20 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NW * 64, shmem));
     per_cu = std::max(1, per_cu);
     int grid = std::min<int>(A.n_blocks, P->n_cu * per_cu);
-    if (TS == 1) {
+    const int TS = TEAM ? kClassTeam[cls] : 1;
+    A.team_size = TS;
+    if (!TEAM) {
         // leave room for the team workgroups of the larger classes: they must all become resident
         // while this class's persistent workgroups hold their slots
         int reserved = 0;
         for (int c = 0; c < 3; ++c) {
             const int nb = P->class_begin[c + 1] - P->class_begin[c];
-            if (kClassTeam[c] > 1 && nb > 0)
+            if (c < 2 && nb > 0)
                 reserved += std::max(1, std::min(nb, P->n_cu / kClassTeam[c])) * kClassTeam[c];
         }
         grid = std::min<int>(A.n_blocks, std::max(P->n_cu / 2, P->n_cu * per_cu - reserved));
     }
-    if (TS > 1) {
+    if (TEAM) {
         // teams of TS workgroups, statically assigned blocks; the whole grid must be able to be
         // resident at once (at most one workgroup per CU is assumed)
         A.n_teams = std::max(1, std::min<int>(A.n_blocks, P->n_cu / TS));
@@ -709,7 +718,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     }
     void* params[] = {(void*)&A, (void*)&qcap};
     HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(NW * 64), params, shmem, stream));
-    if (TS > 1) {
+    if (TEAM) {
         commit_team_kernel<<<A.n_blocks, 256, 0, stream>>>(A);
         HIP_TRY(hipGetLastError());
     }
@@ -723,9 +732,9 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A) {
     HIP_TRY(hipEventRecord(P->ev_fork, P->stream));
     int rc;
     for (int c = 0; c < 3; ++c) HIP_TRY(hipStreamWaitEvent(P->class_stream[c], P->ev_fork, 0));
-    if ((rc = launch_panel_class<U, kClassWaves[0], kClassTeam[0]>(P, A, 0, P->class_stream[0])) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[1], kClassTeam[1]>(P, A, 1, P->class_stream[1])) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[2], kClassTeam[2]>(P, A, 2, P->class_stream[2])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[0], true, kClassCols[0]>(P, A, 0, P->class_stream[0])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[1], true, kClassCols[1]>(P, A, 1, P->class_stream[1])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[2], false, kClassCols[2]>(P, A, 2, P->class_stream[2])) != VIPRS_OK) return rc;
     for (int c = 0; c < 3; ++c) {
         HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
         HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join[c], 0));
@@ -733,8 +742,9 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A) {
     if (P->low_memory && P->n_epi > 0) {
         A.blocks = P->d_dense.p;
         A.n_blocks = (int)P->dense_h.size();
-        const int eg = (int)((P->n_epi + kEpiWaves - 1) / kEpiWaves);
-        estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, P->stream>>>(A, P->d_epi.p, (int)P->n_epi);
+        const int eg = (int)std::min<int64_t>((P->n_epi + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
+        estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, P->stream>>>(A, P->d_epi.p, (int)P->n_epi,
+                                                                                         P->d_counters.p + 3);
         HIP_TRY(hipGetLastError());
     }
     return VIPRS_OK;

@@ -45,60 +45,92 @@ template <> __device__ __forceinline__ float4 load4<int16_t>(const int16_t* p) {
                        (float)(int16_t)(w.y >> 16));
 }
 
+// CPL consecutive columns of one row as floats (CPL = 4: one 16-byte load for f32)
+template <int CPL> struct RowVec { float v[CPL]; };
+
+template <typename U, int CPL> __device__ __forceinline__ RowVec<CPL> load_cols(const U* p);
+template <> __device__ __forceinline__ RowVec<4> load_cols<float, 4>(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return RowVec<4>{{t.x, t.y, t.z, t.w}};
+}
+template <> __device__ __forceinline__ RowVec<2> load_cols<float, 2>(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    return RowVec<2>{{t.x, t.y}};
+}
+template <> __device__ __forceinline__ RowVec<1> load_cols<float, 1>(const float* p) { return RowVec<1>{{*p}}; }
+template <> __device__ __forceinline__ RowVec<4> load_cols<int8_t, 4>(const int8_t* p) {
+    const float4 t = load4<int8_t>(p);
+    return RowVec<4>{{t.x, t.y, t.z, t.w}};
+}
+template <> __device__ __forceinline__ RowVec<2> load_cols<int8_t, 2>(const int8_t* p) {
+    const short w = *reinterpret_cast<const short*>(p);
+    return RowVec<2>{{(float)(int8_t)(w), (float)(int8_t)(w >> 8)}};
+}
+template <> __device__ __forceinline__ RowVec<1> load_cols<int8_t, 1>(const int8_t* p) { return RowVec<1>{{(float)*p}}; }
+template <> __device__ __forceinline__ RowVec<4> load_cols<int16_t, 4>(const int16_t* p) {
+    const float4 t = load4<int16_t>(p);
+    return RowVec<4>{{t.x, t.y, t.z, t.w}};
+}
+template <> __device__ __forceinline__ RowVec<2> load_cols<int16_t, 2>(const int16_t* p) {
+    const int w = *reinterpret_cast<const int*>(p);
+    return RowVec<2>{{(float)(int16_t)(w), (float)(int16_t)(w >> 16)}};
+}
+template <> __device__ __forceinline__ RowVec<1> load_cols<int16_t, 1>(const int16_t* p) { return RowVec<1>{{(float)*p}}; }
+
 __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
 constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
-constexpr int kStripPrefetch = 16;   // row loads in flight per updater lane
+constexpr int kStripBytesInFlight = 64;  // floats of row data in flight per updater lane (16 x 16 B)
 
 // LDS carve (floats): q[qcap] | a[2][64] | T[2][64*64]
 __host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
 
-// Trailing update of one 256-column strip by one wave: q[c..c+3] = fma(R[row][c..c+3], a_row, .)
-// for the 64 rows of a panel, in row order, with kStripPrefetch row loads (16 B per lane each) in
-// flight per wave.  The row loop is rolled in groups of kStripPrefetch so that every load is
-// consumed exactly one group later (a fully unrolled loop lets hipcc sink the loads next to their
-// uses, leaving two in flight), and there is no runtime guard around any load (a guard makes hipcc
-// wait vmcnt(0) per row).  FULL = false (partial last panel of a block): rows past its end are
-// clamped to its last row; their a is 0, so fma(R, 0, q) == q leaves q untouched.
-template <typename U, bool FULL>
+// Trailing update of one strip (64 * CPL columns) by one wave: q[c..c+CPL-1] = fma(R[row][c..], a_row, .)
+// for the 64 rows of a panel, in row order, with DEPTH row loads in flight per lane (DEPTH * CPL = 64
+// floats of row data per lane whatever the strip width).  The row loop is rolled in groups of DEPTH
+// so that every load is consumed exactly one group later (a fully unrolled loop lets hipcc sink the
+// loads next to their uses, leaving two in flight), and there is no runtime guard around any load
+// (a guard makes hipcc wait vmcnt(0) per row).  FULL = false (partial last panel of a block): rows
+// past its end are clamped to its last row; their a is 0, so fma(R, 0, q) == q leaves q untouched.
+template <typename U, int CPL, bool FULL>
 __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int last_row, float avec,
                                              float* __restrict__ lq_c) {
-    static_assert(kPanel % kStripPrefetch == 0, "panel must be a whole number of prefetch groups");
-    float4 qv = *reinterpret_cast<float4*>(lq_c);
-    float4 buf[kStripPrefetch];
+    constexpr int DEPTH = kStripBytesInFlight / CPL;
+    static_assert(kPanel % DEPTH == 0, "panel must be a whole number of prefetch groups");
+    float qv[CPL];
 #pragma unroll
-    for (int k = 0; k < kStripPrefetch; ++k)
-        buf[k] = load4<U>(rowp + (int64_t)(FULL ? k : min(k, last_row)) * stride);
+    for (int i = 0; i < CPL; ++i) qv[i] = lq_c[i];
+    RowVec<CPL> buf[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+        buf[k] = load_cols<U, CPL>(rowp + (int64_t)(FULL ? k : min(k, last_row)) * stride);
 #pragma unroll 1
-    for (int g = 0; g < kPanel / kStripPrefetch - 1; ++g) {
+    for (int g = 0; g < kPanel / DEPTH - 1; ++g) {
 #pragma unroll
-        for (int k = 0; k < kStripPrefetch; ++k) {
-            const float4 v = buf[k];
-            const int rn = kStripPrefetch * (g + 1) + k;
-            buf[k] = load4<U>(rowp + (int64_t)(FULL ? rn : min(rn, last_row)) * stride);
-            const float a = rl(avec, kStripPrefetch * g + k);
-            qv.x = __builtin_fmaf(v.x, a, qv.x);
-            qv.y = __builtin_fmaf(v.y, a, qv.y);
-            qv.z = __builtin_fmaf(v.z, a, qv.z);
-            qv.w = __builtin_fmaf(v.w, a, qv.w);
+        for (int k = 0; k < DEPTH; ++k) {
+            const RowVec<CPL> v = buf[k];
+            const int rn = DEPTH * (g + 1) + k;
+            buf[k] = load_cols<U, CPL>(rowp + (int64_t)(FULL ? rn : min(rn, last_row)) * stride);
+            const float a = rl(avec, DEPTH * g + k);
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.v[i], a, qv[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
-    for (int k = 0; k < kStripPrefetch; ++k) {
-        const float4 v = buf[k];
-        const float a = rl(avec, kPanel - kStripPrefetch + k);
-        qv.x = __builtin_fmaf(v.x, a, qv.x);
-        qv.y = __builtin_fmaf(v.y, a, qv.y);
-        qv.z = __builtin_fmaf(v.z, a, qv.z);
-        qv.w = __builtin_fmaf(v.w, a, qv.w);
+    for (int k = 0; k < DEPTH; ++k) {
+        const RowVec<CPL> v = buf[k];
+        const float a = rl(avec, kPanel - DEPTH + k);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.v[i], a, qv[i]);
     }
-    *reinterpret_cast<float4*>(lq_c) = qv;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) lq_c[i] = qv[i];
 }
 
-template <typename U, bool SYM, bool EXACT, int NW, int TS>
+template <typename U, bool SYM, bool EXACT, int NW, bool TEAM, int CPL>
 __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A, int qcap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lq = smem;
@@ -137,13 +169,15 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     // chain reaches it, through 8-byte {tag, value} granules in global memory (one relaxed
     // agent-scope atomic store / load per lane; the data is the flag, so no fence is needed).
     // Blocks are assigned to teams statically (team t: blocks t, t + n_teams, ...).
-    const int team = (TS > 1) ? (int)blockIdx.x / TS : 0;
-    const int member = (TS > 1) ? (int)blockIdx.x % TS : 0;
+    constexpr int kSW = kPanel * CPL;                   // strip width (columns per updater wave)
+    const int TS = TEAM ? A.team_size : 1;
+    const int team = TEAM ? (int)blockIdx.x / TS : 0;
+    const int member = TEAM ? (int)blockIdx.x % TS : 0;
     int team_iter = 0;
 
     for (;;) {
         int blk;
-        if (TS > 1) {
+        if (TEAM) {
             blk = team + team_iter * A.n_teams;
             ++team_iter;
         } else {
@@ -157,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
         const BlockDesc bd = A.blocks[blk];
         const int64_t s0 = bd.start;
         const int b = bd.size;
-        unsigned long long* __restrict__ gran = (TS > 1) ? A.granules + bd.gr_off * kPanel : nullptr;
+        unsigned long long* __restrict__ gran = TEAM ? A.granules + bd.gr_off * kPanel : nullptr;
         const int stride = bd.stride;
         const U* __restrict__ base = ldd + bd.ld_off;
         const int np = (b + kPanel - 1) / kPanel;
@@ -221,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const U* __restrict__ nptr = base + (int64_t)rn0 * stride + rn0 + lane;
 
                     float qc = lq[r0 + lane];
-                    if (TS > 1 && p >= 2 && ((p >> 2) % TS) != member) {
+                    if (TEAM && p >= 2 && (((p * kPanel) / kSW) % TS) != member) {
                         // panel p lives in another member's strip: take its q (all trailing updates
                         // a_0 .. a_{p-2} applied) from the owner's granules, tag = p + 1
                         unsigned long long g = 0;
@@ -283,11 +317,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                             A.var_mu[j] = mu;
                             A.var_gamma[j] = gamma;
                             A.eta_diff[j] = d;
-                            if (TS == 1) A.eta[j] = eta_old + d;
+                            if (!TEAM) A.eta[j] = eta_old + d;
                         } else {
                             A.eta_diff[j] = 0.0f;
                         }
-                        if (TS > 1) A.eta_out[j] = skip ? eta_old : eta_old + d;
+                        if (TEAM) A.eta_out[j] = skip ? eta_old : eta_old + d;
                     }
                     my_skipped += __popcll(__ballot(live && skip));
                     a_prev = (live && !skip) ? dq * d : 0.0f;
@@ -312,20 +346,20 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const int rr0 = pp * kPanel;
                     const int last_row = min(kPanel, b - rr0) - 1;
                     const float avec = la[(pp & 1) * kPanel + lane];
-                    const int nstrips = (bpad + kStrip - 1) / kStrip;
+                    const int nstrips = (bpad + kSW - 1) / kSW;
                     const bool any_a = __ballot(avec != 0.0f) != 0;
                     // strips of this member are dealt round-robin to its updater waves; the strip
                     // that holds panel p+1 goes first so that its q can be handed over early
-                    const int s_pri = (p + 1) >> 2;
+                    const int s_pri = ((p + 1) * kPanel) / kSW;
                     const int n_mine = (nstrips - member + TS - 1) / TS;       // strips member, member+TS, ...
                     for (int k = uw; k < n_mine; k += NW - 1) {
                         int st = member + k * TS;
-                        if (TS > 1) {
+                        if (TEAM) {
                             // rotate so that the priority strip (if this member owns it) is slot 0
                             const int k_pri = (s_pri % TS == member) ? (s_pri - member) / TS : 0;
                             st = member + ((k + k_pri) % n_mine) * TS;
                         }
-                        const int c = st * kStrip + 4 * lane;
+                        const int c = st * kSW + CPL * lane;
                         const int cp = c >> 6;
                         // symmetric form: every column except the chain's two panels (left of the
                         // chain = SNPs already visited, their q keeps accumulating for the next
@@ -334,11 +368,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
                         if (any_a && active) {
                             if (last_row == kPanel - 1)
-                                strip_update<U, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                strip_update<U, CPL, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
                             else
-                                strip_update<U, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                strip_update<U, CPL, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
                         }
-                        if (TS > 1 && st == s_pri && p + 1 < np && p + 1 >= 2) {
+                        if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
                             // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
                             __builtin_amdgcn_wave_barrier();
                             const float v = lq[(p + 1) * kPanel + lane];
@@ -353,9 +387,9 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
             __syncthreads();
         }
         {   // teams: every member owns the final q of its own strips
-            float* __restrict__ qdst = (TS > 1) ? A.q_out : A.q;
+            float* __restrict__ qdst = TEAM ? A.q_out : A.q;
             for (int i = tid; i < b; i += NW * 64)
-                if (TS == 1 || ((i / kStrip) % TS) == member) qdst[s0 + i] = lq[i];
+                if (!TEAM || ((i / kSW) % TS) == member) qdst[s0 + i] = lq[i];
         }
         __syncthreads();
     }
@@ -382,41 +416,53 @@ struct EpiItem { int32_t blk; int32_t row0; };
 
 template <typename U, int NW>
 __global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs<float> A, const EpiItem* items,
-                                                                       int n_items) {
+                                                                       int n_items, int32_t* counter) {
     __shared__ float tile[NW][kPanel * (kPanel + 1)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
-    const int item = blockIdx.x * NW + wave;
-    if (item >= n_items) return;
-    const EpiItem it = items[item];
-    const BlockDesc bd = A.blocks[it.blk];
-    const int b = bd.size, stride = bd.stride, r0 = it.row0;
-    const int64_t s0 = bd.start;
-    const U* __restrict__ base = ldd + bd.ld_off;
-    const int nrows = min(kPanel, b - r0);
     float* tl = tile[wave];
-    float s = 0.0f;
-    for (int c0 = r0; c0 < b; c0 += kPanel) {
-        const int col = c0 + lane;
-        const float dv = (col < b) ? A.eta_diff[s0 + col] : 0.0f;
-        // row-wise coalesced loads -> LDS (pitch 65)
-#pragma unroll 8
-        for (int k = 0; k < kPanel; ++k) {
-            float v = 0.0f;
-            if (k < nrows && col < b) v = static_cast<float>(base[(int64_t)(r0 + k) * stride + col]);
-            tl[k * (kPanel + 1) + lane] = v;
+    for (;;) {
+        // persistent waves pull (block, 64-row group) items, longest rows first
+        int item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const EpiItem it = items[item];
+        const BlockDesc bd = A.blocks[it.blk];
+        const int b = bd.size, stride = bd.stride, r0 = it.row0;
+        const int64_t s0 = bd.start;
+        const U* __restrict__ base = ldd + bd.ld_off;
+        const int nrows = min(kPanel, b - r0);
+        float s = 0.0f;
+
+        // all 64 row loads of a tile are issued before the previous tile is consumed: one tile
+        // (16 KB per wave) is always in flight
+        float cur[kPanel], nxt[kPanel];
+        const U* __restrict__ p0 = base + (int64_t)r0 * stride + lane;
+#pragma unroll
+        for (int k = 0; k < kPanel; ++k) cur[k] = static_cast<float>(p0[(int64_t)min(k, nrows - 1) * stride + r0]);
+        for (int c0 = r0; c0 < b; c0 += kPanel) {
+            const int cn = (c0 + kPanel < b) ? c0 + kPanel : c0;            // next tile (or this one again)
+#pragma unroll
+            for (int k = 0; k < kPanel; ++k) nxt[k] = static_cast<float>(p0[(int64_t)min(k, nrows - 1) * stride + cn]);
+            const int col = c0 + lane;
+            const float dv = (col < b) ? A.eta_diff[s0 + col] : 0.0f;
+            // transpose through LDS (pitch 65: conflict-free both ways): lane r walks row r
+#pragma unroll
+            for (int k = 0; k < kPanel; ++k) tl[k * (kPanel + 1) + lane] = cur[k];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 16
+            for (int i = 0; i < kPanel; ++i) {
+                const float v = tl[lane * (kPanel + 1) + i];
+                const float di = rl(dv, i);
+                if (c0 + i > r0 + lane) s = __builtin_fmaf(v, di, s);      // strictly right of the diagonal
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < kPanel; ++k) cur[k] = nxt[k];
         }
-        __builtin_amdgcn_wave_barrier();
-        // lane r walks row r in column order
-#pragma unroll 8
-        for (int i = 0; i < kPanel; ++i) {
-            const float v = tl[lane * (kPanel + 1) + i];
-            const float di = rl(dv, i);
-            if (c0 + i > r0 + lane) s = __builtin_fmaf(v, di, s);
-        }
-        __builtin_amdgcn_wave_barrier();
+        if (lane < nrows) A.q[s0 + r0 + lane] += A.dq * s;
     }
-    if (lane < nrows) A.q[s0 + r0 + lane] += A.dq * s;
 }
 
 }  // namespace viprs

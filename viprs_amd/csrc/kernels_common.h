@@ -28,6 +28,7 @@ struct EStepArgs {
     unsigned long long* granules; // team kernels: {tag, value} hand-off granules (zeroed before every launch)
     int32_t* error;              // set to non-zero when a bounded spin gives up
     int32_t n_teams;             // team kernels: number of teams in the launch
+    int32_t team_size;           // team kernels: workgroups per team
     unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
     // row addressing for the generic kernels: row j holds rowlen[j] elements starting at element
     // rowstart[j] of ld_rows, covering columns lb[j] .. lb[j] + rowlen[j] - 1.  (Either the caller's
