@@ -222,7 +222,9 @@ def main():
                 "step": "device state re-init + one E-step sweep over all blocks",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "estep_panel_kernel" + (" + estep_upper_epilogue_kernel" if ld.low_memory else ""),
+                "bound": "hbm",
+                "kernel": "estep_panel_kernel (3 size classes on 3 streams; the largest two share blocks between CUs)"
+                          + (" + estep_upper_epilogue_kernel" if ld.low_memory else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_ms_avg": k_avg_ms, "sweep_ms_avg": float(np.mean(sweep_ms)) if sweep_ms else None,
