@@ -116,11 +116,15 @@ def main():
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
 
     dist = None
+    backend = os.environ.get("VIPRS_BENCH_BACKEND", "nccl")       # nccl = RCCL over xGMI; gloo for dry runs
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from viprs_amd import _lib
     from viprs_amd.plan import DeviceState, LDPlan
@@ -143,8 +147,8 @@ def main():
     ss = syn.make_sumstats(ld, seed=seed)
     inp = syn.make_inputs(ss)
 
-    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, ld.low_memory, device=local_rank,
-                  math_mode=args.math)
+    device = local_rank % _lib.device_count()
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, ld.low_memory, device=device, math_mode=args.math)
     state = DeviceState(plan, "float32", "spike_slab")
     for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
         state.upload(name, getattr(inp, name))
@@ -156,8 +160,9 @@ def main():
     def barrier():
         state.synchronize()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -171,11 +176,13 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(ld.m)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(ld.m)], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_snps = float(tot.item())
     else:

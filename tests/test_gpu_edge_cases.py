@@ -1,0 +1,130 @@
+"""GPU: edge cases of the drop-in boundary and full-size properties (BASELINE.json sizes)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+from viprs_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_chromosome(gpu):
+    from viprs_amd.vi import e_step_hip as S
+    z = lambda: np.zeros(0, np.float32)
+    S.cpp_e_step(np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, np.float32), z(), z(), z(), z(), z(), z(),
+                 z(), z(), z(), 1.0, 1, False)
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_singleton_blocks_and_int32_indptr(gpu, low_memory):
+    ld, ss, inp = syn.make_problem(sizes=[1] * 70 + [3, 1, 2], low_memory=low_memory, seed=5, indptr_dtype=np.int32)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=2)
+    got = H.run_hip(ld, inp, st0, sweeps=2)
+    H.assert_state_close(got, ref)
+
+
+@pytest.mark.parametrize("ld_dtype", [np.float32, np.int8])
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_team_blocks_bit_exact(gpu, ld_dtype, low_memory):
+    """Blocks large enough for the multi-CU team kernels (>= 1280 and >= 2304 SNPs)."""
+    ld, ss, inp = syn.make_problem(sizes=[2500, 1300, 1290, 4100], low_memory=low_memory, ld_dtype=ld_dtype, seed=9)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=2)
+    got = H.run_hip(ld, inp, st0, sweeps=2)
+    H.assert_state_close(got, ref)
+    if not low_memory:
+        H.assert_state_equal(got, ref)
+
+
+def test_fast_math_mode_within_tolerance(gpu):
+    from viprs_amd.vi import e_step_hip as S
+    ld, ss, inp = syn.make_problem(sizes=[700, 300], low_memory=False, seed=12)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=1)
+    S.set_default_math_mode("fast")
+    try:
+        got = H.run_hip(ld, inp, st0, sweeps=1)
+    finally:
+        S.set_default_math_mode("exact")
+    # the hardware-transcendental sigmoid may flip the skip branch for SNPs whose |eta_diff| sits within
+    # rounding of the threshold; everything else stays inside the 1e-5 relative tolerance
+    H.assert_state_close(got, ref, rtol=1e-5, max_flips=3)
+
+
+def test_float64_state_and_exotic_ld_dtypes(gpu):
+    for ld_dtype, T in ((np.float32, np.float64), (np.float64, np.float64), (np.int32, np.float32), (np.int64, np.float32)):
+        ld, ss, inp = syn.make_problem(sizes=[90, 140], low_memory=False, ld_dtype=ld_dtype, seed=3, float_precision=T)
+        st0 = inp.state_copy()
+        ref = H.run_oracle(ld, inp, st0, sweeps=2)
+        got = H.run_hip(ld, inp, st0, sweeps=2)
+        H.assert_state_close(got, ref, rtol=1e-5 if T == np.float32 else 1e-11)
+
+
+def test_low_memory_mismatch_and_threads_are_handled(gpu):
+    from viprs_amd.plan import LDPlan
+    ld, ss, inp = syn.make_problem(sizes=[64], low_memory=False, seed=2)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+    st = inp.state_copy()
+    with pytest.raises(ValueError, match="low_memory"):
+        plan.e_step(inp.std_beta, st["var_gamma"], st["var_mu"], st["eta"], st["q"], st["eta_diff"], inp.u_logs,
+                    inp.sqrt_half_var_tau, inp.mu_mult, 1.0, threads=1, low_memory=True)
+    a, b = inp.state_copy(), inp.state_copy()
+    for st, thr in ((a, 1), (b, 8)):     # `threads` is accepted and ignored: always the serial semantics
+        plan.e_step(inp.std_beta, st["var_gamma"], st["var_mu"], st["eta"], st["q"], st["eta_diff"], inp.u_logs,
+                    inp.sqrt_half_var_tau, inp.mu_mult, 1.0, threads=thr)
+    H.assert_state_equal(a, b)
+    plan.close()
+
+
+def test_cfg2_full_size_against_oracle(gpu):
+    """BASELINE configs[1]: chr22-like, ~19k SNPs / 40 LD blocks, symmetric and upper forms."""
+    for low_memory in (False, True):
+        ld, ss, inp = syn.make_problem("cfg2", low_memory=low_memory)
+        st0 = inp.state_copy()
+        ref = H.run_oracle(ld, inp, st0, sweeps=3)
+        got = H.run_hip(ld, inp, st0, sweeps=3)
+        H.assert_state_close(got, ref)
+        if not low_memory:
+            H.assert_state_equal(got, ref)
+
+
+def test_cfg3_full_size_properties(gpu):
+    """BASELINE configs[2] (1.1 M SNPs, 1 700 blocks): size-independent properties of one sweep from
+    q = eta = 0 -- q == (R - I) eta per block (closed form), run-to-run bit reproducibility, and the
+    oracle on a sample of blocks (largest, smallest, a few in between)."""
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=False)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+    state = DeviceState(plan)
+    for n in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+        state.upload(n, getattr(inp, n))
+    outs = []
+    for _ in range(2):
+        state.reset(inp.pi)
+        state.e_step(ld.dq_scale)
+        outs.append({k: state.download(k) for k in H.STATE})
+    H.assert_state_equal(outs[0], outs[1])                       # race-free by construction
+    got = outs[0]
+    assert plan.last_skipped() == int((got["eta_diff"] == 0).sum())
+    sizes = np.diff(ld.block_start)
+    order = np.argsort(sizes)
+    sample = list(order[:3]) + list(order[-3:]) + list(order[len(order) // 2 - 2: len(order) // 2 + 2])
+    for bi in sample:
+        s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+        b = e - s
+        off = int(ld.ld_indptr[s])
+        R = ld.ld_data[off:off + b * b].reshape(b, b).astype(np.float64)
+        q = (R - np.eye(b)) @ got["eta"][s:e].astype(np.float64)
+        np.testing.assert_allclose(got["q"][s:e], q, rtol=5e-4, atol=5e-6)
+        # the same block alone through the oracle: bit-identical
+        sub = syn.SyntheticLD(np.zeros(b, np.int32), np.arange(0, b * b + 1, b, dtype=np.int64),
+                              ld.ld_data[off:off + b * b], np.array([0, b]), ld.rho[bi:bi + 1], False, 1.0)
+        st = {k: v[s:e].copy() for k, v in inp.state_copy().items()}
+        O.cpp_e_step(sub.ld_left_bound, sub.ld_indptr, sub.ld_data, inp.std_beta[s:e].copy(), st["var_gamma"],
+                     st["var_mu"], st["eta"], st["q"], st["eta_diff"], inp.u_logs[s:e].copy(),
+                     inp.sqrt_half_var_tau[s:e].copy(), inp.mu_mult[s:e].copy(), 1.0, 1, False)
+        for k in H.STATE:
+            assert np.array_equal(got[k][s:e], st[k]), (k, int(bi), b)
+    plan.close()
