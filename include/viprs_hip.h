@@ -163,6 +163,29 @@ int viprs_state_e_step(viprs_state* state, double dq_scale, const int32_t* activ
                        int n_active, int sync);
 int viprs_state_synchronize(viprs_state* state);
 
+/* ---- device-resident EM iteration (spike-and-slab): host prep, zeta and the M-step / ELBO sums ---
+ * Replaces the O(m) NumPy passes of VIPRS.e_step / compute_zeta / m_step / elbo
+ * (VIPRS.py:400-418, :888-897, :426-471, :497-581) so that fit() moves only scalars per iteration. */
+/* n_per_snp (float64, (m,)), uploaded once.                                                      */
+int viprs_state_set_n_per_snp(viprs_state* state, const double* n_per_snp);
+/* On-device VIPRS.py:400-418 in float64, rounded to the state precision at the end:
+ *   var_tau = n one_plus_lambda / sigma_epsilon + tau_beta
+ *   mu_mult = n / (var_tau sigma_epsilon);  sqrt_half_var_tau = sqrt(var_tau / 2)
+ *   u_logs  = logit_pi + 0.5 (log_tau_beta - log var_tau)
+ * (the scalars logit_pi = log(pi) - log(1 - pi), log_tau_beta and one_plus_lambda = 1 + lambda_min
+ * are evaluated by the caller so that the reference's scalar dtype promotion -- float32 scalars in
+ * VIPRS.py:400-406 -- can be reproduced exactly).                                                 */
+int viprs_state_prep(viprs_state* state, double logit_pi, double log_tau_beta, double sigma_epsilon,
+                     double tau_beta, double one_plus_lambda);
+/* Deterministic (fixed-order) float64 reductions over the plan's SNPs with the hyper-parameters of
+ * the last viprs_state_prep; `out` receives VIPRS_N_SUMS doubles on the HOST:
+ *   [0] sum gamma  [1] sum zeta  [2] sum(one_plus_lambda zeta + q eta)  [3] sum std_beta eta  [4] sum eta^2
+ *   [5] sum g log g  [6] sum (1-g) log(1-g)  [7] sum g  [8] sum (1-g)   (g clipped to [1e-15, 1-1e-15])
+ *   [9] sum g log var_tau  [10] max |eta_diff|
+ * zeta = gamma (mu^2 + 1/var_tau) in float64 (VIPRS.py:896).  Synchronises the plan's stream.      */
+#define VIPRS_N_SUMS 11
+int viprs_state_sums(viprs_state* state, double one_plus_lambda, double* out);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last viprs_state_e_step / viprs_e_step* call on
  * this plan, measured on the stream they were launched on.  `which`: 0 = all kernels of the

@@ -128,3 +128,53 @@ def test_cfg3_full_size_properties(gpu):
         for k in H.STATE:
             assert np.array_equal(got[k][s:e], st[k]), (k, int(bi), b)
     plan.close()
+
+
+def test_device_prep_and_sums_match_host_formulas(gpu):
+    """viprs_state_prep / viprs_state_sums (device-resident EM iteration) against the NumPy statements
+    of VIPRS.py:400-418, :896, :426-471, :497-581 used by the host path."""
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld, ss, inp = syn.make_problem(sizes=[300, 1400, 77], low_memory=False, seed=4)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+    st = DeviceState(plan)
+    st.upload("std_beta", inp.std_beta)
+    st.set_n_per_snp(ss.n_per_snp)
+    pi, sig, tau, lam = np.float32(0.013), np.float32(0.77), 123.4, np.float32(0.01)
+    logit = float(np.log(pi) - np.log(1.0 - pi))
+    st.reset(float(pi))
+    st.prep(logit, float(np.log(tau)), sig, tau, 1.0 + lam)
+    var_tau = ss.n_per_snp * (1.0 + lam) / sig + tau
+    np.testing.assert_array_equal(st.download("mu_mult"), (ss.n_per_snp / (var_tau * sig)).astype(np.float32))
+    np.testing.assert_allclose(st.download("u_logs"),
+                               (np.log(pi) - np.log(1.0 - pi) + 0.5 * (np.log(tau) - np.log(var_tau))).astype(np.float32),
+                               rtol=1.2e-7)
+    np.testing.assert_array_equal(st.download("sqrt_half_var_tau"), np.sqrt(0.5 * var_tau).astype(np.float32))
+    st.e_step(ld.dq_scale)
+    v = st.sums(1.0 + lam)
+    g, mu, eta, q, ed = (st.download(k).astype(np.float64) for k in ("var_gamma", "var_mu", "eta", "q", "eta_diff"))
+    zeta = g * (mu ** 2 + 1.0 / var_tau)
+    gc, ng = np.clip(g, 1e-15, 1 - 1e-15), np.clip(1 - g, 1e-15, 1 - 1e-15)
+    want = [g.sum(), zeta.sum(), ((1.0 + lam) * zeta + (q.astype(np.float32) * eta.astype(np.float32))).sum(),
+            (inp.std_beta.astype(np.float64) * eta).sum(), (eta ** 2).sum(), (gc * np.log(gc)).sum(),
+            (ng * np.log(ng)).sum(), gc.sum(), ng.sum(), (gc * np.log(var_tau)).sum(), np.abs(ed).max()]
+    np.testing.assert_allclose(v, want, rtol=1e-12, atol=1e-300)
+    v2 = st.sums(1.0 + lam)
+    assert np.array_equal(v, v2)                                  # fixed-order reduction: reproducible
+    plan.close()
+
+
+def test_device_resident_fit_equals_host_mirrored_fit(gpu):
+    from viprs_amd.data import ArrayDataLoader
+    from viprs_amd.model import VIPRS
+    gdl = ArrayDataLoader.synthetic({21: [210, 330], 22: [1300, 64]}, seed=77)
+    runs = []
+    for resident in (True, False):
+        m = VIPRS(gdl, low_memory=True, device_resident=resident)
+        m.fit(max_iter=40, theta_0={"pi": 0.01, "sigma_epsilon": 0.8})
+        runs.append(m)
+    a, b = runs
+    assert a.optim_result.nit == b.optim_result.nit and a.optim_result.message == b.optim_result.message
+    np.testing.assert_allclose(a.history["ELBO"], b.history["ELBO"], rtol=1e-7, atol=0.02)
+    for c in a.chromosomes:
+        np.testing.assert_allclose(a.pip[c], b.pip[c], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(a.post_mean_beta[c], b.post_mean_beta[c], rtol=1e-3, atol=1e-7)

@@ -23,6 +23,7 @@ MODEL_SPIKE_SLAB, MODEL_MIXTURE, MODEL_GRID = 0, 1, 2
  INFO_LD_ELEM_SIZE, INFO_DEVICE, INFO_LOW_MEMORY, INFO_N_CU) = range(11)
 
 OK, EINVAL, ELAYOUT, EDEVICE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+N_SUMS = 11
 
 
 class ViprsHipError(RuntimeError):
@@ -69,6 +70,9 @@ _PROTOS = {
     "viprs_state_reset": (_i, [_vp, _d]),
     "viprs_state_e_step": (_i, [_vp, _d, _vp, _i, _i]),
     "viprs_state_synchronize": (_i, [_vp]),
+    "viprs_state_set_n_per_snp": (_i, [_vp, _vp]),
+    "viprs_state_prep": (_i, [_vp, _d, _d, _d, _d, _d]),
+    "viprs_state_sums": (_i, [_vp, _d, ctypes.POINTER(_d)]),
     "viprs_plan_last_kernel_ms": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "viprs_plan_last_skipped": (_i, [_vp, _pi64]),
     "viprs_plan_timing_reset": (_i, [_vp]),

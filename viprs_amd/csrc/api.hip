@@ -94,6 +94,77 @@ __global__ void reset_state_kernel(T* var_gamma, T* var_mu, int64_t n_wide, T* e
     if (i < n_vec) { eta[i] = (T)0; q[i] = (T)0; eta_diff[i] = (T)0; }
 }
 
+// VIPRS.py:400-418 on the device (float64, cast to T at the end)
+template <typename T>
+__global__ void prep_kernel(const double* __restrict__ n, int64_t m, double logit_pi, double log_tau_beta,
+                            double sigma_eps, double tau_beta, double one_plus_lambda, T* __restrict__ mu_mult,
+                            T* __restrict__ u_logs, T* __restrict__ shvt, double* __restrict__ var_tau_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double vt = n[i] * one_plus_lambda / sigma_eps + tau_beta;
+    var_tau_out[i] = vt;
+    mu_mult[i] = (T)(n[i] / (vt * sigma_eps));
+    u_logs[i] = (T)(logit_pi + 0.5 * (log_tau_beta - log(vt)));
+    shvt[i] = (T)sqrt(0.5 * vt);
+}
+
+constexpr int kSumsBlock = 256;
+constexpr int kNSums = VIPRS_N_SUMS;
+
+// stage 1: per-workgroup partial sums (fixed assignment of elements to threads, tree reduction in
+// LDS: deterministic); stage 2 adds the partials in index order
+template <typename T>
+__global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __restrict__ gam, const T* __restrict__ mu,
+                                                          const T* __restrict__ eta, const T* __restrict__ q,
+                                                          const T* __restrict__ ed, const T* __restrict__ beta,
+                                                          const double* __restrict__ var_tau, double one_plus_lambda,
+                                                          double* __restrict__ partials) {
+    __shared__ double red[kNSums][kSumsBlock];
+    double acc[kNSums];
+#pragma unroll
+    for (int k = 0; k < kNSums; ++k) acc[k] = 0.0;
+    const double lo = 1e-15, hi = 1.0 - 1e-15;       // np.finfo(float64).resolution (VIPRS.py:509)
+    for (int64_t i = (int64_t)blockIdx.x * kSumsBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kSumsBlock) {
+        const double g = (double)gam[i], mud = (double)mu[i], vt = var_tau[i];
+        const double zeta = g * (mud * mud + 1.0 / vt);                       // VIPRS.py:896
+        acc[0] += g;
+        acc[1] += zeta;
+        acc[2] += one_plus_lambda * zeta + (double)(q[i] * eta[i]);        // :455 (q*eta in T, as np.multiply)
+        acc[3] += (double)beta[i] * (double)eta[i];
+        acc[4] += (double)eta[i] * (double)eta[i];
+        const double gc = fmin(fmax(g, lo), hi), ng = fmin(fmax(1.0 - g, lo), hi);
+        acc[5] += gc * log(gc);
+        acc[6] += ng * log(ng);
+        acc[7] += gc;
+        acc[8] += ng;
+        acc[9] += gc * log(vt);
+        acc[10] = fmax(acc[10], fabs((double)ed[i]));
+    }
+#pragma unroll
+    for (int k = 0; k < kNSums; ++k) red[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = kSumsBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < kNSums - 1; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+            red[kNSums - 1][threadIdx.x] = fmax(red[kNSums - 1][threadIdx.x], red[kNSums - 1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kNSums) partials[(int64_t)blockIdx.x * kNSums + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void sums_final_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= kNSums) return;
+    double a = 0.0;
+    for (int b = 0; b < n_blocks; ++b) {
+        const double v = partials[(int64_t)b * kNSums + k];
+        a = (k == kNSums - 1) ? fmax(a, v) : a + v;
+    }
+    out[k] = a;
+}
+
 // zeroes the work-queue heads, the skip counter and the team hand-off granules in ONE launch
 __global__ void sweep_prologue_kernel(int32_t* counters, int n_counters, unsigned long long* skipped,
                                       unsigned long long* granules, int64_t n_granules) {
@@ -160,6 +231,7 @@ struct viprs_state {
     DevBuf<char> f[VIPRS_FIELD_COUNT];
     DevBuf<int32_t> d_active;               // grid: active model indices of the current call
     DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
+    DevBuf<double> d_n, d_var_tau, d_partials, d_sums;   // device-resident EM iteration
     size_t field_elems(int field) const {
         const size_t m = (size_t)plan->m;
         switch (field) {
@@ -962,6 +1034,73 @@ int viprs_e_step_grid(viprs_plan* P, int float_dtype, int G, const void* std_bet
     void* outs[] = {var_gamma, var_mu, eta, q, eta_diff};
     const int out_fields[] = {VIPRS_FIELD_VAR_GAMMA, VIPRS_FIELD_VAR_MU, VIPRS_FIELD_ETA, VIPRS_FIELD_Q, VIPRS_FIELD_ETA_DIFF};
     return one_shot(S, ins, in_fields, 9, outs, out_fields, 5, dq_scale, active_model_idx, n_active);
+}
+
+int viprs_state_set_n_per_snp(viprs_state* S, const double* n) {
+    if (!S || !n) return fail(VIPRS_EINVAL, "null argument");
+    viprs_plan* P = S->plan;
+    HIP_TRY(hipSetDevice(P->device));
+    const size_t m = (size_t)P->m;
+    if (m == 0) return VIPRS_OK;
+    HIP_TRY(S->d_n.alloc(m));
+    HIP_TRY(S->d_var_tau.alloc(m));
+    HIP_TRY(hipMemcpy(S->d_n.p, n, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(S->d_var_tau.p, 0, m * sizeof(double)));
+    return VIPRS_OK;
+}
+
+int viprs_state_prep(viprs_state* S, double logit_pi, double log_tau_beta, double sigma_epsilon, double tau_beta,
+                     double one_plus_lambda) {
+    if (!S) return fail(VIPRS_EINVAL, "null state");
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EUNSUPPORTED, "device prep: spike-and-slab only");
+    viprs_plan* P = S->plan;
+    if (P->m == 0) return VIPRS_OK;
+    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    const unsigned grid = (unsigned)((P->m + 255) / 256);
+    if (S->float_dtype == VIPRS_F32)
+        prep_kernel<float><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
+                                                        one_plus_lambda, (float*)S->f[VIPRS_FIELD_MU_MULT].p,
+                                                        (float*)S->f[VIPRS_FIELD_U_LOGS].p,
+                                                        (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+    else
+        prep_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
+                                                         one_plus_lambda, (double*)S->f[VIPRS_FIELD_MU_MULT].p,
+                                                         (double*)S->f[VIPRS_FIELD_U_LOGS].p,
+                                                         (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+    HIP_TRY(hipGetLastError());
+    return VIPRS_OK;
+}
+
+int viprs_state_sums(viprs_state* S, double one_plus_lambda, double* out) {
+    if (!S || !out) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EUNSUPPORTED, "device sums: spike-and-slab only");
+    viprs_plan* P = S->plan;
+    for (int k = 0; k < kNSums; ++k) out[k] = 0.0;
+    if (P->m == 0) return VIPRS_OK;
+    if (!S->d_var_tau.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp / viprs_state_prep have not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
+    if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
+    if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
+    if (S->float_dtype == VIPRS_F32)
+        sums_kernel<float><<<nb, kSumsBlock, 0, P->stream>>>(
+            P->m, (const float*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const float*)S->f[VIPRS_FIELD_VAR_MU].p,
+            (const float*)S->f[VIPRS_FIELD_ETA].p, (const float*)S->f[VIPRS_FIELD_Q].p,
+            (const float*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const float*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p,
+            one_plus_lambda, S->d_partials.p);
+    else
+        sums_kernel<double><<<nb, kSumsBlock, 0, P->stream>>>(
+            P->m, (const double*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const double*)S->f[VIPRS_FIELD_VAR_MU].p,
+            (const double*)S->f[VIPRS_FIELD_ETA].p, (const double*)S->f[VIPRS_FIELD_Q].p,
+            (const double*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const double*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p,
+            one_plus_lambda, S->d_partials.p);
+    HIP_TRY(hipGetLastError());
+    sums_final_kernel<<<1, 64, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, S->d_sums.p, kNSums * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return check_device_error(P);
 }
 
 static int sweep_ms(viprs_plan* P, int64_t sweep, int which, double* ms) {

@@ -36,7 +36,7 @@ class VIPRS:
 
     def __init__(self, gdl, fix_params=None, tracked_params=None, lambda_min=None, float_precision="float32",
                  order="F", low_memory=True, dequantize_on_the_fly=False, threads=1,
-                 device=None, comm=None, math_mode="exact", e_step_fn=None):
+                 device=None, comm=None, math_mode="exact", e_step_fn=None, device_resident=True):
         """Same arguments as the reference (VIPRS.py:68-77) plus:
 
         :param device: HIP device index (default: ``comm.rank`` modulo the visible devices).
@@ -44,6 +44,9 @@ class VIPRS:
         :param math_mode: 'exact' (bit-for-bit the reference's arithmetic) or 'fast'.
         :param e_step_fn: test hook -- a callable with ``cpp_e_step``'s positional signature that
             replaces the HIP kernels (used by the CPU tests with the oracle).
+        :param device_resident: keep the whole EM iteration on the GPU (host prep, zeta, M-step / ELBO
+            sums as device kernels; only ~11 scalars per chromosome cross PCIe per iteration).  The
+            NumPy state attributes are refreshed when ``fit()`` returns or on ``sync_host()``.
         """
         if gdl.genotype is None and (gdl.ld is None or gdl.sumstats_table is None):
             raise AssertionError("The data loader must contain summary statistics and LD matrices.")
@@ -110,6 +113,12 @@ class VIPRS:
                                         device=self.device, math_mode=math_mode)
                 self._dstate[c] = self._make_device_state(self._plans[c])
                 self._dstate[c].upload("std_beta", self.std_beta[c])
+        self._resident = bool(device_resident) and e_step_fn is None and self._supports_resident()
+        if self._resident:
+            for c in self.chromosomes:
+                self._dstate[c].set_n_per_snp(self.n_per_snp[c])
+        self._host_stale = False
+        self._last_prep = None
 
         # ---- model state -------------------------------------------------------------------------
         self.var_gamma, self.var_mu, self.var_tau, self._log_var_tau = {}, {}, {}, {}
@@ -143,6 +152,9 @@ class VIPRS:
     def _make_device_state(self, plan):
         from ..plan import DeviceState
         return DeviceState(plan, self.float_precision, "spike_slab")
+
+    def _supports_resident(self):
+        return True
 
     # ---- initialisation (VIPRS.py:213-359) -------------------------------------------------------
     def initialize(self, theta_0=None, param_0=None):
@@ -219,6 +231,7 @@ class VIPRS:
         self.q = {c: np.zeros_like(e, dtype=T) for c, e in self.eta.items()}
         self._log_var_tau = {c: np.log(self.var_tau[c]) for c in self.var_tau}
         self._sums_valid = False
+        self._host_stale = False
         self._push_state()
 
     def set_fixed_params(self, fix_params):
@@ -242,6 +255,18 @@ class VIPRS:
             for name in self._STATE:
                 ds.download(name, out=getattr(self, name)[c])
 
+    def sync_host(self):
+        """Refresh the NumPy state attributes from the GPU (device-resident mode)."""
+        if self._resident and self._host_stale:
+            self._pull_state()
+            if self._last_prep is not None:
+                sigma_epsilon, tau_beta, lam = self._last_prep
+                for c in self.chromosomes:
+                    self.var_tau[c] = (self.n_per_snp[c] * (1.0 + lam) / sigma_epsilon) + tau_beta
+                    np.log(self.var_tau[c], out=self._log_var_tau[c])
+            self.zeta = self.compute_zeta()
+            self._host_stale = False
+
     # ---- E-step -------------------------------------------------------------------------------------
     def _prep(self, c):
         """Host prep of VIPRS.py:396-418 (float64, cast to the state precision at the end)."""
@@ -262,6 +287,18 @@ class VIPRS:
                 self._e_step_fn(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], self.std_beta[c],
                                 self.var_gamma[c], self.var_mu[c], self.eta[c], self.q[c], self.eta_diff[c],
                                 u_logs, shvt, mu_mult, self.dequantize_scale, self.threads, self.low_memory)
+        elif self._resident:
+            # whole iteration on the device: prep kernel + sweep per chromosome, nothing crosses PCIe
+            pi, tau_beta = self.pi, self.tau_beta
+            logit_pi = float(np.log(pi) - np.log(1.0 - pi))          # scalar dtype semantics of VIPRS.py:405
+            for c in self.chromosomes:
+                ds = self._dstate[c]
+                ds.prep(logit_pi, float(np.log(tau_beta)), self.sigma_epsilon, tau_beta, 1.0 + self.lambda_min)
+                ds.e_step(self.dequantize_scale, sync=False)
+            self._last_prep = (self.sigma_epsilon, tau_beta, self.lambda_min)
+            self._host_stale = True
+            self._sums_valid = False
+            return
         else:
             for c in self.chromosomes:               # launch everything (one stream per chromosome) ...
                 u_logs, shvt, mu_mult = self._prep(c)
@@ -298,6 +335,17 @@ class VIPRS:
                 [3] sum_c std_beta_c.eta_c [4] sum eta^2           [5..8] ELBO sums
                 (max|eta_diff| travels in a separate max-reduction)"""
         lam = self.lambda_min
+        if self._resident and self._host_stale:
+            s = np.zeros(10, dtype=np.float64)
+            self._dev_max_eta_diff = 0.0
+            for c in self.chromosomes:
+                v = self._dstate[c].sums(1.0 + lam)
+                s[0] += v[0] / self.shapes[c]
+                s[1:5] += v[1:5]
+                s[5:9] += v[5:9]
+                s[9] += v[9]
+                self._dev_max_eta_diff = max(self._dev_max_eta_diff, float(v[10]))
+            return s
         s = np.zeros(9, dtype=np.float64)
         for c in self.chromosomes:
             g, z = self.var_gamma[c], self.zeta[c]
@@ -323,7 +371,10 @@ class VIPRS:
             return self._sums
         self._sums_valid = True
         self._sums = self.comm.allreduce_sum(self._partial_sums())
-        local_max = max([float(np.max(np.abs(d))) for d in self.eta_diff.values()] or [0.0])
+        if self._resident and self._host_stale:
+            local_max = self._dev_max_eta_diff
+        else:
+            local_max = max([float(np.max(np.abs(d))) for d in self.eta_diff.values()] or [0.0])
         self._max_eta_diff = float(self.comm.allreduce_max(np.array([local_max]))[0])
         return self._sums
 
@@ -389,6 +440,7 @@ class VIPRS:
             elif t == "max_eta_diff":
                 self.history["max_eta_diff"].append(self._max_eta_diff)
             elif callable(t):
+                self.sync_host()
                 self.history[t.__name__].append(t(self))
 
     # ---- EM loop (VIPRS.py:909-1124): same stopping rules, evaluated on the reduced sums ------------
@@ -450,6 +502,7 @@ class VIPRS:
                 res.update(elbo, stop_iteration=True, success=stop[0], message=stop[1])
             prev_elbo, prev_sigma_g = elbo, self._sigma_g
 
+        self.sync_host()
         self.update_posterior_moments()
         if not res.stop_iteration:
             res.update(self.elbo(), stop_iteration=True, success=False, increment=False,

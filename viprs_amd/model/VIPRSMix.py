@@ -30,6 +30,9 @@ class VIPRSMix(VIPRS):
         from ..plan import DeviceState
         return DeviceState(plan, self.float_precision, "mixture", self.K)
 
+    def _supports_resident(self):
+        return False          # mixture M-step sums still run on the host
+
     # ---- hyper-parameter initialisation (VIPRSMix.py:60-167) --------------------------------------
     def initialize_theta(self, theta_0=None):
         th = self._merge_theta(theta_0)

@@ -232,6 +232,25 @@ class DeviceState:
     def reset(self, pi):
         L.check(L.lib.viprs_state_reset(self._h, float(pi)))
 
+    # -- device-resident EM iteration (spike-and-slab) ------------------------------------------
+    def set_n_per_snp(self, n_per_snp):
+        n = np.ascontiguousarray(n_per_snp, dtype=np.float64)
+        if n.shape != (self.plan.m,):
+            raise ValueError(f"n_per_snp: expected shape ({self.plan.m},), got {n.shape}")
+        L.check(L.lib.viprs_state_set_n_per_snp(self._h, _ptr(n)))
+
+    def prep(self, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda):
+        """VIPRS.py:400-418 on the device (asynchronous on the plan's stream).  The scalars are
+        evaluated by the caller (reference dtype semantics)."""
+        L.check(L.lib.viprs_state_prep(self._h, float(logit_pi), float(log_tau_beta), float(sigma_epsilon),
+                                       float(tau_beta), float(one_plus_lambda)))
+
+    def sums(self, one_plus_lambda):
+        """The M-step / ELBO partial sums of this plan's SNPs (float64, deterministic order)."""
+        out = (ctypes.c_double * L.N_SUMS)()
+        L.check(L.lib.viprs_state_sums(self._h, float(one_plus_lambda), out))
+        return np.array(out[:], dtype=np.float64)
+
     def e_step(self, dq_scale=1.0, active_model_idx=None, sync=True):
         if active_model_idx is not None:
             active = np.ascontiguousarray(active_model_idx, dtype=np.int32)
