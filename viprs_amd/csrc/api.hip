@@ -536,7 +536,7 @@ int viprs_state_create(viprs_state** out, viprs_plan* plan, int float_dtype, int
     S->float_dtype = float_dtype;
     S->model_kind = model_kind;
     S->width = width;
-    if (plan->n_granule_rows > 0 && model_kind == VIPRS_MODEL_SPIKE_SLAB) {
+    if (plan->n_granule_rows > 0) {
         HIP_TRY(S->eta_out.alloc((size_t)plan->m * float_size(float_dtype)));
         HIP_TRY(S->q_out.alloc((size_t)plan->m * float_size(float_dtype)));
     }
@@ -718,8 +718,10 @@ int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A, int model, bool dense
     }
 }
 
+enum { kPanelSpikeSlab = 0, kPanelGridColumn = 1, kPanelMixture = 2 };
+
 template <typename U, int NW, bool TEAM, int CPL>
-int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t stream) {
+int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t stream, int model) {
     const int begin = P->class_begin[cls], end = P->class_begin[cls + 1];
     if (end <= begin) return VIPRS_OK;
     A.blocks = P->d_dense.p + begin;
@@ -731,9 +733,11 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     const bool exact = P->math_mode == VIPRS_MATH_EXACT;
     const bool upper = P->low_memory != 0;
     const void* kfn = nullptr;
-#define PK(SY, EX) (const void*)estep_panel_kernel<U, SY, EX, NW, TEAM, CPL>
-    if (upper) kfn = exact ? PK(false, true) : PK(false, false);
-    else kfn = exact ? PK(true, true) : PK(true, false);
+#define PK(MODEL) (upper ? (const void*)estep_panel_kernel<U, MODEL, false, NW, TEAM, CPL> \
+                          : (const void*)estep_panel_kernel<U, MODEL, true, NW, TEAM, CPL>)
+    if (model == kPanelGridColumn) kfn = PK(GridColumnModel);
+    else if (model == kPanelMixture) kfn = PK(MixtureModel);
+    else kfn = exact ? PK(SpikeSlabModel<true>) : PK(SpikeSlabModel<false>);
 #undef PK
     if (shmem > 160 * 1024) return fail(VIPRS_EUNSUPPORTED, "LD block too large for the LDS-resident panel kernel");
     if (shmem > 48 * 1024)
@@ -800,13 +804,13 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
 // Panel kernels of the three size classes run concurrently on their own streams (forked from /
 // joined back into the plan's stream with events); the upper-triangular second pass follows.
 template <typename U>
-int launch_panel(viprs_plan* P, EStepArgs<float> A) {
+int launch_panel(viprs_plan* P, EStepArgs<float> A, int model = kPanelSpikeSlab) {
     HIP_TRY(hipEventRecord(P->ev_fork, P->stream));
     int rc;
     for (int c = 0; c < 3; ++c) HIP_TRY(hipStreamWaitEvent(P->class_stream[c], P->ev_fork, 0));
-    if ((rc = launch_panel_class<U, kClassWaves[0], true, kClassCols[0]>(P, A, 0, P->class_stream[0])) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[1], true, kClassCols[1]>(P, A, 1, P->class_stream[1])) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[2], false, kClassCols[2]>(P, A, 2, P->class_stream[2])) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[0], true, kClassCols[0]>(P, A, 0, P->class_stream[0], model)) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[1], true, kClassCols[1]>(P, A, 1, P->class_stream[1], model)) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[2], false, kClassCols[2]>(P, A, 2, P->class_stream[2], model)) != VIPRS_OK) return rc;
     for (int c = 0; c < 3; ++c) {
         HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
         HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join[c], 0));
@@ -860,21 +864,59 @@ int run_spike_slab(viprs_state* S, double dq) {
     return VIPRS_OK;
 }
 
-// mixture / grid: generic kernels over every block (dense blocks through the repacked layout)
-int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_active, int n_active) {
+static int sweep_prologue(viprs_plan* P) {
+    const int64_t ng = P->n_granule_rows * kPanel;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
+    sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, ng);
+    HIP_TRY(hipGetLastError());
+    return VIPRS_OK;
+}
+
+template <typename T>
+static void offset_column(EStepArgs<T>& A, const EStepArgs<T>& base, int64_t off) {
+    A = base;
+    A.var_gamma += off; A.var_mu += off; A.eta += off; A.q += off; A.eta_diff += off;
+    A.u_logs += off; A.shvt += off; A.mu_mult += off;
+}
+
+static int launch_panel_u(viprs_plan* P, const EStepArgs<float>& A, int model) {
+    switch (P->ld_dtype) {
+        case VIPRS_LD_F32: return launch_panel<float>(P, A, model);
+        case VIPRS_LD_I8: return launch_panel<int8_t>(P, A, model);
+        case VIPRS_LD_I16: return launch_panel<int16_t>(P, A, model);
+        default: return fail(VIPRS_EINVAL, "dense schedule with unsupported LD dtype");
+    }
+}
+
+// mixture / grid.  fp32 state on dense blocks: the panel kernels with the model's policy (the grid
+// runs its independent models one after the other, each on its own column of the (m, G) arrays);
+// everything else (ragged blocks, fp64 state, K > kPanelMaxK): the generic kernels.
+int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_active, int n_active,
+                      const int32_t* h_active) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    sweep_prologue_kernel<<<1, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, 0);
-    HIP_TRY(hipGetLastError());
+    int rc = sweep_prologue(P);
+    if (rc != VIPRS_OK) return rc;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     HIP_TRY(hipEventRecord(ev[0], P->stream));
     HIP_TRY(hipEventRecord(ev[2], P->stream));
-    int rc;
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
         A.active = d_active;
         A.n_active = n_active;
-        rc = launch_generic_u<float>(P, A, model, true);
+        const bool panel_ok = !P->dense_h.empty() && (model == kGenGrid || S->width <= kPanelMaxK);
+        if (panel_ok && model == kGenMixture) {
+            rc = launch_panel_u(P, A, kPanelMixture);
+        } else if (panel_ok && model == kGenGrid) {
+            for (int i = 0; i < n_active && rc == VIPRS_OK; ++i) {
+                EStepArgs<float> Ag;
+                offset_column(Ag, A, (int64_t)h_active[i] * P->m);
+                if (i > 0) rc = sweep_prologue(P);          // fresh queue heads / granules per model
+                if (rc == VIPRS_OK) rc = launch_panel_u(P, Ag, kPanelGridColumn);
+            }
+        } else {
+            rc = launch_generic_u<float>(P, A, model, true);
+        }
         if (rc == VIPRS_OK) rc = launch_generic_u<float>(P, A, model, false);
     } else {
         EStepArgs<double> A = make_args<double>(S, dq);
@@ -899,7 +941,7 @@ int viprs_state_e_step(viprs_state* S, double dq_scale, const int32_t* active, i
     int rc;
     switch (S->model_kind) {
         case VIPRS_MODEL_SPIKE_SLAB: rc = run_spike_slab(S, dq_scale); break;
-        case VIPRS_MODEL_MIXTURE: rc = run_generic_model(S, dq_scale, kGenMixture, nullptr, 0); break;
+        case VIPRS_MODEL_MIXTURE: rc = run_generic_model(S, dq_scale, kGenMixture, nullptr, 0, nullptr); break;
         case VIPRS_MODEL_GRID: {
             std::vector<int32_t> all;
             if (!active) {                                    // default: every model is active
@@ -916,7 +958,7 @@ int viprs_state_e_step(viprs_state* S, double dq_scale, const int32_t* active, i
             HIP_TRY(hipMemcpyAsync(S->d_active.p, active, sizeof(int32_t) * (size_t)n_active, hipMemcpyHostToDevice,
                                    S->plan->stream));
             HIP_TRY(hipStreamSynchronize(S->plan->stream));   // `active` may be a temporary
-            rc = run_generic_model(S, dq_scale, kGenGrid, S->d_active.p, n_active);
+            rc = run_generic_model(S, dq_scale, kGenGrid, S->d_active.p, n_active, active);
             break;
         }
         default: return fail(VIPRS_EINVAL, "bad model kind");

@@ -130,7 +130,178 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
     for (int i = 0; i < CPL; ++i) lq_c[i] = qv[i];
 }
 
-template <typename U, bool SYM, bool EXACT, int NW, bool TEAM, int CPL>
+// ---------------------------------------------------------------------------------------------
+// Model policies: what one SNP update computes (the serial chain evaluates `update` with the
+// lane-select table lookup; after the 64 steps every lane replays its own SNP with the per-lane
+// lookup -- same operations, same inputs, same bits -- and `finish` stores the outputs).
+//   load    per-SNP inputs of SNP j (lane-resident for a whole panel)
+//   update  d = new eta - old eta from the current q[j];  returns false on the skip branch
+//   finish  replay + stores; returns the scaled eta_diff (0 for skipped SNPs)
+// ---------------------------------------------------------------------------------------------
+template <bool EXACT>
+struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
+    struct In { float mm, beta, sv, ulog, eta_old; };
+    static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
+        In in;
+        in.mm = live ? A.mu_mult[j] : 0.0f;
+        in.beta = live ? A.std_beta[j] : 0.0f;
+        in.sv = live ? A.shvt[j] : 0.0f;
+        in.ulog = live ? A.u_logs[j] : 0.0f;
+        in.eta_old = live ? A.eta[j] : 0.0f;
+        return in;
+    }
+    template <int LOOKUP>
+    static __device__ __forceinline__ bool update(const In& in, float q, const ExpTab& tab, float& d, int sel) {
+        float mu, gamma;
+        snp_update<EXACT, LOOKUP>(in.mm, in.beta, in.sv, in.ulog, in.eta_old, q, tab, mu, gamma, d, sel);
+        return !(fabsf(d) < Eps<float>::value);                       // :410
+    }
+    template <bool TEAM>
+    static __device__ __forceinline__ float finish(const EStepArgs<float>& A, int64_t j, const In& in, float q,
+                                                   const ExpTab& tab, bool live, bool writer, bool& skipped) {
+        float mu, gamma, d;
+        snp_update<EXACT, kLookupPerLane>(in.mm, in.beta, in.sv, in.ulog, in.eta_old, q, tab, mu, gamma, d);
+        const bool skip = fabsf(d) < Eps<float>::value;
+        if (live && writer) {
+            if (!skip) {
+                A.var_mu[j] = mu;                                         // :416-418
+                A.var_gamma[j] = gamma;
+                A.eta_diff[j] = d;
+                if (!TEAM) A.eta[j] = in.eta_old + d;                     // :431
+            } else {
+                A.eta_diff[j] = 0.0f;                                     // :412
+            }
+            if (TEAM) A.eta_out[j] = skip ? in.eta_old : in.eta_old + d;
+        }
+        skipped = live && skip;
+        return (live && !skip) ? A.dq * d : 0.0f;
+    }
+};
+
+// One column of e_step_grid (e_step.hpp:599-635): models of a grid are independent, so the host runs
+// this policy once per active model with the (m, G) column-major arrays offset to that column.
+// Different arithmetic from e_step: no fma in mu / the logit / d, half_var_tau instead of its
+// square root, no skip branch.
+struct GridColumnModel {
+    struct In { float mm, beta, hvt, ulog, eta_old; };
+    static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
+        In in;
+        in.mm = live ? A.mu_mult[j] : 0.0f;
+        in.beta = live ? A.std_beta[j] : 0.0f;
+        in.hvt = live ? A.shvt[j] : 0.0f;
+        in.ulog = live ? A.u_logs[j] : 0.0f;
+        in.eta_old = live ? A.eta[j] : 0.0f;
+        return in;
+    }
+    template <int LOOKUP>
+    static __device__ __forceinline__ void core(const In& in, float q, const ExpTab& tab, float& mu, float& gamma,
+                                                float& d, int sel) {
+        mu = in.mm * (in.beta - q);                                       // :613
+        const float u = in.ulog + in.hvt * mu * mu;                       // :616
+        gamma = sigmoid_exact<LOOKUP>(u, tab, sel);                       // :617
+        d = gamma * mu - in.eta_old;                                      // :620
+    }
+    template <int LOOKUP>
+    static __device__ __forceinline__ bool update(const In& in, float q, const ExpTab& tab, float& d, int sel) {
+        float mu, gamma;
+        core<LOOKUP>(in, q, tab, mu, gamma, d, sel);
+        return true;
+    }
+    template <bool TEAM>
+    static __device__ __forceinline__ float finish(const EStepArgs<float>& A, int64_t j, const In& in, float q,
+                                                   const ExpTab& tab, bool live, bool writer, bool& skipped) {
+        float mu, gamma, d;
+        core<kLookupPerLane>(in, q, tab, mu, gamma, d, 0);
+        if (live && writer) {
+            A.var_mu[j] = mu;
+            A.var_gamma[j] = gamma;
+            A.eta_diff[j] = d;
+            if (TEAM) A.eta_out[j] = in.eta_old + d; else A.eta[j] = in.eta_old + d;   // :633
+        }
+        skipped = false;
+        return live ? A.dq * d : 0.0f;
+    }
+};
+
+// e_step_mixture (e_step.hpp:496-537) for K <= kPanelMaxK components ((m, K) arrays C-ordered).
+constexpr int kPanelMaxK = 8;
+struct MixtureModel {
+    struct In { float mm[kPanelMaxK], sv[kPanelMaxK], ulog[kPanelMaxK]; float lnp, beta, eta_old; int K; };
+    static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
+        In in;
+        in.K = A.width;
+#pragma unroll
+        for (int k = 0; k < kPanelMaxK; ++k) {
+            const bool on = live && k < in.K;
+            const int64_t idx = on ? j * in.K + k : 0;
+            in.mm[k] = on ? A.mu_mult[idx] : 0.0f;
+            in.sv[k] = on ? A.shvt[idx] : 0.0f;
+            in.ulog[k] = on ? A.u_logs[idx] : 0.0f;
+        }
+        in.lnp = live ? A.log_null_pi[j] : 0.0f;
+        in.beta = live ? A.std_beta[j] : 0.0f;
+        in.eta_old = live ? A.eta[j] : 0.0f;
+        return in;
+    }
+    template <int LOOKUP>
+    static __device__ __forceinline__ void core(const In& in, float q, const ExpTab& tab, float (&mu)[kPanelMaxK],
+                                                float (&gam)[kPanelMaxK], float& d, int sel) {
+        const float r = in.beta - q;                                      // :505
+        float u[kPanelMaxK];
+        float mx = in.lnp;                                                // max over u_0..u_K (c_max, :58-71)
+#pragma unroll
+        for (int k = 0; k < kPanelMaxK; ++k) {
+            mu[k] = in.mm[k] * r;                                         // :509
+            const float t = in.sv[k] * mu[k];
+            u[k] = __builtin_fmaf(t, t, in.ulog[k]);                      // :511
+            if (k < in.K) mx = fmaxf(mx, u[k]);
+        }
+        float ssum = 0.0f;                                                // softmax, :231-240: k = 0..K in order
+#pragma unroll
+        for (int k = 0; k < kPanelMaxK; ++k) {
+            if (k < in.K) {
+                u[k] = expf_glibc_nonpos<LOOKUP>(u[k] - mx, tab, sel);
+                ssum += u[k];
+            }
+        }
+        ssum += expf_glibc_nonpos<LOOKUP>(in.lnp - mx, tab, sel);
+        d = -in.eta_old;                                                  // :519
+#pragma unroll
+        for (int k = 0; k < kPanelMaxK; ++k) {
+            if (k < in.K) {
+                gam[k] = u[k] / ssum;                                     // :239
+                d = __builtin_fmaf(gam[k], mu[k], d);                     // :523
+            }
+        }
+    }
+    template <int LOOKUP>
+    static __device__ __forceinline__ bool update(const In& in, float q, const ExpTab& tab, float& d, int sel) {
+        float mu[kPanelMaxK], gam[kPanelMaxK];
+        core<LOOKUP>(in, q, tab, mu, gam, d, sel);
+        return true;
+    }
+    template <bool TEAM>
+    static __device__ __forceinline__ float finish(const EStepArgs<float>& A, int64_t j, const In& in, float q,
+                                                   const ExpTab& tab, bool live, bool writer, bool& skipped) {
+        float mu[kPanelMaxK], gam[kPanelMaxK], d;
+        core<kLookupPerLane>(in, q, tab, mu, gam, d, 0);
+        if (live && writer) {
+#pragma unroll
+            for (int k = 0; k < kPanelMaxK; ++k) {
+                if (k < in.K) {
+                    A.var_mu[j * in.K + k] = mu[k];
+                    A.var_gamma[j * in.K + k] = gam[k];
+                }
+            }
+            A.eta_diff[j] = d;
+            if (TEAM) A.eta_out[j] = in.eta_old + d; else A.eta[j] = in.eta_old + d;   // :536
+        }
+        skipped = false;
+        return live ? A.dq * d : 0.0f;
+    }
+};
+
+template <typename U, typename MODEL, bool SYM, int NW, bool TEAM, int CPL>
 __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A, int qcap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lq = smem;
@@ -145,7 +316,6 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     ExpTab tab;
     tab.init();
     unsigned long long my_skipped = 0;
-    const float eps = Eps<float>::value;
     const float dq = A.dq;
 
     // Admission control (optional; thresholds computed by the host).  Blocks are queued in
@@ -204,16 +374,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
 
         // ---- chain wave: inputs and first diagonal-tile rows of the NEXT panel, fetched under the
         //      current panel's serial updates so that no HBM latency sits between two panels
-        float n_mm = 0.0f, n_beta = 0.0f, n_sv = 0.0f, n_ulog = 0.0f, n_eta = 0.0f;
+        typename MODEL::In nxt_in{};
         float dnext[kChainPrefetch];
         if (wave == 0) {
             const bool live0 = lane < b;
-            const int64_t j0 = s0 + (live0 ? lane : 0);
-            n_mm = live0 ? A.mu_mult[j0] : 0.0f;
-            n_beta = live0 ? A.std_beta[j0] : 0.0f;
-            n_sv = live0 ? A.shvt[j0] : 0.0f;
-            n_ulog = live0 ? A.u_logs[j0] : 0.0f;
-            n_eta = live0 ? A.eta[j0] : 0.0f;
+            nxt_in = MODEL::load(A, s0 + (live0 ? lane : 0), live0);
 #pragma unroll
             for (int k = 0; k < kChainPrefetch; ++k)
                 dnext[k] = static_cast<float>(base[(int64_t)min(k, b - 1) * stride + lane]);
@@ -228,16 +393,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     const int nrows = min(kPanel, b - r0);
                     const int64_t j = s0 + r0 + lane;
                     const bool live = lane < nrows;
-                    const float mm = n_mm, beta = n_beta, sv = n_sv, ulog = n_ulog, eta_old = n_eta;
+                    const typename MODEL::In in = nxt_in;
                     {   // next panel's inputs (consumed one phase later)
                         const int rn = r0 + kPanel + lane;
                         const bool ln = rn < b;
-                        const int64_t jn = s0 + (ln ? rn : 0);
-                        n_mm = ln ? A.mu_mult[jn] : 0.0f;
-                        n_beta = ln ? A.std_beta[jn] : 0.0f;
-                        n_sv = ln ? A.shvt[jn] : 0.0f;
-                        n_ulog = ln ? A.u_logs[jn] : 0.0f;
-                        n_eta = ln ? A.eta[jn] : 0.0f;
+                        nxt_in = MODEL::load(A, s0 + (ln ? rn : 0), ln);
                     }
 
                     // diagonal tile rows, streamed kChainPrefetch rows ahead.  All 64 steps always
@@ -293,10 +453,9 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         else
                             dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
                                 nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
-                        float mu, gamma, d;
-                        snp_update<EXACT, kLookupLane>(mm, beta, sv, ulog, eta_old, qc, tab, mu, gamma, d, jj);
+                        float d;
                         // dead lanes (past a partial last panel) are forced onto the skip path
-                        const bool upd = !(fabsf(d) < eps) && live;
+                        const bool upd = MODEL::template update<kLookupLane>(in, qc, tab, d, jj) && live;
                         const float a_lane = upd ? dq * d : 0.0f;
                         // (keeps hipcc from hoisting 64 loop-invariant lane masks and spilling them)
                         int l = lane;
@@ -309,22 +468,9 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
 
                     // lane-parallel replay of the 64 updates (same operations, same inputs ->
                     // same bits) to produce the per-SNP outputs without serialising the stores
-                    float mu, gamma, d;
-                    snp_update<EXACT, kLookupPerLane>(mm, beta, sv, ulog, eta_old, qcap_v, tab, mu, gamma, d);
-                    const bool skip = fabsf(d) < eps;
-                    if (live && member == 0) {
-                        if (!skip) {
-                            A.var_mu[j] = mu;
-                            A.var_gamma[j] = gamma;
-                            A.eta_diff[j] = d;
-                            if (!TEAM) A.eta[j] = eta_old + d;
-                        } else {
-                            A.eta_diff[j] = 0.0f;
-                        }
-                        if (TEAM) A.eta_out[j] = skip ? eta_old : eta_old + d;
-                    }
-                    my_skipped += __popcll(__ballot(live && skip));
-                    a_prev = (live && !skip) ? dq * d : 0.0f;
+                    bool skipped_lane;
+                    a_prev = MODEL::template finish<TEAM>(A, j, in, qcap_v, tab, live, member == 0, skipped_lane);
+                    my_skipped += __popcll(__ballot(skipped_lane));
                     la[(p & 1) * kPanel + lane] = a_prev;
                     lq[r0 + lane] = qc;
                 }
