@@ -1,3 +1,9 @@
+#!/bin/bash
+# rocprofv3 collection for profiles/ (run on the GPU box through gpurun):
+#   bash tools/profile.sh <tag> [bench.py args]     e.g.  bash tools/profile.sh r02 --low-memory
+# then, back in the authoring container:
+#   python profiles/summarize.py <tag> gpurun_out/<tag>_stats gpurun_out/<tag>_fetch gpurun_out/<tag>_write <traffic-key>
+# Counters are collected in their own passes (kernel-trace only), one PMC counter per pass.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
@@ -6,4 +12,4 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 "$@" > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 "$@" > /dev/null 2>&1
 cat $R/gpurun_out/${TAG}_stats/*/*kernel_stats.csv | head -8 | cut -c1-170
-cat $R/gpurun_out/${TAG}_stats_bench.json | cut -c1-300
+cut -c1-300 $R/gpurun_out/${TAG}_stats_bench.json

@@ -203,6 +203,7 @@ struct viprs_plan {
     int admit_grid = 0;
     double admit_factor = 1.5;
     int64_t n_epi = 0;
+    int epi_begin[4] = {0, 0, 0, 0};        // per size class ranges of d_epi
     DevBuf<int32_t> d_lb;
     DevBuf<int64_t> d_ip;
     DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
@@ -457,12 +458,20 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         HIP_TRY(hipDeviceSynchronize());
         if (P->low_memory) {
             std::vector<EpiItem> items;
-            for (size_t i = 0; i < P->dense_h.size(); ++i)
-                for (int r0 = 0; r0 < P->dense_h[i].size; r0 += kPanel) items.push_back({(int32_t)i, r0});
-            // longest rows first (the item cost is the number of columns right of its rows)
-            std::stable_sort(items.begin(), items.end(), [&](const EpiItem& x, const EpiItem& y) {
-                return P->dense_h[(size_t)x.blk].size - x.row0 > P->dense_h[(size_t)y.blk].size - y.row0;
-            });
+            for (int c = 0; c < 3; ++c) {
+                P->epi_begin[c] = (int)items.size();
+                std::vector<EpiItem> cls;
+                for (int i = P->class_begin[c]; i < P->class_begin[c + 1]; ++i)
+                    for (int r0 = 0; r0 < P->dense_h[(size_t)i].size; r0 += kPanel)
+                        cls.push_back({(int32_t)(i - P->class_begin[c]), r0});        // block index inside its class
+                // longest rows first (the item cost is the number of columns right of its rows)
+                const int cb = P->class_begin[c];
+                std::stable_sort(cls.begin(), cls.end(), [&](const EpiItem& x, const EpiItem& y) {
+                    return P->dense_h[(size_t)(cb + x.blk)].size - x.row0 > P->dense_h[(size_t)(cb + y.blk)].size - y.row0;
+                });
+                items.insert(items.end(), cls.begin(), cls.end());
+            }
+            P->epi_begin[3] = (int)items.size();
             P->n_epi = (int64_t)items.size();
             HIP_TRY(P->d_epi.alloc(items.size()));
             HIP_TRY(hipMemcpy(P->d_epi.p, items.data(), sizeof(EpiItem) * items.size(), hipMemcpyHostToDevice));
@@ -798,6 +807,17 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
         commit_team_kernel<<<A.n_blocks, 256, 0, stream>>>(A);
         HIP_TRY(hipGetLastError());
     }
+    if (upper) {
+        // the reference's second pass for this class, right behind its forward kernel on the same
+        // stream (so it overlaps the forward kernels of the other classes)
+        const int eb = P->epi_begin[cls], en = P->epi_begin[cls + 1] - eb;
+        if (en > 0) {
+            const int eg = (int)std::min<int64_t>((en + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
+            estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, stream>>>(A, P->d_epi.p + eb, en,
+                                                                                      P->d_counters.p + 8 + cls);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     return VIPRS_OK;
 }
 
@@ -814,14 +834,6 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A, int model = kPanelSpikeSlab)
     for (int c = 0; c < 3; ++c) {
         HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
         HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join[c], 0));
-    }
-    if (P->low_memory && P->n_epi > 0) {
-        A.blocks = P->d_dense.p;
-        A.n_blocks = (int)P->dense_h.size();
-        const int eg = (int)std::min<int64_t>((P->n_epi + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
-        estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, P->stream>>>(A, P->d_epi.p, (int)P->n_epi,
-                                                                                         P->d_counters.p + 3);
-        HIP_TRY(hipGetLastError());
     }
     return VIPRS_OK;
 }
