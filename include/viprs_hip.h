@@ -185,6 +185,14 @@ int viprs_state_prep(viprs_state* state, double logit_pi, double log_tau_beta, d
  * zeta = gamma (mu^2 + 1/var_tau) in float64 (VIPRS.py:896).  Synchronises the plan's stream.      */
 #define VIPRS_N_SUMS 11
 int viprs_state_sums(viprs_state* state, double one_plus_lambda, double* out);
+/* The same two operations on ONE model (column `g`) of a grid state ((m, G) column-major arrays),
+ * for the batched grid fit: e_step_grid takes half_var_tau = var_tau / 2 (e_step.hpp:616) where
+ * e_step takes its square root, otherwise the formulas are those above.                            */
+int viprs_state_prep_column(viprs_state* state, int g, double logit_pi, double log_tau_beta, double sigma_epsilon,
+                            double tau_beta, double one_plus_lambda);
+int viprs_state_sums_column(viprs_state* state, int g, double one_plus_lambda, double* out);
+/* Per-column re-initialisation of a grid state: var_gamma[:, g] = pi_g, everything else 0.         */
+int viprs_state_reset_column(viprs_state* state, int g, double pi);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last viprs_state_e_step / viprs_e_step* call on

@@ -163,5 +163,37 @@ def main():
               "pi", model.pi, "sig_eps", model.sigma_epsilon)
 
 
+def grid_cases():
+    """VIPRSGrid (serial grid fits through VIPRS.fit, pathwise and independent) + HyperparameterGrid."""
+    GWADataLoader = sys.modules["magenpy"].GWADataLoader
+    from viprs.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+    from viprs.model.gridsearch.VIPRSGrid import VIPRSGrid
+    chrom_sizes = {22: [300, 250, 350]}
+    for pathwise in (True, False):
+        gdl, inputs = make_loader(GWADataLoader, chrom_sizes, np.float32, seed=401)
+        grid = HyperparameterGrid(sigma_epsilon_steps=2, pi_steps=3, n_snps=gdl.m, h2_est=0.2, h2_se=0.1)
+        model = VIPRSGrid(gdl, grid, low_memory=True)
+        model.fit(pathwise=pathwise, max_iter=80, disable_pbar=True)
+        vr = model.validation_result
+        name = "fitgrid_pathwise" if pathwise else "fitgrid_independent"
+        out = dict(n=gdl.n, pathwise=pathwise, chroms=np.array([22]), grid_sigma_epsilon=vr["sigma_epsilon"].to_numpy(),
+                   grid_pi=vr["pi"].to_numpy(), elbo=vr["ELBO"].to_numpy().astype(np.float64),
+                   converged=vr["Converged"].to_numpy(), messages=np.array(list(vr["Optimization_message"])),
+                   nit=np.array([r.nit for r in model.optim_results]), tau_beta=np.asarray(model.tau_beta, dtype=np.float64),
+                   sigma_g=np.asarray(model._sigma_g, dtype=np.float64))
+        for c in (22,):
+            ld_sym, ld_up, ss = inputs[c]
+            out[f"sizes_{c}"] = np.array(chrom_sizes[c])
+            out[f"std_beta_{c}"] = ss.std_beta
+            out[f"n_per_snp_{c}"] = ss.n_per_snp
+            out[f"rho_{c}"] = ld_sym.rho
+            out[f"pip_{c}"] = model.pip[c]
+            out[f"post_mean_beta_{c}"] = model.post_mean_beta[c]
+            out[f"q_{c}"] = model.q[c]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "ELBO", out["elbo"], "nit", out["nit"], out["messages"][:2])
+
+
 if __name__ == "__main__":
     main()
+    grid_cases()

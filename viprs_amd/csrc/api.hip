@@ -98,14 +98,15 @@ __global__ void reset_state_kernel(T* var_gamma, T* var_mu, int64_t n_wide, T* e
 template <typename T>
 __global__ void prep_kernel(const double* __restrict__ n, int64_t m, double logit_pi, double log_tau_beta,
                             double sigma_eps, double tau_beta, double one_plus_lambda, T* __restrict__ mu_mult,
-                            T* __restrict__ u_logs, T* __restrict__ shvt, double* __restrict__ var_tau_out) {
+                            T* __restrict__ u_logs, T* __restrict__ shvt, double* __restrict__ var_tau_out,
+                            int half_not_sqrt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const double vt = n[i] * one_plus_lambda / sigma_eps + tau_beta;
     var_tau_out[i] = vt;
     mu_mult[i] = (T)(n[i] / (vt * sigma_eps));
     u_logs[i] = (T)(logit_pi + 0.5 * (log_tau_beta - log(vt)));
-    shvt[i] = (T)sqrt(0.5 * vt);
+    shvt[i] = half_not_sqrt ? (T)(0.5 * vt) : (T)sqrt(0.5 * vt);     // e_step_grid takes var_tau / 2 (e_step.hpp:616)
 }
 
 constexpr int kSumsBlock = 256;
@@ -623,6 +624,25 @@ static int check_device_error(viprs_plan* P) {
     return VIPRS_OK;
 }
 
+template <typename T>
+static int sums_launch(viprs_state* S, int64_t off, int64_t vt_off, double one_plus_lambda, double* out) {
+    viprs_plan* P = S->plan;
+    const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
+    if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
+    if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
+    sums_kernel<T><<<nb, kSumsBlock, 0, P->stream>>>(
+        P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (const T*)S->f[VIPRS_FIELD_VAR_MU].p + off,
+        (const T*)S->f[VIPRS_FIELD_ETA].p + off, (const T*)S->f[VIPRS_FIELD_Q].p + off,
+        (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, (const T*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p + vt_off,
+        one_plus_lambda, S->d_partials.p);
+    HIP_TRY(hipGetLastError());
+    sums_final_kernel<<<1, 64, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, S->d_sums.p, kNSums * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return check_device_error(P);
+}
+
 extern "C" {
 
 int viprs_state_synchronize(viprs_state* S) {
@@ -1116,12 +1136,12 @@ int viprs_state_prep(viprs_state* S, double logit_pi, double log_tau_beta, doubl
         prep_kernel<float><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
                                                         one_plus_lambda, (float*)S->f[VIPRS_FIELD_MU_MULT].p,
                                                         (float*)S->f[VIPRS_FIELD_U_LOGS].p,
-                                                        (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+                                                        (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p, 0);
     else
         prep_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
                                                          one_plus_lambda, (double*)S->f[VIPRS_FIELD_MU_MULT].p,
                                                          (double*)S->f[VIPRS_FIELD_U_LOGS].p,
-                                                         (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+                                                         (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p, 0);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
 }
@@ -1134,27 +1154,82 @@ int viprs_state_sums(viprs_state* S, double one_plus_lambda, double* out) {
     if (P->m == 0) return VIPRS_OK;
     if (!S->d_var_tau.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp / viprs_state_prep have not been called");
     HIP_TRY(hipSetDevice(P->device));
-    const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
-    if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
-    if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
+    return S->float_dtype == VIPRS_F32 ? sums_launch<float>(S, 0, 0, one_plus_lambda, out)
+                                       : sums_launch<double>(S, 0, 0, one_plus_lambda, out);
+}
+
+static int grid_column_check(viprs_state* S, int g) {
+    if (!S) return fail(VIPRS_EINVAL, "null state");
+    if (S->model_kind != VIPRS_MODEL_GRID) return fail(VIPRS_EINVAL, "not a grid state");
+    if (g < 0 || g >= S->width) return fail(VIPRS_EINVAL, "model index out of range");
+    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    return VIPRS_OK;
+}
+
+int viprs_state_prep_column(viprs_state* S, int g, double logit_pi, double log_tau_beta, double sigma_epsilon,
+                            double tau_beta, double one_plus_lambda) {
+    int rc = grid_column_check(S, g);
+    if (rc != VIPRS_OK) return rc;
+    viprs_plan* P = S->plan;
+    if (P->m == 0) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    if (S->d_var_tau.n < (size_t)P->m * S->width) {      // one var_tau column per model
+        HIP_TRY(hipStreamSynchronize(P->stream));
+        HIP_TRY(S->d_var_tau.alloc((size_t)P->m * S->width));
+    }
+    const int64_t off = (int64_t)g * P->m;
+    const unsigned grid = (unsigned)((P->m + 255) / 256);
     if (S->float_dtype == VIPRS_F32)
-        sums_kernel<float><<<nb, kSumsBlock, 0, P->stream>>>(
-            P->m, (const float*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const float*)S->f[VIPRS_FIELD_VAR_MU].p,
-            (const float*)S->f[VIPRS_FIELD_ETA].p, (const float*)S->f[VIPRS_FIELD_Q].p,
-            (const float*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const float*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p,
-            one_plus_lambda, S->d_partials.p);
+        prep_kernel<float><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
+                                                        one_plus_lambda, (float*)S->f[VIPRS_FIELD_MU_MULT].p + off,
+                                                        (float*)S->f[VIPRS_FIELD_U_LOGS].p + off,
+                                                        (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p + off,
+                                                        S->d_var_tau.p + off, 1);
     else
-        sums_kernel<double><<<nb, kSumsBlock, 0, P->stream>>>(
-            P->m, (const double*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const double*)S->f[VIPRS_FIELD_VAR_MU].p,
-            (const double*)S->f[VIPRS_FIELD_ETA].p, (const double*)S->f[VIPRS_FIELD_Q].p,
-            (const double*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const double*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p,
-            one_plus_lambda, S->d_partials.p);
+        prep_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
+                                                         one_plus_lambda, (double*)S->f[VIPRS_FIELD_MU_MULT].p + off,
+                                                         (double*)S->f[VIPRS_FIELD_U_LOGS].p + off,
+                                                         (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p + off,
+                                                         S->d_var_tau.p + off, 1);
     HIP_TRY(hipGetLastError());
-    sums_final_kernel<<<1, 64, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
+    return VIPRS_OK;
+}
+
+int viprs_state_sums_column(viprs_state* S, int g, double one_plus_lambda, double* out) {
+    if (!out) return fail(VIPRS_EINVAL, "null argument");
+    int rc = grid_column_check(S, g);
+    if (rc != VIPRS_OK) return rc;
+    viprs_plan* P = S->plan;
+    for (int k = 0; k < kNSums; ++k) out[k] = 0.0;
+    if (P->m == 0) return VIPRS_OK;
+    if (S->d_var_tau.n < (size_t)P->m * S->width) return fail(VIPRS_EINVAL, "viprs_state_prep_column has not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    const int64_t off = (int64_t)g * P->m;
+    return S->float_dtype == VIPRS_F32 ? sums_launch<float>(S, off, off, one_plus_lambda, out)
+                                       : sums_launch<double>(S, off, off, one_plus_lambda, out);
+}
+
+int viprs_state_reset_column(viprs_state* S, int g, double pi) {
+    if (!S) return fail(VIPRS_EINVAL, "null state");
+    if (S->model_kind != VIPRS_MODEL_GRID) return fail(VIPRS_EINVAL, "not a grid state");
+    if (g < 0 || g >= S->width) return fail(VIPRS_EINVAL, "model index out of range");
+    viprs_plan* P = S->plan;
+    if (P->m == 0) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    const int64_t off = (int64_t)g * P->m, n = P->m;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (S->float_dtype == VIPRS_F32)
+        reset_state_kernel<float><<<grid, 256, 0, P->stream>>>(
+            (float*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (float*)S->f[VIPRS_FIELD_VAR_MU].p + off, n,
+            (float*)S->f[VIPRS_FIELD_ETA].p + off, (float*)S->f[VIPRS_FIELD_Q].p + off,
+            (float*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, n, (float)pi);
+    else
+        reset_state_kernel<double><<<grid, 256, 0, P->stream>>>(
+            (double*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (double*)S->f[VIPRS_FIELD_VAR_MU].p + off, n,
+            (double*)S->f[VIPRS_FIELD_ETA].p + off, (double*)S->f[VIPRS_FIELD_Q].p + off,
+            (double*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, n, pi);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, S->d_sums.p, kNSums * sizeof(double), hipMemcpyDeviceToHost, P->stream));
-    HIP_TRY(hipStreamSynchronize(P->stream));
-    return check_device_error(P);
+    return VIPRS_OK;
 }
 
 static int sweep_ms(viprs_plan* P, int64_t sweep, int which, double* ms) {

@@ -1,4 +1,5 @@
 from .VIPRS import VIPRS
 from .VIPRSMix import VIPRSMix
+from .gridsearch import HyperparameterGrid, VIPRSGrid, bayesian_model_average, select_best_model
 
-__all__ = ["VIPRS", "VIPRSMix"]
+__all__ = ["VIPRS", "VIPRSMix", "VIPRSGrid", "HyperparameterGrid", "select_best_model", "bayesian_model_average"]

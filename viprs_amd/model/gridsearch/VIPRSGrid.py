@@ -1,0 +1,254 @@
+"""``VIPRSGrid`` -- the spike-and-slab model over a grid of fixed hyper-parameters.
+
+Two ways to fit the grid:
+
+* ``fit(pathwise=True|False)`` -- the reference's scheme (viprs/model/gridsearch/VIPRSGrid.py:128-258):
+  the grid points are fitted one after the other through ``VIPRS.fit`` (warm-started from the
+  previous point when ``pathwise``); every fit runs the spike-and-slab E-step kernels.
+* ``fit(batched=True)`` -- all grid points at once: the (m, n_models) state lives in
+  one device-resident grid state, every EM iteration runs ``e_step_grid`` (e_step.hpp:555-647, the
+  kernel the reference ships but no longer calls) over the models that are still active, the per-model
+  M-step / ELBO sums come back as a few scalars per model, and converged models drop out of
+  ``active_model_idx``.  Models are independent fits from the standard initialisation.
+
+Either way the outputs have the reference's layout: ``var_gamma / var_mu / var_tau / q`` of shape
+``(m, n_models)`` per chromosome, vector-valued ``pi / sigma_epsilon / tau_beta / _sigma_g``, and the
+``validation_result`` table (grid columns + ``ELBO``, ``Converged``, ``Optimization_message``).
+"""
+import copy
+
+import numpy as np
+import pandas as pd
+
+from ..VIPRS import VIPRS
+from ...utils.optim import ConditionStreak, OptimizeResult
+
+
+class VIPRSGrid(VIPRS):
+
+    def __init__(self, gdl, grid, **kwargs):
+        self.grid_table = grid.to_table()
+        self.n_models = len(self.grid_table)
+        assert self.n_models > 1, "Grid search requires at least 2 models."
+        self.validation_result = None
+        self.optim_results = []
+        super().__init__(gdl, **kwargs)
+        self._grid_state = {}
+
+    # ---- bookkeeping (VIPRSGrid.py:65-126) --------------------------------------------------------
+    @property
+    def converged_models(self):
+        return np.array([r.success for r in self.optim_results])
+
+    @property
+    def terminated_models(self):
+        return np.array([r.stop_iteration for r in self.optim_results])
+
+    @property
+    def valid_terminated_models(self):
+        return np.array([r.valid_optim_result for r in self.optim_results])
+
+    @property
+    def models_to_keep(self):
+        return np.logical_or(~self.terminated_models, self.converged_models)
+
+    def to_validation_table(self):
+        if self.validation_result is None or len(self.validation_result) < 1:
+            raise ValueError("Validation result is not set!")
+        return pd.DataFrame(self.validation_result)
+
+    def init_optim_meta(self):
+        super().init_optim_meta()
+        self.optim_results = []
+
+    # ---- fitting -------------------------------------------------------------------------------------
+    def fit(self, pathwise=True, batched=False, **fit_kwargs):
+        fit_kwargs.pop("disable_pbar", None)
+        if batched:
+            return self._fit_batched(**fit_kwargs)
+        return self._fit_serial(pathwise, **fit_kwargs)
+
+    def _collect(self, store, i):
+        for c in self.shapes:
+            store["var_gamma"][c][:, i] = self.var_gamma[c]
+            store["var_mu"][c][:, i] = self.var_mu[c]
+            store["var_tau"][c][:, i] = self.var_tau[c]
+            store["q"][c][:, i] = self.q[c]
+        store["sigma_epsilon"][i], store["pi"][i] = self.sigma_epsilon, self.pi
+        store["sigma_g"][i], store["tau_beta"][i] = self._sigma_g, self.tau_beta
+
+    def _new_store(self):
+        T = self.float_precision
+        mk = lambda: {c: np.empty((s, self.n_models), dtype=T) for c, s in self.shapes.items()}
+        return dict(var_gamma=mk(), var_mu=mk(), var_tau=mk(), q=mk(),
+                    sigma_epsilon=np.empty(self.n_models, T), pi=np.empty(self.n_models, T),
+                    sigma_g=np.empty(self.n_models, T), tau_beta=np.empty(self.n_models, T),
+                    elbo=np.empty(self.n_models, T))
+
+    def _publish(self, store, optim_results):
+        self.optim_result.nit = int(np.sum([r.nit for r in optim_results]))
+        self.optim_results = optim_results
+        self.var_gamma, self.var_mu, self.var_tau, self.q = (store[k] for k in ("var_gamma", "var_mu", "var_tau", "q"))
+        self.eta = self.compute_eta()
+        self.zeta = self.compute_zeta()
+        self._log_var_tau = {c: np.log(self.var_tau[c]) for c in self.var_tau}
+        self._host_stale = False
+        self.update_posterior_moments()
+        self.sigma_epsilon, self.pi = store["sigma_epsilon"], store["pi"]
+        self._sigma_g, self.tau_beta = store["sigma_g"], store["tau_beta"]
+        self.model_elbos = store["elbo"].astype(np.float64)
+        self.validation_result = self.grid_table.copy()
+        self.validation_result["ELBO"] = store["elbo"]
+        self.validation_result["Converged"] = self.converged_models
+        self.validation_result["Optimization_message"] = [r.message for r in self.optim_results]
+        return self
+
+    def _fit_serial(self, pathwise, **fit_kwargs):
+        """One VIPRS.fit per grid point (VIPRSGrid.py:194-225)."""
+        store, results = self._new_store(), []
+        params = self.grid_table.to_dict(orient="records")
+        for i in range(self.n_models):
+            self.set_fixed_params(params[i])
+            super().fit(continued=(i > 0 and pathwise), **fit_kwargs)
+            results.append(copy.deepcopy(self.optim_result))
+            self.optim_result.reset()
+            store["elbo"][i] = self.history["ELBO"][-1]
+            self._collect(store, i)
+        return self._publish(store, results)
+
+    # ---- all grid points at once -------------------------------------------------------------------------
+    def _fit_batched(self, max_iter=1000, theta_0=None, min_iter=3, f_abs_tol=1e-6, x_abs_tol=1e-6, patience=10,
+                     **kwargs):
+        if self._e_step_fn is not None or self.comm.world_size != 1:
+            raise NotImplementedError("the batched grid fit runs on one GPU through the device-resident grid state")
+        from ...plan import DeviceState
+        G, T = self.n_models, self._T
+        params = self.grid_table.to_dict(orient="records")
+        # per-model hyper-parameters: grid values are fixed, the rest follows VIPRS.initialize_theta
+        th = []
+        for g in range(G):
+            self.fix_params = dict(params[g])
+            self.initialize_theta(dict(theta_0) if theta_0 else None)
+            th.append(dict(pi=self.pi, sigma_epsilon=self.sigma_epsilon, tau_beta=self.tau_beta,
+                           lam=self.lambda_min, fixed=set(params[g])))
+        self.fix_params = {}
+        states = {}
+        for c in self.chromosomes:
+            st = self._grid_state.get(c)
+            if st is None:
+                st = self._grid_state[c] = DeviceState(self._plans[c], self.float_precision, "grid", G)
+                st.upload("std_beta", self.std_beta[c])
+                st.set_n_per_snp(self.n_per_snp[c])
+            for g in range(G):
+                st.reset_column(g, float(th[g]["pi"]))
+            states[c] = st
+
+        def sums(g):
+            s = np.zeros(11)
+            for c in self.chromosomes:
+                v = states[c].sums_column(g, 1.0 + th[g]["lam"])
+                s[0] += v[0] / self.shapes[c]
+                s[1:10] += v[1:10]
+                s[10] = max(s[10], v[10])
+            return s
+
+        def elbo(g, s, sigma_g):
+            p = th[g]
+            e = -np.log(2.0 * np.pi * p["sigma_epsilon"])
+            if "sigma_epsilon" not in p["fixed"]:
+                e -= 1.0
+            else:
+                e -= (1.0 / p["sigma_epsilon"]) * (1.0 - 2.0 * s[3] + sigma_g)
+            e *= 0.5 * self.n
+            e -= s[5] - np.log(p["pi"]) * s[7]
+            e -= s[6] - np.log(1.0 - p["pi"]) * s[8]
+            e += 0.5 * ((1.0 + np.log(p["tau_beta"])) * s[7] - s[9])
+            e -= 0.5 * p["tau_beta"] * s[1]
+            return float(e)
+
+        results = [OptimizeResult() for _ in range(G)]
+        sigma_g = np.zeros(G)
+        prev_elbo = np.full(G, -np.inf)
+        prev_sigma_g = np.zeros(G)
+        plateau = [ConditionStreak() for _ in range(G)]
+        dropping = [ConditionStreak() for _ in range(G)]
+        elbos = np.zeros(G)
+        active = np.arange(G, dtype=np.int32)
+        for g in range(G):                       # initial ELBO needs var_tau of the initial hyper-parameters
+            p = th[g]
+            for c in self.chromosomes:
+                states[c].prep_column(g, float(np.log(p["pi"]) - np.log(1.0 - p["pi"])), float(np.log(p["tau_beta"])),
+                                      p["sigma_epsilon"], p["tau_beta"], 1.0 + p["lam"])
+
+        for i in range(1, max_iter + 1):
+            if active.size == 0:
+                break
+            for g in active:
+                p = th[g]
+                p["sigma_epsilon_e"], p["tau_beta_e"] = p["sigma_epsilon"], p["tau_beta"]   # what var_tau is built from
+                for c in self.chromosomes:
+                    states[c].prep_column(g, float(np.log(p["pi"]) - np.log(1.0 - p["pi"])),
+                                          float(np.log(p["tau_beta"])), p["sigma_epsilon"], p["tau_beta"],
+                                          1.0 + p["lam"])
+            for c in self.chromosomes:
+                states[c].e_step(self.dequantize_scale, active_model_idx=active, sync=False)
+            still = []
+            for g in active:
+                p, s = th[g], sums(g)
+                if "pi" not in p["fixed"]:                                   # VIPRS.m_step, per model
+                    p["pi"] = T.type(s[0] / self._n_chroms_total)
+                if "tau_beta" not in p["fixed"]:
+                    p["tau_beta"] = p["pi"] * self.n_snps / s[1]
+                sigma_g[g] = s[2]
+                if "sigma_epsilon" not in p["fixed"]:
+                    p["sigma_epsilon"] = 1.0 + T.type(-2.0 * s[3]) + sigma_g[g]
+                e = elbos[g] = elbo(g, s, sigma_g[g])
+                mse = 1.0 - 2.0 * s[3] + (sigma_g[g] - s[1] + s[4])
+                h2 = sigma_g[g] / (sigma_g[g] + p["sigma_epsilon"])
+                plateau[g].update((i > min_iter) and np.isclose(sigma_g[g], prev_sigma_g[g], atol=x_abs_tol, rtol=0.0)
+                                  and s[10] < x_abs_tol * 10, i)
+                dropping[g].update((e < prev_elbo[g]) and not np.isclose(e, prev_elbo[g], atol=1e3 * f_abs_tol, rtol=1e-4), i)
+                stop = None                                                    # VIPRS.fit stopping rules
+                if mse < 0.0:
+                    stop = (False, f"The MSE is negative ({mse:.6f}).")
+                elif not np.isfinite(e):
+                    stop = (False, "Objective (ELBO) is undefined.")
+                elif p["sigma_epsilon"] < 0.0:
+                    stop = (False, "Residual variance estimate is negative.")
+                elif h2 > 1.0 or h2 < 0.0:
+                    stop = (False, "Estimated heritability is out of bounds.")
+                elif (i > min_iter) and np.isclose(prev_elbo[g], e, atol=f_abs_tol, rtol=0.0):
+                    stop = (True, "Objective (ELBO) converged successfully.")
+                elif (i > min_iter) and s[10] < x_abs_tol:
+                    stop = (True, "Variational parameters converged successfully.")
+                elif plateau[g].counter > patience:
+                    stop = (True, "LD-weighted variational parameters converged successfully.")
+                elif dropping[g].counter > patience:
+                    stop = (False, "The objective (ELBO) is decreasing.")
+                if stop is None:
+                    results[g].update(e)
+                    still.append(g)
+                else:
+                    results[g].update(e, stop_iteration=True, success=stop[0], message=stop[1])
+                prev_elbo[g], prev_sigma_g[g] = e, sigma_g[g]
+            active = np.array(still, dtype=np.int32)
+        for g in range(G):
+            if not results[g].stop_iteration:
+                results[g].update(elbos[g], stop_iteration=True, success=False, increment=False,
+                                  message="Maximum iterations reached without convergence.\\n"
+                                          "You may need to run the model for more iterations.")
+
+        # ---- read the (m, G) state back in the reference's layout ---------------------------------------
+        store = self._new_store()
+        for c in self.chromosomes:
+            for name in ("var_gamma", "var_mu", "q"):
+                store[name][c][...] = states[c].download(name)
+            for g in range(G):
+                p = th[g]
+                store["var_tau"][c][:, g] = (self.n_per_snp[c] * (1.0 + p["lam"]) / p["sigma_epsilon_e"]) + p["tau_beta_e"]
+        for g in range(G):
+            p = th[g]
+            store["sigma_epsilon"][g], store["pi"][g] = p["sigma_epsilon"], p["pi"]
+            store["tau_beta"][g], store["sigma_g"][g], store["elbo"][g] = p["tau_beta"], sigma_g[g], elbos[g]
+        self.eta_diff = {c: states[c].download("eta_diff") for c in self.chromosomes}
+        return self._publish(store, results)

@@ -251,6 +251,19 @@ class DeviceState:
         L.check(L.lib.viprs_state_sums(self._h, float(one_plus_lambda), out))
         return np.array(out[:], dtype=np.float64)
 
+    # -- one model (column) of a grid state -----------------------------------------------------
+    def prep_column(self, g, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda):
+        L.check(L.lib.viprs_state_prep_column(self._h, int(g), float(logit_pi), float(log_tau_beta),
+                                              float(sigma_epsilon), float(tau_beta), float(one_plus_lambda)))
+
+    def sums_column(self, g, one_plus_lambda):
+        out = (ctypes.c_double * L.N_SUMS)()
+        L.check(L.lib.viprs_state_sums_column(self._h, int(g), float(one_plus_lambda), out))
+        return np.array(out[:], dtype=np.float64)
+
+    def reset_column(self, g, pi):
+        L.check(L.lib.viprs_state_reset_column(self._h, int(g), float(pi)))
+
     def e_step(self, dq_scale=1.0, active_model_idx=None, sync=True):
         if active_model_idx is not None:
             active = np.ascontiguousarray(active_model_idx, dtype=np.int32)
