@@ -18,7 +18,7 @@ from viprs_amd.utils import synthetic as syn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-FIT = sorted(glob.glob(os.path.join(HERE, "golden", "fit_*.npz")))
+FIT = sorted(glob.glob(os.path.join(HERE, "golden", "fit_*.npz")))     # (fitgrid_*: tests/test_grid.py)
 
 
 def loader_from_fixture(fx):

@@ -13,7 +13,7 @@ from tests import helpers as H
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURES = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.npz"))
-                  if not os.path.basename(p).startswith("fit_"))   # fit_*: tests/test_fit.py
+                  if not os.path.basename(p).startswith("fit"))   # fit_* / fitgrid_*: tests/test_fit.py, test_grid.py
 STATE = ("var_gamma", "var_mu", "eta", "q", "eta_diff")
 
 
