@@ -97,3 +97,25 @@ def test_batched_grid_fit_matches_independent_reference_fits(gpu):
     np.testing.assert_allclose(np.asarray(model.tau_beta, dtype=np.float64), fx["tau_beta"], rtol=2e-2)
     assert all(model.converged_models)
     assert model.var_gamma[22].shape == (model.shapes[22], 6) and model.eta_diff[22].shape == (model.shapes[22], 6)
+
+
+def test_posterior_table_and_pseudo_validation_cpu():
+    """BayesPRSModel.to_table / pseudo_validate equivalents on a fitted grid and a
+    fitted single model: column naming as the reference, pseudo-R^2 = (r'b)^2 / b'(q + b)."""
+    from viprs_amd.model import VIPRS, VIPRSGrid
+    fx = np.load(os.path.join(HERE, "golden", "fitgrid_independent.npz"))
+    gdl = loader_from_fixture(fx)
+    grid = VIPRSGrid(gdl, _grid(fx, gdl.m), low_memory=True, e_step_fn=O.cpp_e_step).fit(pathwise=True, max_iter=80)
+    tab = grid.to_table()
+    assert list(tab.columns[:2]) == ["CHR", "IDX"] and "BETA_5" in tab.columns and "PIP_0" in tab.columns
+    assert len(tab) == gdl.m
+    vb = {22: fx["std_beta_22"]}
+    r2 = grid.pseudo_validate(vb)
+    assert r2.shape == (6,) and np.all(np.isfinite(r2)) and np.all(r2 > 0)
+    b = grid.post_mean_beta[22][:, 2].astype(np.float64)
+    want = (fx["std_beta_22"] @ b) ** 2 / (b @ (grid.q[22][:, 2] + b))
+    np.testing.assert_allclose(r2[2], want, rtol=1e-5)
+    single = VIPRS(gdl, low_memory=True, e_step_fn=O.cpp_e_step).fit(max_iter=30, theta_0={"pi": 0.01, "sigma_epsilon": 0.8})
+    t1 = single.to_table()
+    assert {"BETA", "PIP", "VAR_BETA"} <= set(t1.columns)
+    assert np.isscalar(float(single.pseudo_validate(vb)))

@@ -327,6 +327,49 @@ class VIPRS:
         self.post_mean_beta = {c: e.copy() for c, e in self.eta.items()}
         self.post_var_beta = {c: z - self.eta[c] ** 2 for c, z in self.zeta.items()}
 
+    # ---- posterior tables and pseudo-validation (BayesPRSModel.py:333-410) --------------------------
+    def to_table(self, col_subset=("CHR", "SNP", "POS", "A1", "A2"), per_chromosome=False):
+        """Posterior estimates as a pandas table: the data loader's SNP columns (``gdl.to_snp_table``
+        when it has one -- a magenpy loader does --, otherwise CHR + the SNP's index) followed by
+        BETA / PIP / VAR_BETA (``BETA_0, BETA_1, ...`` for grid models, as the reference names them)."""
+        import pandas as pd
+        if self.post_mean_beta is None:
+            raise Exception("The posterior means for BETA are not set. Call `.fit()` first.")
+        if hasattr(self.gdl, "to_snp_table"):
+            tables = self.gdl.to_snp_table(col_subset=col_subset, per_chromosome=True)
+        else:
+            tables = {c: pd.DataFrame({"CHR": c, "IDX": np.arange(self.shapes[c])}) for c in self.chromosomes}
+
+        def cols(name, a):
+            a = np.asarray(a)
+            if a.ndim == 1:
+                return {name: a}
+            return {f"{name}_{i}": a[:, i] for i in range(a.shape[1])}
+
+        for c in self.chromosomes:
+            add = dict(cols("BETA", self.post_mean_beta[c]))
+            if self.pip is not None:
+                add.update(cols("PIP", self.pip[c]))
+            if self.post_var_beta is not None:
+                add.update(cols("VAR_BETA", self.post_var_beta[c]))
+            tables[c] = pd.concat([tables[c], pd.DataFrame(add, index=tables[c].index)], axis=1)
+        return tables if per_chromosome else pd.concat([tables[c] for c in self.chromosomes])
+
+    def pseudo_validate(self, validation_std_beta=None):
+        """Pseudo-R^2 of the fitted effects against standardized marginal betas of an independent
+        cohort that shares this LD reference: (r'b)^2 / (b'Rb) with R b = q + b
+        (BayesPRSModel.py:397-410, pseudo_metrics.py `_streamlined_pseudo_r2`); one value per model
+        for grid fits."""
+        vb = validation_std_beta if validation_std_beta is not None else getattr(self, "validation_std_beta", None)
+        assert self.post_mean_beta is not None, "The posterior means for BETA are not set. Call `.fit()` first."
+        assert vb is not None, "standardized betas of a validation set are required"
+        cat = lambda d: np.concatenate([np.asarray(d[c]) for c in self.chromosomes], axis=0)
+        r, b = cat(vb), cat(self.post_mean_beta)
+        rb_w = cat({c: self.q[c] + self.post_mean_beta[c] for c in self.chromosomes})
+        rb = np.sum((b.T * r).T, axis=0)
+        bsb = np.sum(b * rb_w, axis=0)
+        return rb ** 2 / bsb
+
     # ---- partial sums: everything the M-step, the ELBO and the stopping rules need ------------------
     def _partial_sums(self):
         """Per-rank sums over the local SNPs; summed over ranks by one all-reduce.
