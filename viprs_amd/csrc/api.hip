@@ -52,7 +52,7 @@ size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0);
 static int kLargeBlock = 2304, kMediumBlock = 1280;
 constexpr int kClassWaves[3] = {4, 4, 4};
 static int kClassTeam[3] = {8, 3, 1};       // workgroups (CUs) sharing one block of the class (0/1: teams)
-constexpr int kClassCols[3] = {2, 4, 4};    // columns per updater lane: narrower strips = more streaming waves per block
+constexpr int kClassCols[3] = {4, 4, 4};    // columns per updater lane: narrower strips = more streaming waves per block
 constexpr int kEpiWaves = 4;
 
 template <typename V> struct DevBuf {
@@ -547,8 +547,8 @@ int viprs_state_create(viprs_state** out, viprs_plan* plan, int float_dtype, int
     S->model_kind = model_kind;
     S->width = width;
     if (plan->n_granule_rows > 0) {
-        HIP_TRY(S->eta_out.alloc((size_t)plan->m * float_size(float_dtype)));
-        HIP_TRY(S->q_out.alloc((size_t)plan->m * float_size(float_dtype)));
+        HIP_TRY(S->eta_out.alloc(S->field_elems(VIPRS_FIELD_ETA) * float_size(float_dtype)));
+        HIP_TRY(S->q_out.alloc(S->field_elems(VIPRS_FIELD_ETA) * float_size(float_dtype)));
     }
     for (int k = 0; k < VIPRS_FIELD_COUNT; ++k) {
         const size_t bytes = S->field_elems(k) * float_size(float_dtype);
@@ -681,6 +681,7 @@ EStepArgs<T> make_args(viprs_state* S, double dq) {
     A.eta_out = (T*)S->eta_out.p;
     A.q_out = (T*)S->q_out.p;
     A.granules = P->d_granules.p;
+    A.granule_rows = P->n_granule_rows;
     A.error = P->d_error.p;
     A.dq = (T)dq;
     A.low_memory = P->low_memory;
@@ -774,7 +775,9 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NW * 64, shmem));
     per_cu = std::max(1, per_cu);
-    int grid = std::min<int>(A.n_blocks, P->n_cu * per_cu);
+    const int n_models = std::max(1, A.n_active);
+    const int64_t n_items = (int64_t)A.n_blocks * n_models;
+    int grid = (int)std::min<int64_t>(n_items, (int64_t)P->n_cu * per_cu);
     const int TS = TEAM ? kClassTeam[cls] : 1;
     A.team_size = TS;
     if (!TEAM) {
@@ -784,18 +787,18 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
         for (int c = 0; c < 3; ++c) {
             const int nb = P->class_begin[c + 1] - P->class_begin[c];
             if (c < 2 && nb > 0)
-                reserved += std::max(1, std::min(nb, P->n_cu / kClassTeam[c])) * kClassTeam[c];
+                reserved += (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nb * n_models, P->n_cu / kClassTeam[c])) * kClassTeam[c];
         }
-        grid = std::min<int>(A.n_blocks, std::max(P->n_cu / 2, P->n_cu * per_cu - reserved));
+        grid = (int)std::min<int64_t>(n_items, std::max(P->n_cu / 2, P->n_cu * per_cu - reserved));
     }
     if (TEAM) {
         // teams of TS workgroups, statically assigned blocks; the whole grid must be able to be
         // resident at once (at most one workgroup per CU is assumed)
-        A.n_teams = std::max(1, std::min<int>(A.n_blocks, P->n_cu / TS));
+        A.n_teams = (int)std::max<int64_t>(1, std::min<int64_t>(n_items, P->n_cu / TS));
         grid = A.n_teams * TS;
     }
     A.admit = nullptr;
-    if (cls == 2 && P->admit_factor > 0.0) {
+    if (cls == 2 && P->admit_factor > 0.0 && n_models == 1) {
         if (P->admit_grid != grid) {
             // Concurrency needed to keep HBM busy while the head is at a block of b SNPs:
             // a workgroup streams 64 rows x b columns per chain phase (~10 us), i.e. about
@@ -824,7 +827,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     void* params[] = {(void*)&A, (void*)&qcap};
     HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(NW * 64), params, shmem, stream));
     if (TEAM) {
-        commit_team_kernel<<<A.n_blocks, 256, 0, stream>>>(A);
+        commit_team_kernel<<<dim3(A.n_blocks, n_models), 256, 0, stream>>>(A);
         HIP_TRY(hipGetLastError());
     }
     if (upper) {
@@ -832,7 +835,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
         // stream (so it overlaps the forward kernels of the other classes)
         const int eb = P->epi_begin[cls], en = P->epi_begin[cls + 1] - eb;
         if (en > 0) {
-            const int eg = (int)std::min<int64_t>((en + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
+            const int eg = (int)std::min<int64_t>(((int64_t)en * n_models + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
             estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, stream>>>(A, P->d_epi.p + eb, en,
                                                                                       P->d_counters.p + 8 + cls);
             HIP_TRY(hipGetLastError());
@@ -896,19 +899,16 @@ int run_spike_slab(viprs_state* S, double dq) {
     return VIPRS_OK;
 }
 
-static int sweep_prologue(viprs_plan* P) {
-    const int64_t ng = P->n_granule_rows * kPanel;
+static int sweep_prologue(viprs_plan* P, int n_models = 1) {
+    const int64_t ng = P->n_granule_rows * kPanel * std::max(1, n_models);
+    if (P->d_granules.n < (size_t)ng) {                      // grid launches: one granule set per active model
+        HIP_TRY(hipStreamSynchronize(P->stream));
+        HIP_TRY(P->d_granules.alloc((size_t)ng));
+    }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
     sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, ng);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
-}
-
-template <typename T>
-static void offset_column(EStepArgs<T>& A, const EStepArgs<T>& base, int64_t off) {
-    A = base;
-    A.var_gamma += off; A.var_mu += off; A.eta += off; A.q += off; A.eta_diff += off;
-    A.u_logs += off; A.shvt += off; A.mu_mult += off;
 }
 
 static int launch_panel_u(viprs_plan* P, const EStepArgs<float>& A, int model) {
@@ -927,7 +927,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
                       const int32_t* h_active) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    int rc = sweep_prologue(P);
+    int rc = sweep_prologue(P, model == kGenGrid ? n_active : 1);
     if (rc != VIPRS_OK) return rc;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     HIP_TRY(hipEventRecord(ev[0], P->stream));
@@ -940,12 +940,9 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         if (panel_ok && model == kGenMixture) {
             rc = launch_panel_u(P, A, kPanelMixture);
         } else if (panel_ok && model == kGenGrid) {
-            for (int i = 0; i < n_active && rc == VIPRS_OK; ++i) {
-                EStepArgs<float> Ag;
-                offset_column(Ag, A, (int64_t)h_active[i] * P->m);
-                if (i > 0) rc = sweep_prologue(P);          // fresh queue heads / granules per model
-                if (rc == VIPRS_OK) rc = launch_panel_u(P, Ag, kPanelGridColumn);
-            }
+            // ONE launch over (block, model) work items (select_model offsets the columns in-kernel)
+            A.granules = P->d_granules.p;
+            rc = launch_panel_u(P, A, kPanelGridColumn);
         } else {
             rc = launch_generic_u<float>(P, A, model, true);
         }

@@ -302,7 +302,7 @@ struct MixtureModel {
 };
 
 template <typename U, typename MODEL, bool SYM, int NW, bool TEAM, int CPL>
-__global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A, int qcap) {
+__global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A0, int qcap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lq = smem;
     float* la = smem + qcap;
@@ -312,20 +312,21 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
     ExpTab tab;
     tab.init();
     unsigned long long my_skipped = 0;
-    const float dq = A.dq;
+    const float dq = A0.dq;
+    const int n_models = max(1, A0.n_active);          // grid: work items are (block, model) pairs
 
     // Admission control (optional; thresholds computed by the host).  Blocks are queued in
     // descending size; workgroup r starts pulling work only once the queue head has reached
     // admit[r].  The head only moves forward and workgroup 0 is never gated: no deadlock.
-    if (A.admit != nullptr) {
-        const int th = A.admit[blockIdx.x];
+    if (A0.admit != nullptr) {
+        const int th = A0.admit[blockIdx.x];
         if (th > 0) {
             if (tid == 0) {
-                while (__hip_atomic_load(A.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < th)
+                while (__hip_atomic_load(A0.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < th)
                     __builtin_amdgcn_s_sleep(64);
             }
             __syncthreads();
@@ -340,28 +341,33 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     // agent-scope atomic store / load per lane; the data is the flag, so no fence is needed).
     // Blocks are assigned to teams statically (team t: blocks t, t + n_teams, ...).
     constexpr int kSW = kPanel * CPL;                   // strip width (columns per updater wave)
-    const int TS = TEAM ? A.team_size : 1;
+    const int TS = TEAM ? A0.team_size : 1;
     const int team = TEAM ? (int)blockIdx.x / TS : 0;
     const int member = TEAM ? (int)blockIdx.x % TS : 0;
     int team_iter = 0;
 
     for (;;) {
-        int blk;
+        int item;
         if (TEAM) {
-            blk = team + team_iter * A.n_teams;
+            item = team + team_iter * A0.n_teams;
             ++team_iter;
         } else {
-            if (tid == 0) s_blk = atomicAdd(A.counter, 1);
+            if (tid == 0) s_blk = atomicAdd(A0.counter, 1);
             __syncthreads();
-            blk = s_blk;
+            item = s_blk;
             __syncthreads();
         }
-        if (blk >= A.n_blocks) break;
+        if (item >= A0.n_blocks * n_models) break;
+        // models of one block are adjacent in the queue, so the workgroups that stream the same LD
+        // rows for different models run at about the same time and share them through L2 / MALL
+        const int blk = item / n_models, model_slot = item - blk * n_models;
+        const EStepArgs<float> A = select_model(A0, model_slot);
 
         const BlockDesc bd = A.blocks[blk];
         const int64_t s0 = bd.start;
         const int b = bd.size;
-        unsigned long long* __restrict__ gran = TEAM ? A.granules + bd.gr_off * kPanel : nullptr;
+        unsigned long long* __restrict__ gran =
+            TEAM ? A.granules + ((int64_t)model_slot * A.granule_rows + bd.gr_off) * kPanel : nullptr;
         const int stride = bd.stride;
         const U* __restrict__ base = ldd + bd.ld_off;
         const int np = (b + kPanel - 1) / kPanel;
@@ -539,11 +545,12 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
         }
         __syncthreads();
     }
-    if (lane == 0 && my_skipped && member == 0) atomicAdd(A.skipped, my_skipped);
+    if (lane == 0 && my_skipped && member == 0) atomicAdd(A0.skipped, my_skipped);
 }
 
 // Copies the team kernels' eta / q outputs into place (runs behind the team kernel on its stream).
-__global__ void commit_team_kernel(EStepArgs<float> A) {
+__global__ void commit_team_kernel(EStepArgs<float> A0) {
+    const EStepArgs<float> A = select_model(A0, blockIdx.y);
     const BlockDesc bd = A.blocks[blockIdx.x];
     for (int i = threadIdx.x; i < bd.size; i += blockDim.x) {
         A.eta[bd.start + i] = A.eta_out[bd.start + i];
@@ -561,19 +568,22 @@ __global__ void commit_team_kernel(EStepArgs<float> A) {
 struct EpiItem { int32_t blk; int32_t row0; };
 
 template <typename U, int NW>
-__global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs<float> A, const EpiItem* items,
+__global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs<float> A0, const EpiItem* items,
                                                                        int n_items, int32_t* counter) {
     __shared__ float tile[NW][kPanel * (kPanel + 1)];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
     float* tl = tile[wave];
+    const int n_models = max(1, A0.n_active);
     for (;;) {
-        // persistent waves pull (block, 64-row group) items, longest rows first
+        // persistent waves pull (block, 64-row group[, model]) items, longest rows first
         int item = 0;
         if (lane == 0) item = atomicAdd(counter, 1);
         item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const EpiItem it = items[item];
+        if (item >= n_items * n_models) break;
+        const int ei = item / n_models;
+        const EStepArgs<float> A = select_model(A0, item - ei * n_models);
+        const EpiItem it = items[ei];
         const BlockDesc bd = A.blocks[it.blk];
         const int b = bd.size, stride = bd.stride, r0 = it.row0;
         const int64_t s0 = bd.start;

@@ -29,6 +29,7 @@ struct EStepArgs {
     int32_t* error;              // set to non-zero when a bounded spin gives up
     int32_t n_teams;             // team kernels: number of teams in the launch
     int32_t team_size;           // team kernels: workgroups per team
+    int64_t granule_rows;        // team kernels: granule rows per model (grid: one set per active model)
     unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
     // row addressing for the generic kernels: row j holds rowlen[j] elements starting at element
     // rowstart[j] of ld_rows, covering columns lb[j] .. lb[j] + rowlen[j] - 1.  (Either the caller's
@@ -60,6 +61,18 @@ struct EStepArgs {
     int32_t n_active;
 };
 
-template <typename U> struct LdLoad;   // element -> float/double conversion (static_cast, as e_step.hpp:173)
+// Grid launches run (block, model) work items: the same kernels, with every (m, G) column-major array
+// offset to the model's column.  n_active == 0 means a plain (m,) state (one "model", no offset).
+template <typename T>
+__device__ __forceinline__ EStepArgs<T> select_model(const EStepArgs<T>& A0, int model_slot) {
+    EStepArgs<T> A = A0;
+    if (A0.n_active > 0) {
+        const int64_t off = (int64_t)A0.active[model_slot] * A0.m;
+        A.var_gamma += off; A.var_mu += off; A.eta += off; A.q += off; A.eta_diff += off;
+        A.u_logs += off; A.shvt += off; A.mu_mult += off;
+        if (A.eta_out) { A.eta_out += off; A.q_out += off; }
+    }
+    return A;
+}
 
 }  // namespace viprs
