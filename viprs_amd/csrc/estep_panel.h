@@ -53,6 +53,19 @@ template <> __device__ __forceinline__ RowVec<4> load_cols<float, 4>(const float
     const float4 t = *reinterpret_cast<const float4*>(p);
     return RowVec<4>{{t.x, t.y, t.z, t.w}};
 }
+template <> __device__ __forceinline__ RowVec<8> load_cols<float, 8>(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    const float4 u = *reinterpret_cast<const float4*>(p + 4);
+    return RowVec<8>{{t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w}};
+}
+template <> __device__ __forceinline__ RowVec<8> load_cols<int8_t, 8>(const int8_t* p) {
+    const float4 t = load4<int8_t>(p), u = load4<int8_t>(p + 4);
+    return RowVec<8>{{t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w}};
+}
+template <> __device__ __forceinline__ RowVec<8> load_cols<int16_t, 8>(const int16_t* p) {
+    const float4 t = load4<int16_t>(p), u = load4<int16_t>(p + 4);
+    return RowVec<8>{{t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w}};
+}
 template <> __device__ __forceinline__ RowVec<2> load_cols<float, 2>(const float* p) {
     const float2 t = *reinterpret_cast<const float2*>(p);
     return RowVec<2>{{t.x, t.y}};
