@@ -34,9 +34,11 @@ def test_mixture_matches_oracle(gpu, K, low_memory):
         H.assert_state_equal(got, ref)
 
 
+@pytest.mark.parametrize("mfma", ["0", "1"])          # per-(block, model) panel items / batched matrix-core kernel
 @pytest.mark.parametrize("low_memory", [False, True])
-def test_grid_matches_oracle(gpu, low_memory):
+def test_grid_matches_oracle(gpu, low_memory, mfma, monkeypatch):
     from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", mfma)
     ld, ss, inp = syn.make_problem(sizes=[130, 1300, 64], low_memory=low_memory, seed=33)
     g, st0 = _grid_inputs(ld, ss, 32)
     active = np.array([31, 0, 7, 8, 21], dtype=np.int32)[::1]
@@ -54,3 +56,59 @@ def test_grid_matches_oracle(gpu, low_memory):
         H.assert_state_equal(out["hip"], out["ref"])
     untouched = [c for c in range(32) if c not in active]
     assert np.all(out["hip"]["eta"][:, untouched] == 0)
+
+
+def _run_grid(mod, ld, inp, g, st0, active, sweeps=2):
+    st = {k: v.copy(order="F") for k, v in st0.items()}
+    for _ in range(sweeps):
+        mod.cpp_e_step_grid(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, inp.std_beta, st["var_gamma"], st["var_mu"],
+                            st["eta"], st["q"], st["eta_diff"], g["u_logs"], g["hvt"], g["mu_mult"], ld.dq_scale,
+                            active, 1, ld.low_memory)
+    return st
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+@pytest.mark.parametrize("G, n_active", [(1, 1), (3, 3), (32, 32), (40, 40), (70, 37)])
+def test_grid_mfma_model_counts(gpu, G, n_active, low_memory, monkeypatch):
+    """Batched kernel: fewer than / exactly / more than 32 models (chunks of 32), scattered active lists."""
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    ld, ss, inp = syn.make_problem(sizes=[200, 96, 333], low_memory=low_memory, seed=35)
+    g, st0 = _grid_inputs(ld, ss, G)
+    active = np.random.default_rng(G).permutation(G)[:n_active].astype(np.int32)
+    ref = _run_grid(O, ld, inp, g, st0, active)
+    got = _run_grid(S, ld, inp, g, st0, active)
+    for k in STATE:
+        H.assert_close(got[k], ref[k], 1e-5, k)
+    if not low_memory:
+        H.assert_state_equal(got, ref)
+
+
+@pytest.mark.parametrize("ld_dtype", [np.int8, np.int16])
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_grid_mfma_quantised_ld(gpu, ld_dtype, low_memory, monkeypatch):
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    ld, ss, inp = syn.make_problem(sizes=[150, 520, 77], low_memory=low_memory, ld_dtype=ld_dtype, seed=36)
+    g, st0 = _grid_inputs(ld, ss, 12)
+    active = np.arange(12, dtype=np.int32)
+    ref = _run_grid(O, ld, inp, g, st0, active)
+    got = _run_grid(S, ld, inp, g, st0, active)
+    for k in STATE:
+        H.assert_close(got[k], ref[k], 1e-5, k)
+    if not low_memory:
+        H.assert_state_equal(got, ref)
+
+
+def test_grid_mfma_block_shapes(gpu, monkeypatch):
+    """Panel / tile boundaries of the batched kernel: one SNP, 63/64/65, odd and even numbers of panels,
+    blocks that end inside a 128-column tile."""
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    sizes = [1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 2, 321, 448, 449]
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=False, seed=37)
+    g, st0 = _grid_inputs(ld, ss, 9)
+    active = np.array([8, 0, 3, 4, 1, 7], dtype=np.int32)
+    ref = _run_grid(O, ld, inp, g, st0, active, sweeps=3)
+    got = _run_grid(S, ld, inp, g, st0, active, sweeps=3)
+    H.assert_state_equal(got, ref)

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libviprs_hip.so")
+# VIPRS_HIP_LIB: development override (e.g. an instrumented build); the default is the in-tree library
+LIB_PATH = os.environ.get("VIPRS_HIP_LIB") or os.path.join(_HERE, "lib", "libviprs_hip.so")
 
 # dtype / enum codes (include/viprs_hip.h)
 F32, F64 = 0, 1

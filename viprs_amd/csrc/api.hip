@@ -11,6 +11,7 @@
 
 #include "../../include/viprs_hip.h"
 #include "estep_generic.h"
+#include "estep_grid_mfma.h"
 #include "estep_panel.h"
 #include "planner.h"
 
@@ -203,6 +204,8 @@ struct viprs_plan {
     DevBuf<int32_t> d_admit;                // admission thresholds of the small-block class
     int admit_grid = 0;
     double admit_factor = 1.5;
+    int grid_mfma = -1;                     // batched grid E-step on the matrix cores: 1 always, 0 never (per-(block,
+                                            // model) items), -1 when the plan has enough blocks to fill the CUs (VIPRS_GRID_MFMA)
     int64_t n_epi = 0;
     int epi_begin[4] = {0, 0, 0, 0};        // per size class ranges of d_epi
     DevBuf<int32_t> d_lb;
@@ -327,6 +330,7 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
     if (const char* f = getenv("VIPRS_LARGE_BLOCK")) kLargeBlock = atoi(f);
     if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) kMediumBlock = atoi(f);
+    if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
     if (const char* f = getenv("VIPRS_TEAM0")) kClassTeam[0] = std::max(1, atoi(f));
     if (const char* f = getenv("VIPRS_TEAM1")) kClassTeam[1] = std::max(1, atoi(f));
     P->low_memory = low_memory != 0;
@@ -437,8 +441,11 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     if (!P->dense_h.empty()) {
         HIP_TRY(P->d_dense.alloc(P->dense_h.size()));
         HIP_TRY(hipMemcpy(P->d_dense.p, P->dense_h.data(), sizeof(BlockDesc) * P->dense_h.size(), hipMemcpyHostToDevice));
-        // + one strip of slack so that partial-panel tile loads stay inside the allocation
-        const size_t bytes = ((size_t)P->dense_elems + 4 * kStrip) * es;
+        // + slack so that partial-panel tile loads stay inside the allocation: one strip for the panel
+        // kernels, one panel of rows of the widest block for the batched grid kernel (estep_grid_mfma.h)
+        int max_stride = 0;
+        for (const BlockDesc& d : P->dense_h) max_stride = std::max(max_stride, d.stride);
+        const size_t bytes = ((size_t)P->dense_elems + 4 * kStrip + (size_t)kPanel * max_stride) * es;
         HIP_TRY(P->d_ld_dense.alloc(bytes));
         HIP_TRY(hipMemset(P->d_ld_dense.p, 0, bytes));
         dim3 grid(64, (unsigned)P->dense_h.size());
@@ -920,6 +927,54 @@ static int launch_panel_u(viprs_plan* P, const EStepArgs<float>& A, int model) {
     }
 }
 
+// Batched grid E-step on the matrix cores: every LD row is read once for up to 32 models.
+template <typename U>
+static int launch_grid_mfma(viprs_plan* P, EStepArgs<float> A) {
+    A.blocks = P->d_dense.p;
+    A.n_blocks = (int)P->dense_h.size();
+    A.counter = P->d_counters.p + 12;
+    const size_t shmem = (size_t)kGridLdsFloats * sizeof(float);
+    const void* kfn = P->low_memory ? (const void*)estep_grid_mfma_kernel<U, false> : (const void*)estep_grid_mfma_kernel<U, true>;
+    HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * kGridWaves, shmem));
+    const int grid = std::min<int>(A.n_blocks, P->n_cu * std::max(1, per_cu));
+    void* params[] = {(void*)&A};
+    HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(64 * kGridWaves), params, shmem, P->stream));
+    if (P->low_memory) {
+        // update_q_factor_matrix (e_step.hpp:266-303): the per-model second pass, (block rows, model) items
+        const int n_models = std::max(1, A.n_active);
+        for (int c = 0; c < 3; ++c) {
+            const int eb = P->epi_begin[c], en = P->epi_begin[c + 1] - eb;
+            if (en <= 0) continue;
+            EStepArgs<float> Ac = A;
+            Ac.blocks = P->d_dense.p + P->class_begin[c];
+            const int eg = (int)std::min<int64_t>(((int64_t)en * n_models + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
+            estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, P->stream>>>(Ac, P->d_epi.p + eb, en,
+                                                                                          P->d_counters.p + 8 + c);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return VIPRS_OK;
+}
+
+// One workgroup per LD block: worth it once the blocks can occupy a good part of the chip; with a few
+// blocks the (block, model) work items of the panel kernel spread better.  32-bit element offsets.
+static bool use_grid_mfma(const viprs_plan* P, int width) {
+    if ((int64_t)P->m * std::max(1, width) >= (1LL << 31)) return false;
+    if (P->grid_mfma >= 0) return P->grid_mfma != 0;
+    return (int64_t)P->dense_h.size() * 8 >= (int64_t)P->n_cu * 3;
+}
+
+static int launch_grid_mfma_u(viprs_plan* P, const EStepArgs<float>& A) {
+    switch (P->ld_dtype) {
+        case VIPRS_LD_F32: return launch_grid_mfma<float>(P, A);
+        case VIPRS_LD_I8: return launch_grid_mfma<int8_t>(P, A);
+        case VIPRS_LD_I16: return launch_grid_mfma<int16_t>(P, A);
+        default: return fail(VIPRS_EINVAL, "dense schedule with unsupported LD dtype");
+    }
+}
+
 // mixture / grid.  fp32 state on dense blocks: the panel kernels with the model's policy (the grid
 // runs its independent models one after the other, each on its own column of the (m, G) arrays);
 // everything else (ragged blocks, fp64 state, K > kPanelMaxK): the generic kernels.
@@ -939,6 +994,15 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         const bool panel_ok = !P->dense_h.empty() && (model == kGenGrid || S->width <= kPanelMaxK);
         if (panel_ok && model == kGenMixture) {
             rc = launch_panel_u(P, A, kPanelMixture);
+        } else if (panel_ok && model == kGenGrid && use_grid_mfma(P, A.width)) {
+            // matrix-core path: chunks of 32 models, each LD row read once per chunk
+            for (int off = 0; off < n_active && rc == VIPRS_OK; off += kGridModels) {
+                EStepArgs<float> Ac = A;
+                Ac.active = d_active + off;
+                Ac.n_active = std::min(kGridModels, n_active - off);
+                if (off > 0) rc = sweep_prologue(P, 1);
+                if (rc == VIPRS_OK) rc = launch_grid_mfma_u(P, Ac);
+            }
         } else if (panel_ok && model == kGenGrid) {
             // ONE launch over (block, model) work items (select_model offsets the columns in-kernel)
             A.granules = P->d_granules.p;

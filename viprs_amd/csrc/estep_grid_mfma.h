@@ -1,0 +1,534 @@
+// Batched grid E-step (e_step_grid, e_step.hpp:555-647) for up to 32 models at once: every LD row
+// is read ONCE and applied to all models.
+//
+// For one SNP j the reference loops over the active models g and runs, per model, the scalar
+// update (:613-620) followed by the axpy q[g, win(j)] = fma(R[j, .], dq * d_g, q[g, win(j)]) (:623).
+// Models never interact, so the sweep can be re-ordered "all models per SNP" without changing any
+// model's arithmetic.  Re-blocked into panels of 64 SNPs as in estep_panel.h:
+//
+//   wave 0 ("chain")   lane = (column half h, model g): the lane carries the 32 q values of model g for
+//                      columns 32 h .. 32 h + 31 of the current panel in VGPRs.  Per SNP both halves
+//                      evaluate the grid update of their model (inputs staged in LDS; the SNP's own q
+//                      comes from the owning half through v_permlane32_swap) and apply row j of the
+//                      diagonal tile -- staged in LDS as fp32, read as broadcast ds_read_b128 -- to
+//                      their 32 columns.
+//   waves 1..7         the trailing rank-64 update of every other 64-column tile as a GEMM on the
+//                      matrix cores:  Q[32 models x 32 cols] += A[32 models x 64 rows] . R[64 rows x 32 cols]
+//                      with v_mfma_f32_32x32x2_f32, 32 MFMAs per 32-column tile.  On gfx950 that
+//                      instruction is bit-for-bit a k-ordered chain of fp32 fma (one rounding per
+//                      product, no wider accumulator), i.e. exactly the reference's sequence
+//                      q = fma(R[j][c], a_j, q) for j ascending -- so the batched kernel stays
+//                      bit-identical to e_step_grid in symmetric form (tools/mfma_check.py measures
+//                      that property on the device; tests/test_gpu_models.py holds the parity).
+//                      Rows are loaded once per 64-column tile (256 B per row) and split into the two
+//                      32-column B operands with one v_permlane32_swap per row pair.  They also stage
+//                      the next panel's inputs / diagonal tile and flush the previous panel's outputs.
+//
+// q of the block stays in global memory (the (m, G) state itself, L2-resident for the workgroup):
+// per phase the MFMA tiles read and write 128 B per column and model, the same order of traffic
+// as the LD rows.  One workgroup per LD block, blocks pulled from a queue in descending size.
+#pragma once
+#include "device_math.h"
+#include "estep_panel.h"
+#include "kernels_common.h"
+
+namespace viprs {
+
+#ifdef VIPRS_GRID_PROFILE
+#define GPROF(slot, cond) do { if (blk == 0 && lane == 0 && p < 32 && (cond)) s_prof[p][slot] = (unsigned)wall_clock64(); } while (0)
+#else
+#define GPROF(slot, cond) do { } while (0)
+#endif
+
+constexpr int kGridModels = 32;                    // models per launch (one 32-row MFMA tile)
+constexpr int kGridIoPitch = kPanel + 1;           // LDS pitch of the per-panel input/output staging
+// LDS carve (floats): io[2][4][32][65] | a[2][64][32] | diag[2][64][64] | carry[96][64] | qx[2][32][68]
+constexpr int kGridIoArr = kGridModels * kGridIoPitch;
+constexpr int kGridIoFloats = 4 * kGridIoArr;
+constexpr int kGridAFloats = kPanel * kGridModels;
+constexpr int kGridDiagFloats = kPanel * kPanel;
+constexpr int kGridCarryFloats = (kPanel + 32) * 64;   // wave 1's tile (64 LD rows + 32 accumulators per lane) across a barrier
+constexpr int kGridQxPitch = kPanel + 4;                  // 16-byte aligned rows, conflict-free 128-bit reads
+constexpr int kGridQxFloats = kGridModels * kGridQxPitch;
+constexpr int kGridLdsFloats = 2 * kGridIoFloats + 2 * kGridAFloats + 2 * kGridDiagFloats + kGridCarryFloats + 2 * kGridQxFloats;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---- one 64-column tile on the matrix cores, split so that loads can run ahead of the MFMAs --------
+// Q[model][c0 .. c0+63] += sum_k a[model][k] * R[row0 + k][c0 ..] for the 64 rows of a panel, k
+// ascending, for all 32 models.
+
+// this lane's column of the 64 rows of panel `rp` x 64-column tile `ct` (256 B per row and wave)
+template <typename U>
+__device__ __forceinline__ void tile_load_rows(float (&R)[kPanel], const U* __restrict__ base, int stride, int b,
+                                               int rp, int ct, int lane) {
+    const int row0 = rp * kPanel;
+    const int last_row = min(kPanel, b - row0) - 1;
+    const U* __restrict__ p = base + (int64_t)row0 * stride + ct * kPanel + lane;     // ct*64 + lane < stride
+#pragma unroll
+    for (int k = 0; k < kPanel; ++k) R[k] = static_cast<float>(p[(int64_t)min(k, last_row) * stride]);
+    asm volatile("" ::: "memory");      // all 64 loads go out here (hipcc would sink each one to its MFMA)
+}
+
+// accumulators: C[model][col], col = lane & 31 (+32 for acc1), model = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ void tile_load_acc(f32x16& acc0, f32x16& acc1, const EStepArgs<float>& A, const int* act, int64_t s0, int b,
+                                              int ct, int n_models, int lane) {
+    const int half = lane >> 5, c = ct * kPanel + (lane & 31);
+    const bool ok0 = c < b, ok1 = c + 32 < b;
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const unsigned col_off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0;      // m * G < 2^31 (host-checked)
+        v0[r] = A.q[col_off + (ok0 ? c : 0)];
+        v1[r] = A.q[col_off + (ok1 ? c + 32 : 0)];
+    }
+    asm volatile("" ::: "memory");      // issue all 32 loads before the first use
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool okg = g < n_models;
+        acc0[r] = (okg && ok0) ? v0[r] : 0.0f;
+        acc1[r] = (okg && ok1) ? v1[r] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void tile_store_acc(const f32x16& acc0, const f32x16& acc1, const EStepArgs<float>& A,
+                                               const int* act, int64_t s0, int b, int ct, int n_models, int lane) {
+    const int half = lane >> 5, c = ct * kPanel + (lane & 31);
+    const bool ok0 = c < b, ok1 = c + 32 < b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (g < n_models) {
+            const unsigned col_off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0;
+            if (ok0) A.q[col_off + c] = acc0[r];
+            if (ok1) A.q[col_off + c + 32] = acc1[r];
+        }
+    }
+}
+
+// 64 MFMAs: rows (kr, kr + 1) of the panel per pair, k ascending
+__device__ __forceinline__ void tile_compute(f32x16& acc0, f32x16& acc1, const float (&R)[kPanel],
+                                             const float* __restrict__ a_lds, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kr = 0; kr < kPanel; kr += 2) {
+        // [row kr : cols 0..31 | row kr+1 : cols 0..31]  and  [row kr : cols 32..63 | row kr+1 : cols 32..63]
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(R[kr]), __float_as_uint(R[kr + 1]), false, false);
+        const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);
+        const float aop = a_lds[(kr + half) * kGridModels + l31];    // A[model = lane & 31][k = lane >> 5]
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b1, acc1, 0, 0, 0);
+    }
+}
+
+// ---- the same update on a 128-column tile: every lane fetches 4 consecutive columns (16 B for fp32) ----
+// lane = (k slot = lane >> 5, n = lane & 31) loads columns c0 + 4n .. 4n+3 of row 2i + (lane >> 5): one
+// load instruction covers 2 rows x 128 columns, which is directly the B operand of FOUR MFMAs (column
+// 4n + j for j = 0..3) -- no cross-lane shuffle, 32 row loads + 16 accumulator loads in flight per tile
+// (the memory pipeline takes at most 63 per wave, which throttles the 64-column version).
+template <typename U> struct Vec4 { typedef U type __attribute__((ext_vector_type(4))); };
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // q columns start at arbitrary offsets
+
+template <typename U>
+__device__ __forceinline__ void wtile_load_rows(f32x4 (&R)[kPanel / 2], const U* __restrict__ base, int stride, int rp,
+                                                int c0, int lane) {
+    using V = typename Vec4<U>::type;
+    // uniform base + one 32-bit lane offset: the row step is scalar arithmetic (no per-row VGPR address).
+    // Rows past the end of the block (last, partial panel) are read as they lie in memory -- the next
+    // block's rows or the zeroed slack behind the last block -- and meet a = 0 (the plan allocates the slack).
+    int col = c0 + 4 * (lane & 31);
+    if (col >= stride) col = c0;                      // right half of the last (odd) tile: masked by the caller
+    const unsigned voff = (unsigned)(((lane >> 5) * stride + (col - c0)) * (int)sizeof(U));
+    const char* __restrict__ sb = reinterpret_cast<const char*>(base + (int64_t)rp * kPanel * stride + c0);
+    const size_t step = (size_t)2 * stride * sizeof(U);
+#pragma unroll
+    for (int i = 0; i < kPanel / 2; ++i) {
+        const V v = *reinterpret_cast<const V*>(sb + i * step + voff);
+        R[i] = f32x4{static_cast<float>(v[0]), static_cast<float>(v[1]), static_cast<float>(v[2]), static_cast<float>(v[3])};
+    }
+    asm volatile("" ::: "memory");
+}
+
+// accumulators acc[j][r]: model (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c0 + 4 (lane & 31) + j.
+// FULL: the tile lies inside the block (vector access); otherwise element-wise with column masks.
+template <bool FULL>
+__device__ __forceinline__ void wtile_load_acc(f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act, int64_t s0,
+                                               int b, int c0, bool lane_ok, int n_models, int lane) {
+    const int half = lane >> 5, c = c0 + 4 * (lane & 31);
+    // raw loads straight into the accumulator registers, masks applied once everything is in flight
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const unsigned off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0;
+        if (FULL) {
+            const f32x4u v = *reinterpret_cast<const f32x4u*>(A.q + off + (lane_ok ? c : 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][r] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][r] = A.q[off + ((lane_ok && c + j < b) ? c + j : 0)];
+        }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = lane_ok && g < n_models;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][r] = (ok && (FULL || c + j < b)) ? acc[j][r] : 0.0f;
+    }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void wtile_store_acc(const f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act,
+                                                int64_t s0, int b, int c0, bool lane_ok, int n_models, int lane) {
+    const int half = lane >> 5, c = c0 + 4 * (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (lane_ok && g < n_models) {
+            const unsigned off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0 + c;
+            if (FULL) {
+                *reinterpret_cast<f32x4u*>(A.q + off) = f32x4u{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < b) A.q[off + j] = acc[j][r];
+            }
+        }
+    }
+}
+
+// 128 MFMAs: rows (2i, 2i + 1) per step, k ascending
+__device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
+                                              const float* __restrict__ a_lds, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < kPanel / 2; ++i) {
+        const float aop = a_lds[(2 * i + half) * kGridModels + l31];  // A[model = lane & 31][k = lane >> 5]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][j], acc[j], 0, 0, 0);
+    }
+}
+
+constexpr int kGridWaves = 8;                      // 1 chain wave + 7 updater waves
+constexpr int kGridNU = kGridWaves - 1;
+constexpr int kGridPerWave = (kGridModels + kGridNU - 1) / kGridNU;     // model rows a wave stages / flushes
+constexpr int kGridDiagPerWave = (kPanel + kGridNU - 1) / kGridNU;      // diagonal-tile rows a wave stages
+
+template <typename U, bool SYM>
+__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* io = smem;                                   // [2][4][32][65]: mm, ulog, hvt, eta -> mu, gamma, d, eta'
+    float* la = smem + 2 * kGridIoFloats;               // [2][64][32] scaled eta_diff of a panel
+    float* dg = la + 2 * kGridAFloats;                  // [2][64][64] diagonal tile of a panel, fp32
+    f32x4* cy = reinterpret_cast<f32x4*>(dg + 2 * kGridDiagFloats);   // [24][64] x 16 B: wave 1's carried tile
+    float* qx = dg + 2 * kGridDiagFloats + kGridCarryFloats;          // [2][32][68] q of a panel: to / from the chain
+    __shared__ int s_blk;
+    __shared__ int s_act[kGridModels];                  // column of the (m, G) arrays for each model slot
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    constexpr int NU = kGridNU;
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const int n_models = A.n_active;
+    const float dq = A.dq;
+    ExpTab tab;
+    tab.init();
+    // chain-wave roles
+    const int cg = lane & 31, ch = lane >> 5;
+    const bool has_model = cg < n_models;
+    if (tid < kGridModels) s_act[tid] = A.active[min(tid, n_models - 1)];
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) s_blk = atomicAdd(A.counter, 1);
+        __syncthreads();
+        const int blk = s_blk;
+        __syncthreads();
+        if (blk >= A.n_blocks) break;
+        const BlockDesc bd = A.blocks[blk];
+        const int64_t s0 = bd.start;
+        const int b = bd.size, stride = bd.stride;
+        const U* __restrict__ base = ldd + bd.ld_off;
+        const int np = (b + kPanel - 1) / kPanel;
+
+        // waves 1..7: stage the inputs of panel `pp` into io[pp & 1] (4 arrays x n_models rows of 64
+        // floats) and its diagonal tile, converted to fp32, into dg[pp & 1]; all loads first, then LDS
+        auto stage_inputs = [&](int pp, bool with_q) {
+            float* dst = io + (pp & 1) * kGridIoFloats;
+            const int r0 = pp * kPanel;
+            const int j = r0 + lane;
+            const bool ok = j < b;
+            const unsigned jo = (unsigned)s0 + (ok ? j : 0);
+            float v[kGridPerWave][5];
+#pragma unroll
+            for (int i = 0; i < kGridPerWave; ++i) {
+                const int g = min(wave - 1 + NU * i, kGridModels - 1);
+                const unsigned off = (unsigned)s_act[g] * (unsigned)A.m + jo;
+                v[i][0] = A.mu_mult[off]; v[i][1] = A.u_logs[off]; v[i][2] = A.shvt[off]; v[i][3] = A.eta[off];
+                v[i][4] = with_q ? A.q[off] : 0.0f;
+            }
+            const int nrows = min(kPanel, b - r0);
+            const U* __restrict__ dp = base + (int64_t)r0 * stride + r0 + lane;
+            float dv[kGridDiagPerWave];
+#pragma unroll
+            for (int i = 0; i < kGridDiagPerWave; ++i)
+                dv[i] = static_cast<float>(dp[(int64_t)min(wave - 1 + NU * i, nrows - 1) * stride]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < kGridPerWave; ++i) {
+                const int g = wave - 1 + NU * i;
+                if (g < n_models) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) dst[a * kGridIoArr + g * kGridIoPitch + lane] = ok ? v[i][a] : 0.0f;
+                    if (with_q) qx[(pp & 1) * kGridQxFloats + g * kGridQxPitch + lane] = ok ? v[i][4] : 0.0f;
+                }
+            }
+            float* dd = dg + (pp & 1) * kGridDiagFloats;
+#pragma unroll
+            for (int i = 0; i < kGridDiagPerWave; ++i) {
+                const int t = wave - 1 + NU * i;
+                if (t < kPanel) dd[t * kPanel + lane] = dv[i];
+            }
+        };
+        // write the outputs and the final q of panel `pp` (left in io / qx[pp & 1] by the chain) to the state
+        auto flush_outputs = [&](int pp) {
+            const float* src = io + (pp & 1) * kGridIoFloats;
+            const float* qs = qx + (pp & 1) * kGridQxFloats;
+            const int j = pp * kPanel + lane;
+            if (j < b) {
+#pragma unroll
+                for (int i = 0; i < kGridPerWave; ++i) {
+                    const int g = wave - 1 + NU * i;
+                    if (g < n_models) {
+                        const unsigned off = (unsigned)s_act[g] * (unsigned)A.m + (unsigned)(s0 + j);
+                        A.var_mu[off] = src[0 * kGridIoArr + g * kGridIoPitch + lane];
+                        A.var_gamma[off] = src[1 * kGridIoArr + g * kGridIoPitch + lane];
+                        A.eta_diff[off] = src[2 * kGridIoArr + g * kGridIoPitch + lane];
+                        A.eta[off] = src[3 * kGridIoArr + g * kGridIoPitch + lane];
+                        A.q[off] = qs[g * kGridQxPitch + lane];
+                    }
+                }
+            }
+        };
+
+        if (wave > 0) stage_inputs(0, true);
+        __syncthreads();
+
+#ifdef VIPRS_GRID_PROFILE
+        __shared__ unsigned s_prof[32][12];
+#endif
+        for (int p = 0; p <= np; ++p) {
+            GPROF(0, wave == 0);
+            // ---- (1) wave 1 finishes tile p with a_{p-1}: its accumulators already hold q (updated through
+            //      a_{p-2}) and the LD rows came through LDS from the previous phase -- only 64 MFMAs sit
+            //      between the chain's two panels; the result goes to the chain through LDS
+            if (p > 0 && p < np && wave == 1) {
+                float R1[kPanel];
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x4 v = cy[i * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) R1[4 * i + e] = v[e];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = cy[(16 + i) * 64 + lane], w = cy[(20 + i) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc0[4 * i + e] = v[e]; acc1[4 * i + e] = w[e]; }
+                }
+                tile_compute(acc0, acc1, R1, la + ((p - 1) & 1) * kGridAFloats, lane);
+                float* qd = qx + (p & 1) * kGridQxFloats + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    qd[g * kGridQxPitch] = acc0[r];
+                    qd[g * kGridQxPitch + 32] = acc1[r];
+                }
+            }
+            __syncthreads();
+            GPROF(1, wave == 0);
+            if (wave == 0) {
+                // ---- (2) chain: 64 serial SNP updates for all models
+                if (p < np) {
+                    const int r0 = p * kPanel;
+                    const int nrows = min(kPanel, b - r0);
+                    float* iob = io + (p & 1) * kGridIoFloats + cg * kGridIoPitch;
+                    float* lap = la + (p & 1) * kGridAFloats + cg;
+                    const float* drow = dg + (p & 1) * kGridDiagFloats + 32 * ch;
+                    float* qmine = qx + (p & 1) * kGridQxFloats + cg * kGridQxPitch + 32 * ch;
+                    // this lane's 32 columns of its model's q
+                    float qv[32];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(qmine + 4 * i);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qv[4 * i + e] = has_model ? v[e] : 0.0f;
+                    }
+                    const float betav = A.std_beta[s0 + min(r0 + lane, b - 1)];
+#ifdef VIPRS_GRID_PROFILE
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                    GPROF(2, true);
+                    // row jj of the diagonal tile for this half: register c <-> column 32 h + ((c + 16 g4) & 31)
+                    float rw[32];
+                    auto load_row = [&](float (&dst)[32], int jr, int g4) {
+                        const float* rp = drow + jr * kPanel;
+                        const int o0 = 16 * (g4 & 1), o1 = 16 * ((g4 + 1) & 1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 x = *reinterpret_cast<const f32x4*>(rp + o0 + 4 * i);
+                            const f32x4 y = *reinterpret_cast<const f32x4*>(rp + o1 + 4 * i);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                dst[4 * i + e] = x[e];
+                                dst[16 + 4 * i + e] = y[e];
+                            }
+                        }
+                    };
+                    load_row(rw, 0, 0);
+                    float mm = iob[0 * kGridIoArr], ulog = iob[1 * kGridIoArr], hvt = iob[2 * kGridIoArr],
+                          eta_old = iob[3 * kGridIoArr];
+#pragma unroll 1
+                    for (int g4 = 0; g4 < kPanel / 16; ++g4) {
+                        const bool hi_owner = g4 >= 2;                                   // columns 32.. belong to half 1
+                        const bool owner = (ch == 1) == hi_owner;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const int jj = 16 * g4 + k;                                  // wave-uniform
+                            const bool live = jj < nrows;
+                            // next SNP's inputs: in flight while this one is evaluated
+                            const int jn = min(jj + 1, kPanel - 1);
+                            const float mm_n = iob[0 * kGridIoArr + jn], ulog_n = iob[1 * kGridIoArr + jn],
+                                        hvt_n = iob[2 * kGridIoArr + jn], eta_n = iob[3 * kGridIoArr + jn];
+                            // the SNP's own q from the half that owns its column
+                            const unsigned qbits = __float_as_uint(qv[k]);
+                            auto sw = __builtin_amdgcn_permlane32_swap(qbits, qbits, false, false);
+                            const float qcur = __uint_as_float(hi_owner ? sw[1] : sw[0]);
+                            const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
+                            const float mu = mm * (beta - qcur);                         // e_step.hpp:613
+                            const float u = ulog + hvt * mu * mu;                        // :616
+                            const float gamma = sigmoid_exact<kLookupPerLane>(u, tab);   // :617
+                            const float d = gamma * mu - eta_old;                        // :620
+                            const float a = (live && has_model) ? dq * d : 0.0f;
+                            // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order)
+                            __builtin_amdgcn_sched_barrier(0);
+                            float rn[32];
+                            load_row(rn, jn, (jj + 1) >> 4);
+#pragma unroll
+                            for (int c = 0; c < 32; ++c) {                               // :623
+                                qv[c] = __builtin_fmaf(rw[c], a, qv[c]);
+                                asm volatile("" : "+v"(qv[c]));      // apply now (hipcc would sink the chain to its use)
+                            }
+                            if (SYM) qv[k] -= (live && owner && has_model) ? d : 0.0f;   // :629
+                            if (has_model && live && ch == 0) {
+                                iob[0 * kGridIoArr + jj] = mu;
+                                iob[1 * kGridIoArr + jj] = gamma;
+                                iob[2 * kGridIoArr + jj] = d;
+                                iob[3 * kGridIoArr + jj] = eta_old + d;                   // :633
+                            }
+                            if (ch == 0) lap[jj * kGridModels] = a;
+                            mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n;
+#pragma unroll
+                            for (int c = 0; c < 32; ++c) rw[c] = rn[c];
+                            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch distance at one SNP
+                        }
+                        // rotate the q registers by one group of 16 columns
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            const float t = qv[c];
+                            qv[c] = qv[16 + c];
+                            qv[16 + c] = t;
+                        }
+                    }
+                    GPROF(3, true);
+                    if (has_model) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            *reinterpret_cast<f32x4*>(qmine + 4 * i) = f32x4{qv[4 * i], qv[4 * i + 1], qv[4 * i + 2], qv[4 * i + 3]};
+                    }
+                }
+            } else {
+                // ---- (3) waves 1..7, concurrently with the chain: outputs of panel p-1 out of io[(p-1)&1],
+                //      inputs of panel p+1 into the same buffer (each wave flushes and refills its own
+                //      rows, so only its own LDS order matters), then the other 64-column tiles of a_{p-1}
+                if (p > 0) flush_outputs(p - 1);
+                GPROF(5, wave == 1);
+                if (p + 1 < np) stage_inputs(p + 1, false);
+#ifdef VIPRS_GRID_PROFILE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+                GPROF(6, wave == 1);
+                if (p > 0) {
+                    // a_{p-1} on every 64-column tile except p-1 (the chain did it), p (done above) and
+                    // p+1 (wave 1, below); upper-triangular form: only tiles right of p
+                    const int pp = p - 1;
+                    const float* a_lds = la + (pp & 1) * kGridAFloats;
+                    const int n_wide = (np + 1) / 2;                         // 128-column tiles of the block
+                    for (int T = (SYM ? 0 : (p + 2) / 2) + wave - 1; T < n_wide; T += NU) {
+                        auto active64 = [&](int ct) { return ct < np && ct != pp && ct != p && ct != p + 1 && (SYM || ct > p + 1); };
+                        const bool a0 = active64(2 * T), a1 = active64(2 * T + 1);
+                        if (!a0 && !a1) continue;
+                        const bool lane_ok = (lane & 16) ? a1 : a0;          // lanes n < 16: left 64 columns
+                        const int c0 = T * 2 * kPanel;
+                        f32x4 R[kPanel / 2];
+                        f32x16 acc[4];
+                        wtile_load_rows<U>(R, base, stride, pp, c0, lane);
+                        if (c0 + 2 * kPanel <= b) {
+                            wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+                            wtile_compute(acc, R, a_lds, lane);
+                            wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+                        } else {
+                            wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+                            wtile_compute(acc, R, a_lds, lane);
+                            wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+                        }
+                    }
+                }
+                GPROF(11, wave == 1);
+                if (wave == 1 && p + 1 < np) {
+                    // tile p+1 stays with this wave across the barrier (see (1))
+                    float R0[kPanel], R1[kPanel];
+                    f32x16 acc0, acc1;
+                    tile_load_acc(acc0, acc1, A, s_act, s0, b, p + 1, n_models, lane);
+                    if (p > 0) {
+                        tile_load_rows<U>(R0, base, stride, b, p - 1, p + 1, lane);
+                        tile_load_rows<U>(R1, base, stride, b, p, p + 1, lane);
+                        tile_compute(acc0, acc1, R0, la + ((p - 1) & 1) * kGridAFloats, lane);
+                    } else {
+                        tile_load_rows<U>(R1, base, stride, b, p, p + 1, lane);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) cy[i * 64 + lane] = f32x4{R1[4 * i], R1[4 * i + 1], R1[4 * i + 2], R1[4 * i + 3]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        cy[(16 + i) * 64 + lane] = f32x4{acc0[4 * i], acc0[4 * i + 1], acc0[4 * i + 2], acc0[4 * i + 3]};
+                        cy[(20 + i) * 64 + lane] = f32x4{acc1[4 * i], acc1[4 * i + 1], acc1[4 * i + 2], acc1[4 * i + 3]};
+                    }
+                }
+            }
+            GPROF(4, wave == 0); GPROF(7, wave == 1);
+            __syncthreads();
+        }
+#ifdef VIPRS_GRID_PROFILE
+        __syncthreads();
+        if (blk == 0 && tid == 0) {
+            for (int p = 0; p <= np && p < 32; ++p) {
+                const unsigned t = s_prof[p][1];
+                printf("phase %2d: carry %4lld | chain: qread %4lld loop %5lld end %5lld | w1: flush %5lld stage %5lld tiles %5lld end %5lld | tile0: issued %5lld arrived %5lld computed %5lld (x10ns)\n",
+                       p, (long long)(int)(t - s_prof[p][0]), (long long)(int)(s_prof[p][2] - t), (long long)(int)(s_prof[p][3] - t), (long long)(int)(s_prof[p][4] - t),
+                       (long long)(int)(s_prof[p][5] - t), (long long)(int)(s_prof[p][6] - t), (long long)(int)(s_prof[p][11] - t), (long long)(int)(s_prof[p][7] - t),
+                       (long long)(int)(s_prof[p][8] - t), (long long)(int)(s_prof[p][9] - t), (long long)(int)(s_prof[p][10] - t));
+            }
+        }
+        __syncthreads();
+#endif
+    }
+}
+
+}  // namespace viprs
