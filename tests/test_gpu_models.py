@@ -112,3 +112,17 @@ def test_grid_mfma_block_shapes(gpu, monkeypatch):
     ref = _run_grid(O, ld, inp, g, st0, active, sweeps=3)
     got = _run_grid(S, ld, inp, g, st0, active, sweeps=3)
     H.assert_state_equal(got, ref)
+
+
+@pytest.mark.parametrize("ld_dtype", [np.float32, np.int8])
+def test_grid_upper_batched_equals_item_path(gpu, ld_dtype, monkeypatch):
+    """Upper-triangular form: the batched kernels (matrix-core sweep + matrix-core second pass) and the
+    per-(block, model) panel items run the same fma chains -- their states must agree bit for bit."""
+    from viprs_amd.vi import e_step_hip as S
+    res = {}
+    for mfma in ("0", "1"):
+        monkeypatch.setenv("VIPRS_GRID_MFMA", mfma)
+        ld, ss, inp = syn.make_problem(sizes=[257, 700, 31, 129], low_memory=True, ld_dtype=ld_dtype, seed=38)
+        g, st0 = _grid_inputs(ld, ss, 11)
+        res[mfma] = _run_grid(S, ld, inp, g, st0, np.arange(11, dtype=np.int32), sweeps=3)
+    H.assert_state_equal(res["1"], res["0"])

@@ -942,16 +942,18 @@ static int launch_grid_mfma(viprs_plan* P, EStepArgs<float> A) {
     void* params[] = {(void*)&A};
     HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(64 * kGridWaves), params, shmem, P->stream));
     if (P->low_memory) {
-        // update_q_factor_matrix (e_step.hpp:266-303): the per-model second pass, (block rows, model) items
-        const int n_models = std::max(1, A.n_active);
+        // update_q_factor_matrix (e_step.hpp:266-303) for all models of the chunk: (block, 64-row group) items
+        const size_t eshmem = (size_t)kGridEpiWaves * kGridEpiWaveFloats * sizeof(float);
+        const void* efn = (const void*)estep_grid_upper_epilogue_kernel<U>;
+        HIP_TRY(hipFuncSetAttribute(efn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eshmem));
         for (int c = 0; c < 3; ++c) {
             const int eb = P->epi_begin[c], en = P->epi_begin[c + 1] - eb;
             if (en <= 0) continue;
             EStepArgs<float> Ac = A;
             Ac.blocks = P->d_dense.p + P->class_begin[c];
-            const int eg = (int)std::min<int64_t>(((int64_t)en * n_models + kEpiWaves - 1) / kEpiWaves, (int64_t)P->n_cu * 2);
-            estep_upper_epilogue_kernel<U, kEpiWaves><<<eg, kEpiWaves * 64, 0, P->stream>>>(Ac, P->d_epi.p + eb, en,
-                                                                                          P->d_counters.p + 8 + c);
+            const int eg = (int)std::min<int64_t>(((int64_t)en + kGridEpiWaves - 1) / kGridEpiWaves, (int64_t)P->n_cu);
+            estep_grid_upper_epilogue_kernel<U><<<eg, 64 * kGridEpiWaves, eshmem, P->stream>>>(Ac, P->d_epi.p + eb, en,
+                                                                                             P->d_counters.p + 8 + c);
             HIP_TRY(hipGetLastError());
         }
     }

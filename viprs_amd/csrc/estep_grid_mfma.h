@@ -531,4 +531,99 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Upper-triangular second pass for all models at once (update_q_factor_matrix, e_step.hpp:266-303):
+//     q[g, j] += dq * dot(eta_diff[g, j+1 .. end), R[j, j+1 .. end))        for every active model g
+// as C[model][row] = sum_k E[model][k] * R[row][k] on the matrix cores -- per (model, row) the same
+// serial fma chain from 0 in column order as estep_upper_epilogue_kernel (the zero lower-left part of
+// the repacked block is exactly neutral), with every LD tile read once for all models.  One wave owns
+// 64 rows of a block: LD tiles are loaded row-wise (16 B per lane) and transposed through LDS so that
+// lane n supplies row n as the B operand; the eta_diff tile goes through LDS as [k][model].
+// ---------------------------------------------------------------------------------------------
+constexpr int kGridEpiTPitch = kPanel + 1, kGridEpiEPitch = kGridModels + 1;
+constexpr int kGridEpiWaveFloats = kPanel * kGridEpiTPitch + kPanel * kGridEpiEPitch;
+constexpr int kGridEpiWaves = 4;
+
+template <typename U>
+__global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_kernel(EStepArgs<float> A,
+                                                                                       const EpiItem* items, int n_items,
+                                                                                       int32_t* counter) {
+    using V = typename Vec4<U>::type;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_act[kGridModels];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* tl = smem + wave * kGridEpiWaveFloats;       // [64 rows][65]  LD tile, row-major
+    float* el = tl + kPanel * kGridEpiTPitch;           // [64 k][33]     eta_diff tile, [k][model]
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const int n_models = A.n_active;
+    if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
+    __syncthreads();
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lrow = lane >> 4, lcol = (lane & 15) * 4;  // tile loads: 4 rows x 64 columns per instruction
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const EpiItem it = items[item];
+        const BlockDesc bd = A.blocks[it.blk];
+        const int b = bd.size, stride = bd.stride, r0 = it.row0;
+        const int64_t s0 = bd.start;
+        const int nrows = min(kPanel, b - r0);
+        const U* __restrict__ base = ldd + bd.ld_off + (int64_t)r0 * stride + lcol;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+
+        V cur[16], nxt[16];
+        float ecur[kGridModels], enxt[kGridModels];
+        auto load_tile = [&](V (&t)[16], float (&e)[kGridModels], int c0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                t[i] = *reinterpret_cast<const V*>(base + (int64_t)min(4 * i + lrow, nrows - 1) * stride + c0);
+            const int col = c0 + lane;
+            const unsigned off = (unsigned)s0 + (unsigned)min(col, b - 1);
+#pragma unroll
+            for (int g = 0; g < kGridModels; ++g) e[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
+            asm volatile("" ::: "memory");
+        };
+        load_tile(cur, ecur, r0);
+        for (int c0 = r0; c0 < b; c0 += kPanel) {
+            const int cn = (c0 + kPanel < b) ? c0 + kPanel : c0;            // next tile (or this one again)
+            load_tile(nxt, enxt, cn);
+            const bool colok = c0 + lane < b;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tl[(4 * i + lrow) * kGridEpiTPitch + lcol + e] = static_cast<float>(cur[i][e]);
+#pragma unroll
+            for (int g = 0; g < kGridModels; ++g) el[lane * kGridEpiEPitch + g] = (colok && g < n_models) ? ecur[g] : 0.0f;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < kPanel; kk += 2) {
+                const float aop = el[(kk + half) * kGridEpiEPitch + l31];
+                const float b0 = tl[l31 * kGridEpiTPitch + kk + half];
+                const float b1 = tl[(32 + l31) * kGridEpiTPitch + kk + half];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b1, acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+#pragma unroll
+            for (int g = 0; g < kGridModels; ++g) ecur[g] = enxt[g];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (g < n_models) {
+                float* qc = A.q + (unsigned)s_act[g] * (unsigned)A.m + (unsigned)s0 + r0;
+                if (l31 < nrows) qc[l31] += A.dq * acc0[r];
+                if (32 + l31 < nrows) qc[32 + l31] += A.dq * acc1[r];
+            }
+        }
+    }
+}
+
 }  // namespace viprs
