@@ -208,6 +208,7 @@ struct viprs_plan {
                                             // model) items), -1 when the plan has enough blocks to fill the CUs (VIPRS_GRID_MFMA)
     int64_t n_epi = 0;
     int epi_begin[4] = {0, 0, 0, 0};        // per size class ranges of d_epi
+    DevBuf<EpiItem> d_epi_all;              // all items, plan-wide block indices, longest first
     DevBuf<int32_t> d_lb;
     DevBuf<int64_t> d_ip;
     DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
@@ -481,6 +482,17 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
             }
             P->epi_begin[3] = (int)items.size();
             P->n_epi = (int64_t)items.size();
+            // the same items once more with plan-wide block indices, longest first across all classes
+            // (one launch of the batched grid second pass)
+            std::vector<EpiItem> all;
+            for (int c = 0; c < 3; ++c)
+                for (int k = P->epi_begin[c]; k < P->epi_begin[c + 1]; ++k)
+                    all.push_back({(int32_t)(items[(size_t)k].blk + P->class_begin[c]), items[(size_t)k].row0});
+            std::stable_sort(all.begin(), all.end(), [&](const EpiItem& x, const EpiItem& y) {
+                return P->dense_h[(size_t)x.blk].size - x.row0 > P->dense_h[(size_t)y.blk].size - y.row0;
+            });
+            HIP_TRY(P->d_epi_all.alloc(all.size()));
+            HIP_TRY(hipMemcpy(P->d_epi_all.p, all.data(), sizeof(EpiItem) * all.size(), hipMemcpyHostToDevice));
             HIP_TRY(P->d_epi.alloc(items.size()));
             HIP_TRY(hipMemcpy(P->d_epi.p, items.data(), sizeof(EpiItem) * items.size(), hipMemcpyHostToDevice));
         }
@@ -946,14 +958,11 @@ static int launch_grid_mfma(viprs_plan* P, EStepArgs<float> A) {
         const size_t eshmem = (size_t)kGridEpiWaves * kGridEpiWaveFloats * sizeof(float);
         const void* efn = (const void*)estep_grid_upper_epilogue_kernel<U>;
         HIP_TRY(hipFuncSetAttribute(efn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eshmem));
-        for (int c = 0; c < 3; ++c) {
-            const int eb = P->epi_begin[c], en = P->epi_begin[c + 1] - eb;
-            if (en <= 0) continue;
-            EStepArgs<float> Ac = A;
-            Ac.blocks = P->d_dense.p + P->class_begin[c];
+        const int en = (int)P->n_epi;
+        if (en > 0) {
             const int eg = (int)std::min<int64_t>(((int64_t)en + kGridEpiWaves - 1) / kGridEpiWaves, (int64_t)P->n_cu);
-            estep_grid_upper_epilogue_kernel<U><<<eg, 64 * kGridEpiWaves, eshmem, P->stream>>>(Ac, P->d_epi.p + eb, en,
-                                                                                             P->d_counters.p + 8 + c);
+            estep_grid_upper_epilogue_kernel<U><<<eg, 64 * kGridEpiWaves, eshmem, P->stream>>>(A, P->d_epi_all.p, en,
+                                                                                             P->d_counters.p + 8);
             HIP_TRY(hipGetLastError());
         }
     }
