@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--model", default="spike_slab", choices=["spike_slab", "mixture", "grid"],
+                    help="spike_slab = the headline (configs[1..2]); mixture = configs[3] (VIPRSMix); grid = configs[4]")
+    ap.add_argument("--width", type=int, default=0, help="mixture components K (default 4) / grid models G (default 32)")
     ap.add_argument("--seed", type=int, default=7209)
     return ap.parse_args()
 
@@ -149,13 +152,25 @@ def main():
 
     device = local_rank % _lib.device_count()
     plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, ld.low_memory, device=device, math_mode=args.math)
-    state = DeviceState(plan, "float32", "spike_slab")
-    for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
-        state.upload(name, getattr(inp, name))
+    width = args.width or {"spike_slab": 1, "mixture": 4, "grid": 32}[args.model]
+    state = DeviceState(plan, "float32", args.model, width)
+    active = None
+    pi0 = inp.pi
+    if args.model == "spike_slab":
+        for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+            state.upload(name, getattr(inp, name))
+    else:
+        extra = syn.make_mixture_inputs(ss, width) if args.model == "mixture" else syn.make_grid_inputs(ss, width)
+        pi0 = extra.pop("pi")
+        state.upload("std_beta", inp.std_beta)
+        for name, arr in extra.items():
+            state.upload(name, arr)
+        if args.model == "grid":
+            active = np.arange(width, dtype=np.int32)
 
     def step():
-        state.reset(inp.pi)
-        state.e_step(ld.dq_scale, sync=False)
+        state.reset(pi0)
+        state.e_step(ld.dq_scale, active, sync=False)
 
     def barrier():
         state.synchronize()
@@ -195,14 +210,20 @@ def main():
     if rank == 0:
         es = ld_dtype.itemsize
         nnz_streamed = int(ld.ld_indptr[-1]) * (2 if ld.low_memory else 1)   # upper form is read twice
-        algo_bytes = es * nnz_streamed + STATE_BYTES_PER_SNP * ld.m
+        # state bytes per SNP: index (12) + per model column 4 inputs + 5 state reads/writes + std_beta
+        state_bytes = STATE_BYTES_PER_SNP if args.model == "spike_slab" else (
+            12 + 4 + 4 * (3 * width + 1) + 8 * (2 * width + 3) if args.model == "mixture" else 12 + 4 + 36 * width)
+        algo_bytes = es * nnz_streamed + state_bytes * ld.m
         k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(f"{args.config}_{args.ld_dtype}_{'upper' if args.low_memory else 'sym'}")
+                key = f"{args.config}_{args.ld_dtype}_{'upper' if args.low_memory else 'sym'}"
+                if args.model != "spike_slab":
+                    key += f"_{args.model}{width}"
+                traffic = json.load(open(prof)).get(key)
             except Exception:
                 traffic = None
         out = {
@@ -220,7 +241,11 @@ def main():
                 "workload": {"cfg1": "configs[0]: single LD block, 500 SNPs",
                              "cfg2": "configs[1]: chr22-like, ~19k SNPs / 40 LD blocks",
                              "cfg3": "configs[2]: genome-wide, ~1.1M SNPs / 1700 LD blocks"}[args.config]
-                            + ", spike-and-slab, AR(1) block LD",
+                            + {"spike_slab": ", spike-and-slab", "mixture": f", sparse mixture prior K={width} (configs[3])",
+                               "grid": f", grid of {width} (pi, sigma_eps) models batched per SNP (configs[4])"}[args.model]
+                            + ", AR(1) block LD",
+                "model": args.model, "width": width, "snp_model_updates_per_s": total_snps * width * args.steps / elapsed
+                if args.model == "grid" else None,
                 "snps_per_gpu": int(ld.m), "ld_blocks_per_gpu": int(len(sizes)),
                 "ld_entries_per_gpu": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype,
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
@@ -230,14 +255,16 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "estep_panel_kernel (3 size classes on 3 streams; the largest two share blocks between CUs)"
-                          + (" + estep_upper_epilogue_kernel" if ld.low_memory else ""),
+                "kernel": ("estep_grid_mfma_kernel (one workgroup per LD block, LD read once for all models)"
+                           + (" + estep_grid_upper_epilogue_kernel" if ld.low_memory else "")) if args.model == "grid" else
+                          ("estep_panel_kernel (3 size classes on 3 streams; the largest two share blocks between CUs)"
+                           + (" + estep_upper_epilogue_kernel" if ld.low_memory else "")),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
                 "kernel_ms_avg": k_avg_ms, "sweep_ms_avg": float(np.mean(sweep_ms)) if sweep_ms else None,
             },
         }
-        if n_gpus == 1 and args.cpu_seconds > 0:
+        if n_gpus == 1 and args.cpu_seconds > 0 and args.model == "spike_slab":
             out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 

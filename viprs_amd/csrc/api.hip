@@ -778,7 +778,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     A.counter = P->d_counters.p + 4 + cls;
     const int max_b = P->dense_h[begin].size;      // descending order
     const int qcap = (max_b + kPanel - 1) / kPanel * kPanel + kStrip;
-    const size_t shmem = (size_t)panel_lds_floats(qcap) * sizeof(float);
+    const size_t shmem = (size_t)(panel_lds_floats(qcap) + (model == kPanelMixture ? kMixLdsFloats : 0)) * sizeof(float);
     const bool exact = P->math_mode == VIPRS_MATH_EXACT;
     const bool upper = P->low_memory != 0;
     const void* kfn = nullptr;

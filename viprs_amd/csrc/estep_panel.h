@@ -24,6 +24,8 @@
 // Large blocks (a single CU pulls only ~50 GB/s from HBM) are shared by a TEAM of TS workgroups on
 // TS CUs: see the comment at `team` in the kernel.
 #pragma once
+#include <type_traits>
+
 #include "device_math.h"
 #include "kernels_common.h"
 
@@ -90,6 +92,22 @@ template <> __device__ __forceinline__ RowVec<2> load_cols<int16_t, 2>(const int
 }
 template <> __device__ __forceinline__ RowVec<1> load_cols<int16_t, 1>(const int16_t* p) { return RowVec<1>{{(float)*p}}; }
 
+// value of lane - N within a row of 16 lanes (v_mov_b32_dpp row_shr:N); lanes without a source get `fill`
+template <int N> __device__ __forceinline__ float dpp_shr(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x110 + N, 0xf, 0xf, false));
+}
+
+// max(x[lane - N], x[lane]) within a row of 16 lanes, lanes without a source keep x (no NaN canonicalisation:
+// the operands are finite); the two wait states a DPP read of a fresh VALU result needs are in the asm
+template <int N> __device__ __forceinline__ float dpp_max_shr(float x) {
+    float r;
+    if (N == 1) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "0"(x));
+    if (N == 2) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "0"(x));
+    if (N == 4) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "0"(x));
+    if (N == 8) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "0"(x));
+    return r;
+}
+
 __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -153,6 +171,7 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
 // ---------------------------------------------------------------------------------------------
 template <bool EXACT>
 struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
+    static constexpr bool kLaneParallel = false;
     struct In { float mm, beta, sv, ulog, eta_old; };
     static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
         In in;
@@ -196,6 +215,7 @@ struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
 // Different arithmetic from e_step: no fma in mu / the logit / d, half_var_tau instead of its
 // square root, no skip branch.
 struct GridColumnModel {
+    static constexpr bool kLaneParallel = false;
     struct In { float mm, beta, hvt, ulog, eta_old; };
     static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
         In in;
@@ -238,7 +258,11 @@ struct GridColumnModel {
 
 // e_step_mixture (e_step.hpp:496-537) for K <= kPanelMaxK components ((m, K) arrays C-ordered).
 constexpr int kPanelMaxK = 8;
+// LDS of the lane-parallel mixture chain: mu_mult | sqrt_half_var_tau | u_logs | var_mu | var_gamma, [64 SNPs][K]
+constexpr int kMixLdsFloats = 5 * kPanel * kPanelMaxK;
 struct MixtureModel {
+    // the chain evaluates the K + 1 components of ONE SNP on K + 1 lanes (see the chain in estep_panel_kernel)
+    static constexpr bool kLaneParallel = true;
     struct In { float mm[kPanelMaxK], sv[kPanelMaxK], ulog[kPanelMaxK]; float lnp, beta, eta_old; int K; };
     static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
         In in;
@@ -320,6 +344,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
+    float* lmx = lT + 2 * kPanel * kPanel;              // mixture chain only (kMixLdsFloats)
     __shared__ int s_blk;
 
     const int tid = threadIdx.x;
@@ -457,39 +482,139 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
                     }
 
-                    // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own
-                    // q[j]); every lane executes the update arithmetic on its own values, but at
-                    // step j only lane j's result is meaningful: its scaled eta_diff is broadcast
-                    // (one v_readlane) and applied to the whole panel through row j of the
-                    // diagonal tile.  The wave is issue-bound here (one wave per chain), so the
-                    // step is written for instruction count: no input broadcasts, no branches.
-                    float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
+                    if constexpr (MODEL::kLaneParallel) {
+                        // Mixture chain: the K components (and the null component, lane K) of ONE SNP
+                        // are evaluated on K + 1 lanes -- one expf, one divide per SNP instead of K + 1
+                        // and K; the ordered sums of the reference (softmax denominator, e_step.hpp:231-240;
+                        // eta, :519-523) run over v_readlane values in component order.  Component
+                        // inputs of the panel go through LDS as [SNP][k] (the (m, K) arrays' own layout).
+                        const int K = in.K;
+                        float* __restrict__ Lmm = lmx;
+                        float* __restrict__ Lsv = lmx + kPanel * kPanelMaxK;
+                        float* __restrict__ Lul = lmx + 2 * kPanel * kPanelMaxK;
+                        float* __restrict__ Lmu = lmx + 3 * kPanel * kPanelMaxK;
+                        float* __restrict__ Lga = lmx + 4 * kPanel * kPanelMaxK;
 #pragma unroll
-                    for (int jj = 0; jj < kPanel; ++jj) {
-                        if (jj + kChainPrefetch < kPanel)
-                            drow[jj + kChainPrefetch] =
-                                static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
-                        else
-                            dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
-                                nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
-                        float d;
-                        // dead lanes (past a partial last panel) are forced onto the skip path
-                        const bool upd = MODEL::template update<kLookupLane>(in, qc, tab, d, jj) && live;
-                        const float a_lane = upd ? dq * d : 0.0f;
-                        // (keeps hipcc from hoisting 64 loop-invariant lane masks and spilling them)
-                        int l = lane;
-                        asm volatile("" : "+v"(l));
-                        const bool me = (l == jj);
-                        qcap_v = me ? qc : qcap_v;
-                        qc = __builtin_fmaf(drow[jj], rl(a_lane, jj), qc);
-                        if (SYM) qc = (me && upd) ? qc - d : qc;   // e_step.hpp:427 (diagonal entry of the symmetric form)
+                        for (int k = 0; k < kPanelMaxK; ++k) {
+                            if (k < K) {
+                                Lmm[lane * K + k] = in.mm[k];
+                                Lsv[lane * K + k] = in.sv[k];
+                                Lul[lane * K + k] = in.ulog[k];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const int kc = min(lane, K - 1);                   // lanes >= K: harmless copies
+                        float cmm = Lmm[kc], csv = Lsv[kc], cul = Lul[kc];
+                        float dvec = 0.0f, avec = 0.0f;                    // lane j: eta_diff / dq * eta_diff of SNP j
+                        auto run_panel = [&](auto rounds_c) {
+                        constexpr int ROUNDS = decltype(rounds_c)::value;
+#pragma unroll
+                        for (int jj = 0; jj < kPanel; ++jj) {
+                            if (jj + kChainPrefetch < kPanel)
+                                drow[jj + kChainPrefetch] =
+                                    static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
+                            else
+                                dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
+                                    nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
+                            const int jn = (jj + 1 < kPanel) ? jj + 1 : jj;
+                            const float nmm = Lmm[jn * K + kc], nsv = Lsv[jn * K + kc], nul = Lul[jn * K + kc];
+                            const float qj = rl(qc, jj), lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
+                            const float r = rl(in.beta, jj) - qj;                              // :505
+                            const float mu = cmm * r;                                          // :509
+                            const float t = csv * mu;
+                            float u = __builtin_fmaf(t, t, cul);                               // :511
+                            u = (lane == K) ? lnp : u;
+                            // max over lanes 0..K (order-free): inclusive prefix max along the row, read at lane K
+                            float mx = dpp_max_shr<1>(u);
+                            mx = dpp_max_shr<2>(mx);
+                            mx = dpp_max_shr<4>(mx);
+                            mx = dpp_max_shr<8>(mx);
+                            mx = rl(mx, K);                                                    // c_max, :58-71
+                            const float e = expf_glibc_nonpos<kLookupPerLane>(u - mx, tab);
+                            // softmax denominator, :231-240: s = ((e_0 + e_1) + ...) + e_null in this order.
+                            // Lane k adds its e to lane k-1's running sum; after k rounds lane k is final
+                            // and stays so: ROUNDS >= K rounds, no K-dependent branch inside the step.
+                            float ssum = e;
+#pragma unroll
+                            for (int it = 0; it < ROUNDS; ++it) ssum = e + dpp_shr<1>(ssum, 0.0f);
+                            ssum = rl(ssum, K);
+                            const float gam = e / ssum;                                        // :239
+                            // eta_diff, :519-523: d_k = fma(gam_k, mu_k, d_{k-1}), d_{-1} = -eta_old, same scheme
+                            // (lane 0 of `dprev` is never written by the shift and keeps -eta_old)
+                            float d = -eta_old, dprev = -eta_old;
+#pragma unroll
+                            for (int it = 0; it < ROUNDS; ++it) {
+                                asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dprev) : "v"(d));
+                                d = __builtin_fmaf(gam, mu, dprev);
+                            }
+                            d = rl(d, K - 1);
+                            const bool livej = jj < nrows;                                     // wave-uniform
+                            const float a = livej ? dq * d : 0.0f;
+                            if (lane < K) {
+                                Lmu[jj * K + lane] = mu;
+                                Lga[jj * K + lane] = gam;
+                            }
+                            int l = lane;
+                            asm volatile("" : "+v"(l));
+                            const bool me = (l == jj);
+                            dvec = me ? d : dvec;
+                            avec = me ? a : avec;
+                            qc = __builtin_fmaf(drow[jj], a, qc);
+                            if (SYM) qc = (me && livej) ? qc - d : qc;                         // :527
+                            cmm = nmm; csv = nsv; cul = nul;
+                        }
+                        };
+                        if (K <= 4) run_panel(std::integral_constant<int, 4>{});
+                        else run_panel(std::integral_constant<int, kPanelMaxK>{});
+                        __builtin_amdgcn_wave_barrier();
+                        if (member == 0) {
+                            // (m, K) C-order: the panel's var_mu / var_gamma are nrows * K contiguous floats
+                            const int64_t o = (s0 + r0) * K;
+                            for (int i = lane; i < nrows * K; i += 64) {
+                                A.var_mu[o + i] = Lmu[i];
+                                A.var_gamma[o + i] = Lga[i];
+                            }
+                            if (live) {
+                                A.eta_diff[j] = dvec;
+                                if (TEAM) A.eta_out[j] = in.eta_old + dvec; else A.eta[j] = in.eta_old + dvec;   // :536
+                            }
+                        }
+                        a_prev = avec;
+                    } else {
+                    // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own
+                        // q[j]); every lane executes the update arithmetic on its own values, but at
+                        // step j only lane j's result is meaningful: its scaled eta_diff is broadcast
+                        // (one v_readlane) and applied to the whole panel through row j of the
+                        // diagonal tile.  The wave is issue-bound here (one wave per chain), so the
+                        // step is written for instruction count: no input broadcasts, no branches.
+                        float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
+    #pragma unroll
+                        for (int jj = 0; jj < kPanel; ++jj) {
+                            if (jj + kChainPrefetch < kPanel)
+                                drow[jj + kChainPrefetch] =
+                                    static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
+                            else
+                                dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
+                                    nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
+                            float d;
+                            // dead lanes (past a partial last panel) are forced onto the skip path
+                            const bool upd = MODEL::template update<kLookupLane>(in, qc, tab, d, jj) && live;
+                            const float a_lane = upd ? dq * d : 0.0f;
+                            // (keeps hipcc from hoisting 64 loop-invariant lane masks and spilling them)
+                            int l = lane;
+                            asm volatile("" : "+v"(l));
+                            const bool me = (l == jj);
+                            qcap_v = me ? qc : qcap_v;
+                            qc = __builtin_fmaf(drow[jj], rl(a_lane, jj), qc);
+                            if (SYM) qc = (me && upd) ? qc - d : qc;   // e_step.hpp:427 (diagonal entry of the symmetric form)
+                        }
+    
+                        // lane-parallel replay of the 64 updates (same operations, same inputs ->
+                        // same bits) to produce the per-SNP outputs without serialising the stores
+                        bool skipped_lane;
+                        a_prev = MODEL::template finish<TEAM>(A, j, in, qcap_v, tab, live, member == 0, skipped_lane);
+                        my_skipped += __popcll(__ballot(skipped_lane));
                     }
-
-                    // lane-parallel replay of the 64 updates (same operations, same inputs ->
-                    // same bits) to produce the per-SNP outputs without serialising the stores
-                    bool skipped_lane;
-                    a_prev = MODEL::template finish<TEAM>(A, j, in, qcap_v, tab, live, member == 0, skipped_lane);
-                    my_skipped += __popcll(__ballot(skipped_lane));
                     la[(p & 1) * kPanel + lane] = a_prev;
                     lq[r0 + lane] = qc;
                 }

@@ -212,3 +212,37 @@ def make_problem(config="cfg1", low_memory=False, ld_dtype=np.float32, seed=SEED
     ss = make_sumstats(ld, seed=seed, float_precision=float_precision)
     inp = make_inputs(ss, float_precision=float_precision)
     return ld, ss, inp
+
+
+def make_mixture_inputs(ss, K=4, float_precision=np.float32):
+    """Per-SNP inputs of `e_step_mixture` for a K-component sparse mixture prior (VIPRSMix.py:52,
+    :206-223): component variances d_k = 2^-(K-1) .. 1 around the spike-and-slab scale, C-order (m, K)."""
+    T = np.dtype(float_precision)
+    m = ss.n_per_snp.shape[0]
+    d = 2.0 ** np.linspace(-min(K - 1, 7), 0, K)
+    pis = np.full(K, 0.01 / K)
+    sigma_eps, h2 = 0.8, 0.2
+    tau = d * (m * pis.sum() / h2)
+    n = np.asarray(ss.n_per_snp, dtype=np.float64)[:, None]
+    var_tau = n / sigma_eps + tau[None, :]
+    return dict(
+        log_null_pi=np.full(m, np.log(1.0 - pis.sum()), dtype=T),
+        u_logs=np.ascontiguousarray((np.log(pis) - np.log(1 - pis) + 0.5 * (np.log(tau) - np.log(var_tau))).astype(T)),
+        sqrt_half_var_tau=np.ascontiguousarray(np.sqrt(0.5 * var_tau).astype(T)),
+        mu_mult=np.ascontiguousarray((n / (var_tau * sigma_eps)).astype(T)),
+        pi=float(pis[0]))
+
+
+def make_grid_inputs(ss, G=32, float_precision=np.float32):
+    """Per-SNP inputs of `e_step_grid` for G (pi, sigma_epsilon) grid points, column-major (m, G)
+    (VIPRSGrid.py: one column per model)."""
+    T = np.dtype(float_precision)
+    m = ss.n_per_snp.shape[0]
+    pis = np.logspace(-3, -1, G)
+    sig = np.linspace(0.7, 0.95, G)
+    tau = pis * m / (1 - sig)
+    n = np.asarray(ss.n_per_snp, dtype=np.float64)[:, None]
+    var_tau = n / sig[None, :] + tau[None, :]
+    mk = lambda a: np.asfortranarray(a.astype(T))
+    return dict(u_logs=mk(np.log(pis) - np.log(1 - pis) + 0.5 * (np.log(tau) - np.log(var_tau))),
+                half_var_tau=mk(0.5 * var_tau), mu_mult=mk(n / (var_tau * sig[None, :])), pi=float(pis[0]))
