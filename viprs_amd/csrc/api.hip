@@ -52,7 +52,7 @@ size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0);
 // the same CU resources as a small-block workgroup; larger blocks get more CUs, not bigger groups.
 static int kLargeBlock = 2304, kMediumBlock = 1280;
 constexpr int kClassWaves[3] = {4, 4, 4};
-static int kClassTeam[3] = {8, 3, 1};       // workgroups (CUs) sharing one block of the class (0/1: teams)
+static int kClassTeam[3] = {8, 2, 1};       // workgroups (CUs) sharing one block of the class (0/1: teams)
 constexpr int kClassCols[3] = {4, 4, 4};    // columns per updater lane: narrower strips = more streaming waves per block
 constexpr int kEpiWaves = 4;
 

@@ -31,6 +31,12 @@
 
 namespace viprs {
 
+#ifdef VIPRS_PANEL_PROFILE
+#define PPROF(slot, cond) do { if (TEAM && item == 0 && member < 2 && lane == 0 && p < 64 && (cond)) s_pprof[p][slot] = (unsigned)wall_clock64(); } while (0)
+#else
+#define PPROF(slot, cond) do { } while (0)
+#endif
+
 // ---- 4-element row loads, converted with static_cast<float> as e_step.hpp:173 does ----------
 template <typename U> __device__ __forceinline__ float4 load4(const U* p);
 template <> __device__ __forceinline__ float4 load4<float>(const float* p) {
@@ -429,7 +435,11 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
         }
 
         // symmetric form: one extra phase applies the last panel's a-vector to the columns left of it
+#ifdef VIPRS_PANEL_PROFILE
+        __shared__ unsigned s_pprof[64][8];
+#endif
         for (int p = 0; p < np + (SYM ? 1 : 0); ++p) {
+            PPROF(0, wave == 0);
             if (wave == 0) {
                 // ================================ chain ======================================
                 if (p < np) {
@@ -475,6 +485,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         }
                         qc = __uint_as_float((unsigned)g);
                     }
+                    PPROF(1, true);
                     if (p > 0) {
                         // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
                         const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
@@ -482,6 +493,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
                     }
 
+                    PPROF(2, true);
                     if constexpr (MODEL::kLaneParallel) {
                         // Mixture chain: the K components (and the null component, lane K) of ONE SNP
                         // are evaluated on K + 1 lanes -- one expf, one divide per SNP instead of K + 1
@@ -609,6 +621,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                             if (SYM) qc = (me && upd) ? qc - d : qc;   // e_step.hpp:427 (diagonal entry of the symmetric form)
                         }
     
+                        PPROF(3, true);
                         // lane-parallel replay of the 64 updates (same operations, same inputs ->
                         // same bits) to produce the per-SNP outputs without serialising the stores
                         bool skipped_lane;
@@ -617,6 +630,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     }
                     la[(p & 1) * kPanel + lane] = a_prev;
                     lq[r0 + lane] = qc;
+                    PPROF(4, true);
                 }
             } else {
                 // ================================ updaters ===================================
@@ -631,6 +645,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                         *reinterpret_cast<float4*>(T + row * kPanel + tcol) = v;
                     }
                 }
+                PPROF(5, wave == 1);
                 if (p > 0) {
                     const int pp = p - 1;                       // panel whose a-vector is applied
                     const int rr0 = pp * kPanel;
@@ -662,6 +677,7 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                             else
                                 strip_update<U, CPL, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
                         }
+                        if (k == uw) PPROF(6, wave == 1);
                         if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
                             // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
                             __builtin_amdgcn_wave_barrier();
@@ -674,8 +690,20 @@ __global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A
                     }
                 }
             }
+            PPROF(7, wave == 1);
             __syncthreads();
         }
+#ifdef VIPRS_PANEL_PROFILE
+        if (TEAM && item == 0 && member < 2 && tid == 0) {
+            for (int p = 0; p < np && p < 64; p += (p < 4 || p > np - 4) ? 1 : 8) {
+                const unsigned t = s_pprof[p][0];
+                printf("m%d phase %2d @%7u: granule %4d T-apply %4d loop %5d replay %5d end %5d | upd: staged %5d pri %5d all %5d (x10ns)\n",
+                       member, p, t - s_pprof[0][0], (int)(s_pprof[p][1] - t), (int)(s_pprof[p][2] - t), (int)(s_pprof[p][3] - t),
+                       (int)(s_pprof[p][4] - t), (int)(s_pprof[p][4] - t), (int)(s_pprof[p][5] - t), (int)(s_pprof[p][6] - t),
+                       (int)(s_pprof[p][7] - t));
+            }
+        }
+#endif
         {   // teams: every member owns the final q of its own strips
             float* __restrict__ qdst = TEAM ? A.q_out : A.q;
             for (int i = tid; i < b; i += NW * 64)
