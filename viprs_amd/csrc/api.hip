@@ -53,7 +53,6 @@ size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0);
 static int kLargeBlock = 2304, kMediumBlock = 1280;
 constexpr int kClassWaves[3] = {4, 4, 4};
 static int kClassTeam[3] = {8, 2, 1};       // workgroups (CUs) sharing one block of the class (0/1: teams)
-constexpr int kClassCols[3] = {4, 4, 4};    // columns per updater lane: narrower strips = more streaming waves per block
 constexpr int kEpiWaves = 4;
 
 template <typename V> struct DevBuf {
@@ -794,6 +793,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NW * 64, shmem));
     per_cu = std::max(1, per_cu);
+    if (const char* f = getenv("VIPRS_MAX_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(f)));   // experiments
     const int n_models = std::max(1, A.n_active);
     const int64_t n_items = (int64_t)A.n_blocks * n_models;
     int grid = (int)std::min<int64_t>(n_items, (int64_t)P->n_cu * per_cu);
@@ -870,9 +870,9 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A, int model = kPanelSpikeSlab)
     HIP_TRY(hipEventRecord(P->ev_fork, P->stream));
     int rc;
     for (int c = 0; c < 3; ++c) HIP_TRY(hipStreamWaitEvent(P->class_stream[c], P->ev_fork, 0));
-    if ((rc = launch_panel_class<U, kClassWaves[0], true, kClassCols[0]>(P, A, 0, P->class_stream[0], model)) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[1], true, kClassCols[1]>(P, A, 1, P->class_stream[1], model)) != VIPRS_OK) return rc;
-    if ((rc = launch_panel_class<U, kClassWaves[2], false, kClassCols[2]>(P, A, 2, P->class_stream[2], model)) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[0], true, panel_cols<U>()>(P, A, 0, P->class_stream[0], model)) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[1], true, panel_cols<U>()>(P, A, 1, P->class_stream[1], model)) != VIPRS_OK) return rc;
+    if ((rc = launch_panel_class<U, kClassWaves[2], false, panel_cols<U>()>(P, A, 2, P->class_stream[2], model)) != VIPRS_OK) return rc;
     for (int c = 0; c < 3; ++c) {
         HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
         HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join[c], 0));

@@ -118,8 +118,38 @@ __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// CPL consecutive columns of one LD row exactly as stored (float / int8 / int16), converted with
+// static_cast<float> (e_step.hpp:173) only when consumed: the prefetch buffer of an updater lane holds
+// raw bytes, so a 16-byte load brings 4 fp32, 8 int16 or 16 int8 columns.
+template <typename U, int CPL> struct RawRow {
+    static constexpr int kWords = CPL * (int)sizeof(U) / 4;
+    static_assert(CPL * sizeof(U) % 4 == 0 && (kWords == 1 || kWords == 2 || kWords == 4), "1, 2 or 4 dwords per lane and row");
+    unsigned w[kWords];
+    __device__ __forceinline__ float get(int i) const {
+        if constexpr (sizeof(U) == 4) return __uint_as_float(w[i]);
+        else if constexpr (sizeof(U) == 1) return static_cast<float>(static_cast<int8_t>(w[i >> 2] >> (8 * (i & 3))));
+        else return static_cast<float>(static_cast<int16_t>(w[i >> 1] >> (16 * (i & 1))));
+    }
+};
+template <typename U, int CPL> __device__ __forceinline__ RawRow<U, CPL> load_raw(const U* p) {
+    RawRow<U, CPL> r;
+    if constexpr (RawRow<U, CPL>::kWords == 1) {
+        r.w[0] = *reinterpret_cast<const unsigned*>(p);
+    } else if constexpr (RawRow<U, CPL>::kWords == 2) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        r.w[0] = t.x; r.w[1] = t.y;
+    } else {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w;
+    }
+    return r;
+}
+// columns per updater lane: 16-byte loads for fp32 and int16, 8-byte loads for int8 (wider strips leave
+// too few updater waves per block busy)
+template <typename U> __host__ __device__ constexpr int panel_cols() { return sizeof(U) == 4 ? 4 : 8; }
+
 constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
-constexpr int kStripBytesInFlight = 64;  // floats of row data in flight per updater lane (16 x 16 B)
+constexpr int kStripRowsInFlight = 16;   // row loads in flight per updater lane (16 x 16 B for every LD type)
 
 // LDS carve (floats): q[qcap] | a[2][64] | T[2][64*64]
 __host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
@@ -134,34 +164,34 @@ __host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 *
 template <typename U, int CPL, bool FULL>
 __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int last_row, float avec,
                                              float* __restrict__ lq_c) {
-    constexpr int DEPTH = kStripBytesInFlight / CPL;
+    constexpr int DEPTH = kStripRowsInFlight;
     static_assert(kPanel % DEPTH == 0, "panel must be a whole number of prefetch groups");
     float qv[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) qv[i] = lq_c[i];
-    RowVec<CPL> buf[DEPTH];
+    RawRow<U, CPL> buf[DEPTH];
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k)
-        buf[k] = load_cols<U, CPL>(rowp + (int64_t)(FULL ? k : min(k, last_row)) * stride);
+        buf[k] = load_raw<U, CPL>(rowp + (int64_t)(FULL ? k : min(k, last_row)) * stride);
 #pragma unroll 1
     for (int g = 0; g < kPanel / DEPTH - 1; ++g) {
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) {
-            const RowVec<CPL> v = buf[k];
+            const RawRow<U, CPL> v = buf[k];
             const int rn = DEPTH * (g + 1) + k;
-            buf[k] = load_cols<U, CPL>(rowp + (int64_t)(FULL ? rn : min(rn, last_row)) * stride);
+            buf[k] = load_raw<U, CPL>(rowp + (int64_t)(FULL ? rn : min(rn, last_row)) * stride);
             const float a = rl(avec, DEPTH * g + k);
 #pragma unroll
-            for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.v[i], a, qv[i]);
+            for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.get(i), a, qv[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) {
-        const RowVec<CPL> v = buf[k];
+        const RawRow<U, CPL> v = buf[k];
         const float a = rl(avec, kPanel - DEPTH + k);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.v[i], a, qv[i]);
+        for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.get(i), a, qv[i]);
     }
 #pragma unroll
     for (int i = 0; i < CPL; ++i) lq_c[i] = qv[i];
