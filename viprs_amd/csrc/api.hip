@@ -208,6 +208,8 @@ struct viprs_plan {
     int64_t n_epi = 0;
     int epi_begin[4] = {0, 0, 0, 0};        // per size class ranges of d_epi
     DevBuf<EpiItem> d_epi_all;              // all items, plan-wide block indices, longest first
+    DevBuf<EpiItem> d_low_items;            // symmetric form: (block, 128-column tile) items of the batched grid lower pass
+    int64_t n_low_items = 0;
     DevBuf<int32_t> d_lb;
     DevBuf<int64_t> d_ip;
     DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
@@ -464,6 +466,24 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
+        if (!P->low_memory) {
+            // batched grid E-step, symmetric form: the columns left of the chain are finished by
+            // estep_grid_lower_pass_kernel, one item per 128-column tile that has rows below it, longest first
+            std::vector<EpiItem> low;
+            for (size_t i = 0; i < P->dense_h.size(); ++i) {
+                const int np = (P->dense_h[i].size + kPanel - 1) / kPanel;
+                for (int T = 0; 2 * T + 1 < np; ++T) low.push_back({(int32_t)i, T});
+            }
+            std::stable_sort(low.begin(), low.end(), [&](const EpiItem& x, const EpiItem& y) {
+                const int npx = (P->dense_h[(size_t)x.blk].size + kPanel - 1) / kPanel, npy = (P->dense_h[(size_t)y.blk].size + kPanel - 1) / kPanel;
+                return npx - 2 * x.row0 > npy - 2 * y.row0;
+            });
+            P->n_low_items = (int64_t)low.size();
+            if (!low.empty()) {
+                HIP_TRY(P->d_low_items.alloc(low.size()));
+                HIP_TRY(hipMemcpy(P->d_low_items.p, low.data(), sizeof(EpiItem) * low.size(), hipMemcpyHostToDevice));
+            }
+        }
         if (P->low_memory) {
             std::vector<EpiItem> items;
             for (int c = 0; c < 3; ++c) {
@@ -953,6 +973,16 @@ static int launch_grid_mfma(viprs_plan* P, EStepArgs<float> A) {
     const int grid = std::min<int>(A.n_blocks, P->n_cu * std::max(1, per_cu));
     void* params[] = {(void*)&A};
     HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(64 * kGridWaves), params, shmem, P->stream));
+    if (!P->low_memory && P->n_low_items > 0) {
+        // symmetric form: q of the SNPs already visited receives the later rows of its block here
+        const size_t lshmem = (size_t)kGridLowWaves * kGridLowWaveFloats * sizeof(float);
+        const void* lfn = (const void*)estep_grid_lower_pass_kernel<U>;
+        HIP_TRY(hipFuncSetAttribute(lfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lshmem));
+        const int ln = (int)P->n_low_items;
+        const int lg = (int)std::min<int64_t>(((int64_t)ln + kGridLowWaves - 1) / kGridLowWaves, (int64_t)P->n_cu * 2);
+        estep_grid_lower_pass_kernel<U><<<lg, 64 * kGridLowWaves, lshmem, P->stream>>>(A, P->d_low_items.p, ln, P->d_counters.p + 9);
+        HIP_TRY(hipGetLastError());
+    }
     if (P->low_memory) {
         // update_q_factor_matrix (e_step.hpp:266-303) for all models of the chunk: (block, 64-row group) items
         const size_t eshmem = (size_t)kGridEpiWaves * kGridEpiWaveFloats * sizeof(float);

@@ -204,11 +204,11 @@ __device__ __forceinline__ void wtile_store_acc(const f32x16 (&acc)[4], const ES
 
 // 128 MFMAs: rows (2i, 2i + 1) per step, k ascending
 __device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
-                                              const float* __restrict__ a_lds, int lane) {
+                                              const float* __restrict__ a_lds, int lane, int a_pitch = kGridModels) {
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int i = 0; i < kPanel / 2; ++i) {
-        const float aop = a_lds[(2 * i + half) * kGridModels + l31];  // A[model = lane & 31][k = lane >> 5]
+        const float aop = a_lds[(2 * i + half) * a_pitch + l31];      // A[model = lane & 31][k = lane >> 5]
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][j], acc[j], 0, 0, 0);
     }
@@ -465,13 +465,15 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
 #endif
                 GPROF(6, wave == 1);
                 if (p > 0) {
-                    // a_{p-1} on every 64-column tile except p-1 (the chain did it), p (done above) and
-                    // p+1 (wave 1, below); upper-triangular form: only tiles right of p
+                    // a_{p-1} on every 64-column tile right of p+1 (p: done above; p+1: wave 1, below).  The
+                    // tiles LEFT of the chain (symmetric form: q of SNPs already visited keeps receiving
+                    // the later rows) are not needed again in this sweep: estep_grid_lower_pass_kernel
+                    // applies all their updates afterwards, in the same row order, with q read once.
                     const int pp = p - 1;
                     const float* a_lds = la + (pp & 1) * kGridAFloats;
                     const int n_wide = (np + 1) / 2;                         // 128-column tiles of the block
-                    for (int T = (SYM ? 0 : (p + 2) / 2) + wave - 1; T < n_wide; T += NU) {
-                        auto active64 = [&](int ct) { return ct < np && ct != pp && ct != p && ct != p + 1 && (SYM || ct > p + 1); };
+                    for (int T = (p + 2) / 2 + wave - 1; T < n_wide; T += NU) {
+                        auto active64 = [&](int ct) { return ct < np && ct > p + 1; };
                         const bool a0 = active64(2 * T), a1 = active64(2 * T + 1);
                         if (!a0 && !a1) continue;
                         const bool lane_ok = (lane & 16) ? a1 : a0;          // lanes n < 16: left 64 columns
@@ -481,7 +483,13 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                         wtile_load_rows<U>(R, base, stride, pp, c0, lane);
                         if (c0 + 2 * kPanel <= b) {
                             wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+#ifdef VIPRS_GRID_PROFILE
+                            if (T < NU) { GPROF(8, wave == 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GPROF(9, wave == 1); }
+#endif
                             wtile_compute(acc, R, a_lds, lane);
+#ifdef VIPRS_GRID_PROFILE
+                            if (T < NU) { asm volatile("" :: "v"(acc[0]), "v"(acc[3])); GPROF(10, wave == 1); }
+#endif
                             wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
                         } else {
                             wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
@@ -623,6 +631,95 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
                 if (32 + l31 < nrows) qc[32 + l31] += A.dq * acc1[r];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric form, columns left of the chain: q[g, c] of a SNP c already visited still receives
+// fma(R[j, c], dq * eta_diff[g, j], .) from every later SNP j of its block (e_step.hpp:623 with the
+// full row window), in the order of j.  None of these values is read again during the sweep, so
+// they are applied after it: one wave per 128-column tile keeps the tile's 32 x 128 accumulators in
+// registers and streams the rows below the tile's own panels once (LD lower triangle read once, q
+// read and written once), a = dq * eta_diff recomputed from the stored eta_diff exactly as the chain did.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGridLowWaves = 4;
+constexpr int kGridLowEPitch = kGridModels + 1;
+constexpr int kGridLowWaveFloats = 2 * kPanel * kGridLowEPitch;
+
+template <typename U>
+__global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kernel(EStepArgs<float> A, const EpiItem* items,
+                                                                                   int n_items, int32_t* counter) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_act[kGridModels];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* el = smem + wave * kGridLowWaveFloats;        // [2][64 rows][33]: dq * eta_diff of a panel, [row][model]
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const int n_models = A.n_active;
+    const float dq = A.dq;
+    if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
+    __syncthreads();
+    const int n = lane & 31;
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(counter, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const EpiItem it = items[item];
+        const BlockDesc bd = A.blocks[it.blk];
+        const int b = bd.size, stride = bd.stride, T = it.row0;     // row0 = index of the 128-column tile
+        const int64_t s0 = bd.start;
+        const U* __restrict__ base = ldd + bd.ld_off;
+        const int np = (b + kPanel - 1) / kPanel;
+        const int c0 = T * 2 * kPanel;
+        const int p_first = 2 * T + 1;                              // first panel below the tile's left half
+        if (p_first >= np) continue;
+        const bool right = 2 * T + 1 < np;                          // the right 64 columns exist
+        const bool lane_ok = (n < 16) || right;
+        const bool full = c0 + 2 * kPanel <= b;
+
+        f32x16 acc[4];
+        if (full) wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+        else wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+
+        // a tile of panel pq into el[buf]: rows pq*64 .. +63 x models
+        auto stage_a = [&](int pq, int buf) {
+            float* e = el + buf * kPanel * kGridLowEPitch;
+            const int row = pq * kPanel + lane;
+            const bool ok = row < b;
+            const unsigned off = (unsigned)s0 + (unsigned)min(row, b - 1);
+            float v[kGridModels];
+#pragma unroll
+            for (int g = 0; g < kGridModels; ++g) v[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < kGridModels; ++g) e[lane * kGridLowEPitch + g] = (ok && g < n_models) ? dq * v[g] : 0.0f;
+        };
+        f32x4 R0[kPanel / 2], R1[kPanel / 2];
+        wtile_load_rows<U>(R0, base, stride, p_first, c0, lane);
+        stage_a(p_first, 0);
+        int buf = 0;
+        for (int pq = p_first; pq < np; pq += 2) {
+            // -- panel pq from R0 / el[buf], panel pq + 1 in flight into R1
+            const int p1 = min(pq + 1, np - 1);
+            wtile_load_rows<U>(R1, base, stride, p1, c0, lane);
+            if (pq == p_first && n >= 16) {
+#pragma unroll
+                for (int i = 0; i < kPanel / 2; ++i) R0[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // right half: its own panel, no update
+            }
+            __builtin_amdgcn_wave_barrier();
+            wtile_compute(acc, R0, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
+            if (pq + 1 >= np) break;
+            stage_a(pq + 1, buf ^ 1);
+            // -- panel pq + 1 from R1, panel pq + 2 in flight into R0
+            const int p2 = min(pq + 2, np - 1);
+            wtile_load_rows<U>(R0, base, stride, p2, c0, lane);
+            __builtin_amdgcn_wave_barrier();
+            wtile_compute(acc, R1, el + (buf ^ 1) * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
+            if (pq + 2 < np) stage_a(pq + 2, buf);
+        }
+        if (full) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+        else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
     }
 }
 
