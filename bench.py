@@ -62,17 +62,17 @@ def shard_blocks_lpt(sizes, n_parts):
     return [sorted(p) for p in parts]
 
 
-def cpu_baseline(ld, inp, budget_s):
+def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0=None):
     """The reference's own e_step.hpp (oracle/_ref, built from /root/reference by oracle/Makefile)
     timed on this host, state re-initialised before every call: first with threads=1 (the parity
     reference), then with its OpenMP path on all cores (racy Hogwild, e_step.hpp:384-387 -- the
     "reference multithreaded-CPU" figure).  Sample: leading blocks of the same workload sized to
-    the time budget."""
+    the time budget (a mixture / grid SNP-update costs `width` times a spike-and-slab one)."""
     from oracle import oracle as O
     kind = "reference" if O.have_reference() else "restated"
     cores = os.cpu_count() or 1
     # ~0.2-0.5 M SNP-updates/s single-threaded: size the sample for ~budget/3 per single-thread pass
-    target_snps = int(min(ld.m, max(2000, 0.1e6 * budget_s)))
+    target_snps = int(min(ld.m, max(2000, 0.1e6 * budget_s / max(1, width))))
     nb = int(np.searchsorted(ld.block_start, target_snps, side="left"))
     nb = max(1, min(nb, len(ld.block_start) - 1))
     m_s = int(ld.block_start[nb])
@@ -80,15 +80,35 @@ def cpu_baseline(ld, inp, budget_s):
     lb = np.ascontiguousarray(ld.ld_left_bound[:m_s])
     ip = np.ascontiguousarray(ld.ld_indptr[:m_s + 1])
     data = ld.ld_data[:nnz_s]
-    vec = {k: np.ascontiguousarray(getattr(inp, k)[:m_s]) for k in
-           ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult")}
+    T = np.float32
+    std_beta = np.ascontiguousarray(inp.std_beta[:m_s])
+    if model == "spike_slab":
+        vec = {k: np.ascontiguousarray(getattr(inp, k)[:m_s]) for k in ("u_logs", "sqrt_half_var_tau", "mu_mult")}
+    else:
+        order = "F" if model == "grid" else "C"
+        vec = {k: np.asarray(v[:m_s], order=order).copy(order=order) for k, v in extra.items()}
 
     def one(threads):
-        st = {k: np.ascontiguousarray(v[:m_s]).copy() for k, v in inp.state_copy().items()}
-        t0 = time.perf_counter()
-        O.cpp_e_step(lb, ip, data, vec["std_beta"], st["var_gamma"], st["var_mu"], st["eta"], st["q"],
-                     st["eta_diff"], vec["u_logs"], vec["sqrt_half_var_tau"], vec["mu_mult"], ld.dq_scale,
-                     threads, ld.low_memory, kind=kind)
+        if model == "spike_slab":
+            st = {k: np.ascontiguousarray(v[:m_s]).copy() for k, v in inp.state_copy().items()}
+            t0 = time.perf_counter()
+            O.cpp_e_step(lb, ip, data, std_beta, st["var_gamma"], st["var_mu"], st["eta"], st["q"],
+                         st["eta_diff"], vec["u_logs"], vec["sqrt_half_var_tau"], vec["mu_mult"], ld.dq_scale,
+                         threads, ld.low_memory, kind=kind)
+        elif model == "mixture":
+            vg = np.full((m_s, width), pi0, dtype=T)
+            vm = np.zeros((m_s, width), dtype=T)
+            eta, q, ed = (np.zeros(m_s, dtype=T) for _ in range(3))
+            t0 = time.perf_counter()
+            O.cpp_e_step_mixture(lb, ip, data, std_beta, vg, vm, eta, q, ed, vec["log_null_pi"], vec["u_logs"],
+                                 vec["sqrt_half_var_tau"], vec["mu_mult"], ld.dq_scale, threads, ld.low_memory, kind=kind)
+        else:
+            vg = np.full((m_s, width), pi0, dtype=T, order="F")
+            vm, eta, q, ed = (np.zeros((m_s, width), dtype=T, order="F") for _ in range(4))
+            t0 = time.perf_counter()
+            O.cpp_e_step_grid(lb, ip, data, std_beta, vg, vm, eta, q, ed, vec["u_logs"], vec["half_var_tau"],
+                              vec["mu_mult"], ld.dq_scale, np.arange(width, dtype=np.int32), threads, ld.low_memory,
+                              kind=kind)
         return time.perf_counter() - t0
 
     res = {}
@@ -103,8 +123,9 @@ def cpu_baseline(ld, inp, budget_s):
     return {
         "value": res["all_cores"], "unit": "SNP-updates/s", "cores": cores if kind == "reference" else 1,
         "kind": "reference" if kind == "reference" else "port",
-        "sample": f"first {nb} LD blocks ({m_s} SNPs, {nnz_s} LD entries) of the same workload, "
-                  f"state re-initialised per call, median; OpenMP threads={cores} (racy, as the reference)",
+        "sample": f"first {nb} LD blocks ({m_s} SNPs, {nnz_s} LD entries) of the same workload, model={model}"
+                  + (f" width={width}" if model != "spike_slab" else "")
+                  + f", state re-initialised per call, median; OpenMP threads={cores} (racy, as the reference)",
         "single_thread_value": res["threads1"],
     }
 
@@ -155,6 +176,7 @@ def main():
     width = args.width or {"spike_slab": 1, "mixture": 4, "grid": 32}[args.model]
     state = DeviceState(plan, "float32", args.model, width)
     active = None
+    host_extra = None
     pi0 = inp.pi
     if args.model == "spike_slab":
         for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
@@ -162,6 +184,7 @@ def main():
     else:
         extra = syn.make_mixture_inputs(ss, width) if args.model == "mixture" else syn.make_grid_inputs(ss, width)
         pi0 = extra.pop("pi")
+        host_extra = extra
         state.upload("std_beta", inp.std_beta)
         for name, arr in extra.items():
             state.upload(name, arr)
@@ -264,8 +287,8 @@ def main():
                 "kernel_ms_avg": k_avg_ms, "sweep_ms_avg": float(np.mean(sweep_ms)) if sweep_ms else None,
             },
         }
-        if n_gpus == 1 and args.cpu_seconds > 0 and args.model == "spike_slab":
-            out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds)
+        if n_gpus == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds, args.model, width, host_extra, pi0)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -55,7 +55,7 @@ def main():
     else:
         s = syn.block_sizes("cfg3")
         run(s[s >= 2304], ">= 2304 (teams of 8)", args)
-        run(s[(s >= 1280) & (s < 2304)], "1280..2303 (teams of 3)", args)
+        run(s[(s >= 1280) & (s < 2304)], "1280..2303 (teams of 2)", args)
         run(s[s < 1280], "< 1280", args)
         run(s, "cfg3", args)
 
