@@ -6,7 +6,7 @@
 namespace viprs {
 
 constexpr int kPanel = 64;          // SNPs per panel = lanes per wavefront on gfx950
-constexpr int kStrip = 256;         // columns per updater strip (64 lanes x 4 columns)
+constexpr int kStrip = 256;         // padding unit of the per-block q arrays (one fp32 updater strip: 64 lanes x 4 columns)
 
 // One LD block as the device sees it.
 struct BlockDesc {
