@@ -223,3 +223,109 @@ def test_one_shot_call_rate_is_reported(gpu, capsys):
     with capsys.disabled():
         print(f"[one-shot cpp_e_step, cfg2 {ld.m} SNPs] {dt * 1e3:.3f} ms per call = {ld.m / dt / 1e6:.1f} M SNP-updates/s")
     assert dt < 1.0
+
+
+def _block_sample(ld, n_small=2, n_large=2, n_mid=2):
+    sizes = np.diff(ld.block_start)
+    order = np.argsort(sizes)
+    mid = len(order) // 2
+    return list(order[:n_small]) + list(order[-n_large:]) + list(order[mid - n_mid // 2: mid + (n_mid + 1) // 2])
+
+
+def _sub_block(ld, bi):
+    s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+    b = e - s
+    off = int(ld.ld_indptr[s])
+    sub = syn.SyntheticLD(np.zeros(b, np.int32), np.arange(0, b * b + 1, b, dtype=np.int64),
+                          ld.ld_data[off:off + b * b], np.array([0, b]), ld.rho[bi:bi + 1], False, 1.0)
+    return s, e, b, off, sub
+
+
+def test_cfg3_mixture_full_size_properties(gpu):
+    """BASELINE configs[3] (genome-wide, K = 4 sparse mixture): run-to-run bit reproducibility,
+    q == (R - I) eta per block, and the oracle on a sample of blocks (bit-identical)."""
+    from viprs_amd.plan import DeviceState, LDPlan
+    K = 4
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=False)
+    x = syn.make_mixture_inputs(ss, K)
+    pi0 = x.pop("pi")
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+    state = DeviceState(plan, "float32", "mixture", K)
+    state.upload("std_beta", inp.std_beta)
+    for n, a in x.items():
+        state.upload(n, a)
+    outs = []
+    for _ in range(2):
+        state.reset(pi0)
+        state.e_step(ld.dq_scale)
+        outs.append({k: state.download(k) for k in H.STATE})
+    H.assert_state_equal(outs[0], outs[1])
+    got = outs[0]
+    assert np.all(np.isfinite(got["var_mu"])) and np.all(got["var_gamma"] >= 0)
+    assert np.all(got["var_gamma"].sum(axis=1) <= 1.0 + 1e-6)
+    for bi in _block_sample(ld):
+        s, e, b, off, sub = _sub_block(ld, bi)
+        R = ld.ld_data[off:off + b * b].reshape(b, b).astype(np.float64)
+        np.testing.assert_allclose(got["q"][s:e], (R - np.eye(b)) @ got["eta"][s:e].astype(np.float64),
+                                   rtol=5e-4, atol=5e-6)
+        vg = np.full((b, K), pi0, dtype=np.float32)
+        vm = np.zeros((b, K), dtype=np.float32)
+        eta, q, ed = (np.zeros(b, dtype=np.float32) for _ in range(3))
+        O.cpp_e_step_mixture(sub.ld_left_bound, sub.ld_indptr, sub.ld_data, inp.std_beta[s:e].copy(), vg, vm, eta, q,
+                             ed, x["log_null_pi"][s:e].copy(), x["u_logs"][s:e].copy(),
+                             x["sqrt_half_var_tau"][s:e].copy(), x["mu_mult"][s:e].copy(), 1.0, 1, False)
+        ref = dict(var_gamma=vg, var_mu=vm, eta=eta, q=q, eta_diff=ed)
+        for k in H.STATE:
+            assert np.array_equal(got[k][s:e], ref[k]), (k, int(bi), b)
+    plan.close()
+
+
+def test_cfg3_grid_full_size_properties(gpu):
+    """BASELINE configs[4] (genome-wide, 32 grid models batched on the matrix cores): run-to-run bit
+    reproducibility, untouched inactive columns, q == (R - I) eta per block and model, the item
+    schedule on the same inputs (bit-identical) and the oracle on a sample of blocks (bit-identical)."""
+    import os
+    from viprs_amd.plan import DeviceState, LDPlan
+    G = 32
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=False)
+    x = syn.make_grid_inputs(ss, G)
+    pi0 = x.pop("pi")
+    active = np.array([g for g in range(G) if g not in (3, 17)], dtype=np.int32)      # 30 of 32 models
+    results = {}
+    for mode in ("1", "0"):
+        os.environ["VIPRS_GRID_MFMA"] = mode
+        try:
+            plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+        finally:
+            os.environ.pop("VIPRS_GRID_MFMA", None)
+        state = DeviceState(plan, "float32", "grid", G)
+        state.upload("std_beta", inp.std_beta)
+        for n, a in x.items():
+            state.upload(n, a)
+        outs = []
+        for _ in range(2 if mode == "1" else 1):
+            state.reset(pi0)
+            state.e_step(ld.dq_scale, active)
+            outs.append({k: state.download(k) for k in H.STATE})
+        if mode == "1":
+            H.assert_state_equal(outs[0], outs[1])
+        results[mode] = outs[0]
+        plan.close()
+    got = results["1"]
+    H.assert_state_equal(got, results["0"])
+    for g in (3, 17):
+        assert np.all(got["eta"][:, g] == 0) and np.all(got["q"][:, g] == 0) and np.all(got["var_gamma"][:, g] == np.float32(pi0))
+    for bi in _block_sample(ld, 2, 1, 2):
+        s, e, b, off, sub = _sub_block(ld, bi)
+        R = ld.ld_data[off:off + b * b].reshape(b, b).astype(np.float64)
+        for g in (0, 31):
+            np.testing.assert_allclose(got["q"][s:e, g], (R - np.eye(b)) @ got["eta"][s:e, g].astype(np.float64),
+                                       rtol=5e-4, atol=5e-6)
+        mk = lambda v: np.asfortranarray(v)
+        vg = mk(np.full((b, G), pi0, dtype=np.float32))
+        vm, eta, q, ed = (mk(np.zeros((b, G), dtype=np.float32)) for _ in range(4))
+        O.cpp_e_step_grid(sub.ld_left_bound, sub.ld_indptr, sub.ld_data, inp.std_beta[s:e].copy(), vg, vm, eta, q, ed,
+                          mk(x["u_logs"][s:e]), mk(x["half_var_tau"][s:e]), mk(x["mu_mult"][s:e]), 1.0, active, 1, False)
+        ref = dict(var_gamma=vg, var_mu=vm, eta=eta, q=q, eta_diff=ed)
+        for k in H.STATE:
+            assert np.array_equal(got[k][s:e], ref[k]), (k, int(bi), b)
