@@ -185,6 +185,10 @@ int viprs_state_prep(viprs_state* state, double logit_pi, double log_tau_beta, d
  * zeta = gamma (mu^2 + 1/var_tau) in float64 (VIPRS.py:896).  Synchronises the plan's stream.      */
 #define VIPRS_N_SUMS 11
 int viprs_state_sums(viprs_state* state, double one_plus_lambda, double* out);
+/* The same in two halves, so that several plans (chromosomes) reduce concurrently: `begin` enqueues the
+ * reduction and an asynchronous copy on the plan's stream, `end` waits for it and returns the sums. */
+int viprs_state_sums_begin(viprs_state* state, double one_plus_lambda);
+int viprs_state_sums_end(viprs_state* state, double* out);
 /* The same two operations on ONE model (column `g`) of a grid state ((m, G) column-major arrays),
  * for the batched grid fit: e_step_grid takes half_var_tau = var_tau / 2 (e_step.hpp:616) where
  * e_step takes its square root, otherwise the formulas are those above.                            */

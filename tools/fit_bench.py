@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Time `VIPRS.fit()` iterations on a synthetic genome-scale data set (development tool).
+
+    python tools/fit_bench.py [--chroms 1] [--iters 30] [--host-mirrored]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from viprs_amd.data import ArrayDataLoader          # noqa: E402
+from viprs_amd.model.VIPRS import VIPRS             # noqa: E402
+from viprs_amd.utils import synthetic as syn        # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--chroms", type=int, default=1, help="split the blocks over this many chromosomes")
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--host-mirrored", action="store_true")
+    args = ap.parse_args()
+    sizes = syn.block_sizes(args.config)
+    parts = np.array_split(np.arange(len(sizes)), args.chroms)
+    gdl = ArrayDataLoader.synthetic({c + 1: sizes[p] for c, p in enumerate(parts)}, forms=("symmetric",))
+    model = VIPRS(gdl, low_memory=False, device_resident=not args.host_mirrored)
+    t0 = time.perf_counter()
+    model.fit(max_iter=3, min_iter=3)                       # warm-up (plans, first launches)
+    t1 = time.perf_counter()
+    model.fit(max_iter=args.iters, min_iter=args.iters, continued=True)
+    t2 = time.perf_counter()
+    n_it = len(model.history["ELBO"]) - 3
+    print(f"{args.config} x{args.chroms} chromosomes, device_resident={not args.host_mirrored}: warm-up {t1 - t0:.2f} s, "
+          f"{(t2 - t1) / max(1, n_it) * 1e3:.3f} ms per EM iteration ({n_it} iterations), ELBO {model.history['ELBO'][-1]:.6g}; {model.optim_result.message}")
+
+
+if __name__ == "__main__":
+    main()

@@ -155,15 +155,22 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
     if (threadIdx.x < kNSums) partials[(int64_t)blockIdx.x * kNSums + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// one wave per sum: lane l adds the partials of blocks l, l + 64, ... in order, then a fixed xor-shuffle
+// tree combines the 64 lanes -- a deterministic order whatever the timing
 __global__ void sums_final_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
-    const int k = threadIdx.x;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= kNSums) return;
+    const bool is_max = (k == kNSums - 1);
     double a = 0.0;
-    for (int b = 0; b < n_blocks; ++b) {
+    for (int b = lane; b < n_blocks; b += 64) {
         const double v = partials[(int64_t)b * kNSums + k];
-        a = (k == kNSums - 1) ? fmax(a, v) : a + v;
+        a = is_max ? fmax(a, v) : a + v;
     }
-    out[k] = a;
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(a, off, 64);
+        a = is_max ? fmax(a, o) : a + o;
+    }
+    if (lane == 0) out[k] = a;
 }
 
 // zeroes the work-queue heads, the skip counter and the team hand-off granules in ONE launch
@@ -239,6 +246,9 @@ struct viprs_state {
     DevBuf<int32_t> d_active;               // grid: active model indices of the current call
     DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
     DevBuf<double> d_n, d_var_tau, d_partials, d_sums;   // device-resident EM iteration
+    double* h_sums = nullptr;               // pinned landing buffer of the device sums
+    bool sums_pending = false, sums_empty = false;
+    ~viprs_state() { if (h_sums) (void)hipHostFree(h_sums); }
     size_t field_elems(int field) const {
         const size_t m = (size_t)plan->m;
         switch (field) {
@@ -663,22 +673,39 @@ static int check_device_error(viprs_plan* P) {
 }
 
 template <typename T>
-static int sums_launch(viprs_state* S, int64_t off, int64_t vt_off, double one_plus_lambda, double* out) {
+static int sums_enqueue(viprs_state* S, int64_t off, int64_t vt_off, double one_plus_lambda) {
     viprs_plan* P = S->plan;
     const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
     if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
     if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
+    if (!S->h_sums) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), kNSums * sizeof(double), hipHostMallocDefault));
     sums_kernel<T><<<nb, kSumsBlock, 0, P->stream>>>(
         P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (const T*)S->f[VIPRS_FIELD_VAR_MU].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA].p + off, (const T*)S->f[VIPRS_FIELD_Q].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, (const T*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p + vt_off,
         one_plus_lambda, S->d_partials.p);
     HIP_TRY(hipGetLastError());
-    sums_final_kernel<<<1, 64, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
+    sums_final_kernel<<<1, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, S->d_sums.p, kNSums * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    // pinned host buffer: the copy is truly asynchronous, several plans' sums overlap
+    HIP_TRY(hipMemcpyAsync(S->h_sums, S->d_sums.p, kNSums * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    S->sums_pending = true;
+    return VIPRS_OK;
+}
+
+static int sums_finish(viprs_state* S, double* out) {
+    viprs_plan* P = S->plan;
+    if (!S->sums_pending) return fail(VIPRS_EINVAL, "no device sums in flight (viprs_state_sums_begin)");
     HIP_TRY(hipStreamSynchronize(P->stream));
+    S->sums_pending = false;
+    for (int k = 0; k < kNSums; ++k) out[k] = S->h_sums[k];
     return check_device_error(P);
+}
+
+template <typename T>
+static int sums_launch(viprs_state* S, int64_t off, int64_t vt_off, double one_plus_lambda, double* out) {
+    const int rc = sums_enqueue<T>(S, off, vt_off, one_plus_lambda);
+    return rc != VIPRS_OK ? rc : sums_finish(S, out);
 }
 
 extern "C" {
@@ -1258,6 +1285,28 @@ int viprs_state_sums(viprs_state* S, double one_plus_lambda, double* out) {
     HIP_TRY(hipSetDevice(P->device));
     return S->float_dtype == VIPRS_F32 ? sums_launch<float>(S, 0, 0, one_plus_lambda, out)
                                        : sums_launch<double>(S, 0, 0, one_plus_lambda, out);
+}
+
+int viprs_state_sums_begin(viprs_state* S, double one_plus_lambda) {
+    if (!S) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EUNSUPPORTED, "device sums: spike-and-slab only");
+    viprs_plan* P = S->plan;
+    if (P->m == 0) { S->sums_pending = false; S->sums_empty = true; return VIPRS_OK; }
+    S->sums_empty = false;
+    if (!S->d_var_tau.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp / viprs_state_prep have not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    return S->float_dtype == VIPRS_F32 ? sums_enqueue<float>(S, 0, 0, one_plus_lambda)
+                                       : sums_enqueue<double>(S, 0, 0, one_plus_lambda);
+}
+
+int viprs_state_sums_end(viprs_state* S, double* out) {
+    if (!S || !out) return fail(VIPRS_EINVAL, "null argument");
+    if (S->sums_empty) {
+        for (int k = 0; k < kNSums; ++k) out[k] = 0.0;
+        return VIPRS_OK;
+    }
+    HIP_TRY(hipSetDevice(S->plan->device));
+    return sums_finish(S, out);
 }
 
 static int grid_column_check(viprs_state* S, int g) {

@@ -381,8 +381,10 @@ class VIPRS:
         if self._resident and self._host_stale:
             s = np.zeros(10, dtype=np.float64)
             self._dev_max_eta_diff = 0.0
-            for c in self.chromosomes:
-                v = self._dstate[c].sums(1.0 + lam)
+            for c in self.chromosomes:               # every chromosome's reduction in flight ...
+                self._dstate[c].sums_begin(1.0 + lam)
+            for c in self.chromosomes:               # ... then collected in order
+                v = self._dstate[c].sums_end()
                 s[0] += v[0] / self.shapes[c]
                 s[1:5] += v[1:5]
                 s[5:9] += v[5:9]

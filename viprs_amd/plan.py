@@ -251,6 +251,16 @@ class DeviceState:
         L.check(L.lib.viprs_state_sums(self._h, float(one_plus_lambda), out))
         return np.array(out[:], dtype=np.float64)
 
+    def sums_begin(self, one_plus_lambda):
+        """Enqueue the reduction (asynchronous); `sums_end` collects it.  Lets several chromosomes reduce
+        concurrently instead of one synchronisation per chromosome."""
+        L.check(L.lib.viprs_state_sums_begin(self._h, float(one_plus_lambda)))
+
+    def sums_end(self):
+        out = (ctypes.c_double * L.N_SUMS)()
+        L.check(L.lib.viprs_state_sums_end(self._h, out))
+        return np.array(out[:], dtype=np.float64)
+
     # -- one model (column) of a grid state -----------------------------------------------------
     def prep_column(self, g, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda):
         L.check(L.lib.viprs_state_prep_column(self._h, int(g), float(logit_pi), float(log_tau_beta),
