@@ -184,6 +184,10 @@ int viprs_state_prep(viprs_state* state, double logit_pi, double log_tau_beta, d
  *   [9] sum g log var_tau  [10] max |eta_diff|
  * zeta = gamma (mu^2 + 1/var_tau) in float64 (VIPRS.py:896).  Synchronises the plan's stream.      */
 #define VIPRS_N_SUMS 11
+/* Optional per-SNP weights (m doubles; NULL clears them) for sum [0]: with several chromosomes merged into one
+ * plan, w_j = 1 / (SNPs of j's chromosome) makes sum [0] the reference's sum of per-chromosome means
+ * (update_pi, VIPRS.py:446-453). */
+int viprs_state_set_snp_weights(viprs_state* state, const double* weights);
 int viprs_state_sums(viprs_state* state, double one_plus_lambda, double* out);
 /* The same in two halves, so that several plans (chromosomes) reduce concurrently: `begin` enqueues the
  * reduction and an asynchronous copy on the plan's stream, `end` waits for it and returns the sums. */

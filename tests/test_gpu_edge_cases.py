@@ -178,6 +178,15 @@ def test_device_resident_fit_equals_host_mirrored_fit(gpu):
     for c in a.chromosomes:
         np.testing.assert_allclose(a.pip[c], b.pip[c], rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(a.post_mean_beta[c], b.post_mean_beta[c], rtol=1e-3, atol=1e-7)
+    # the resident run above keeps both chromosomes in ONE device plan; one plan per chromosome must agree
+    assert a._merged and set(a._dstate) == {"*"}
+    u = VIPRS(gdl, low_memory=True, device_resident=True, merge_chromosomes=False)
+    u.fit(max_iter=40, theta_0={"pi": 0.01, "sigma_epsilon": 0.8})
+    assert not u._merged and u.optim_result.nit == a.optim_result.nit
+    np.testing.assert_allclose(a.history["ELBO"], u.history["ELBO"], rtol=1e-9, atol=1e-4)
+    for c in a.chromosomes:
+        np.testing.assert_allclose(a.pip[c], u.pip[c], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(a.q[c], u.q[c], rtol=1e-4, atol=1e-7)
 
 
 def test_team_handoffs_are_reproducible_under_repetition(gpu):

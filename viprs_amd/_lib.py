@@ -73,6 +73,7 @@ _PROTOS = {
     "viprs_state_synchronize": (_i, [_vp]),
     "viprs_state_set_n_per_snp": (_i, [_vp, _vp]),
     "viprs_state_prep": (_i, [_vp, _d, _d, _d, _d, _d]),
+    "viprs_state_set_snp_weights": (_i, [_vp, _vp]),
     "viprs_state_sums": (_i, [_vp, _d, ctypes.POINTER(_d)]),
     "viprs_state_sums_begin": (_i, [_vp, _d]),
     "viprs_state_sums_end": (_i, [_vp, ctypes.POINTER(_d)]),

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
                                                           const T* __restrict__ eta, const T* __restrict__ q,
                                                           const T* __restrict__ ed, const T* __restrict__ beta,
                                                           const double* __restrict__ var_tau, double one_plus_lambda,
-                                                          double* __restrict__ partials) {
+                                                          const double* __restrict__ weight, double* __restrict__ partials) {
     __shared__ double red[kNSums][kSumsBlock];
     double acc[kNSums];
 #pragma unroll
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
     for (int64_t i = (int64_t)blockIdx.x * kSumsBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kSumsBlock) {
         const double g = (double)gam[i], mud = (double)mu[i], vt = var_tau[i];
         const double zeta = g * (mud * mud + 1.0 / vt);                       // VIPRS.py:896
-        acc[0] += g;
+        acc[0] += weight ? g * weight[i] : g;                                  // sum_c mean(gamma_c) over merged chromosomes
         acc[1] += zeta;
         acc[2] += one_plus_lambda * zeta + (double)(q[i] * eta[i]);        // :455 (q*eta in T, as np.multiply)
         acc[3] += (double)beta[i] * (double)eta[i];
@@ -246,6 +246,7 @@ struct viprs_state {
     DevBuf<int32_t> d_active;               // grid: active model indices of the current call
     DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
     DevBuf<double> d_n, d_var_tau, d_partials, d_sums;   // device-resident EM iteration
+    DevBuf<double> d_weight;                // optional per-SNP weight of sum [0] (several chromosomes in one plan)
     double* h_sums = nullptr;               // pinned landing buffer of the device sums
     bool sums_pending = false, sums_empty = false;
     ~viprs_state() { if (h_sums) (void)hipHostFree(h_sums); }
@@ -678,17 +679,19 @@ static int sums_enqueue(viprs_state* S, int64_t off, int64_t vt_off, double one_
     const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
     if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
     if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
-    if (!S->h_sums) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), kNSums * sizeof(double), hipHostMallocDefault));
+    // pinned landing buffer: kNSums doubles + the plan's device error word (no second synchronisation)
+    if (!S->h_sums) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), (kNSums + 1) * sizeof(double), hipHostMallocDefault));
     sums_kernel<T><<<nb, kSumsBlock, 0, P->stream>>>(
         P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (const T*)S->f[VIPRS_FIELD_VAR_MU].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA].p + off, (const T*)S->f[VIPRS_FIELD_Q].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, (const T*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p + vt_off,
-        one_plus_lambda, S->d_partials.p);
+        one_plus_lambda, (off == 0 && S->d_weight.p) ? S->d_weight.p : nullptr, S->d_partials.p);
     HIP_TRY(hipGetLastError());
     sums_final_kernel<<<1, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
     HIP_TRY(hipGetLastError());
     // pinned host buffer: the copy is truly asynchronous, several plans' sums overlap
     HIP_TRY(hipMemcpyAsync(S->h_sums, S->d_sums.p, kNSums * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(S->h_sums + kNSums, P->d_error.p, sizeof(int32_t), hipMemcpyDeviceToHost, P->stream));
     S->sums_pending = true;
     return VIPRS_OK;
 }
@@ -699,7 +702,9 @@ static int sums_finish(viprs_state* S, double* out) {
     HIP_TRY(hipStreamSynchronize(P->stream));
     S->sums_pending = false;
     for (int k = 0; k < kNSums; ++k) out[k] = S->h_sums[k];
-    return check_device_error(P);
+    int32_t e = 0;
+    memcpy(&e, S->h_sums + kNSums, sizeof(e));
+    return e != 0 ? check_device_error(P) : VIPRS_OK;       // slow path only when a hand-off timed out
 }
 
 template <typename T>
@@ -1249,6 +1254,17 @@ int viprs_state_set_n_per_snp(viprs_state* S, const double* n) {
     HIP_TRY(S->d_var_tau.alloc(m));
     HIP_TRY(hipMemcpy(S->d_n.p, n, m * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(S->d_var_tau.p, 0, m * sizeof(double)));
+    return VIPRS_OK;
+}
+
+int viprs_state_set_snp_weights(viprs_state* S, const double* w) {
+    if (!S) return fail(VIPRS_EINVAL, "null argument");
+    viprs_plan* P = S->plan;
+    HIP_TRY(hipSetDevice(P->device));
+    const size_t m = (size_t)P->m;
+    if (!w || m == 0) { HIP_TRY(S->d_weight.alloc(0)); return VIPRS_OK; }
+    HIP_TRY(S->d_weight.alloc(m));
+    HIP_TRY(hipMemcpy(S->d_weight.p, w, m * sizeof(double), hipMemcpyHostToDevice));
     return VIPRS_OK;
 }
 

@@ -36,7 +36,8 @@ class VIPRS:
 
     def __init__(self, gdl, fix_params=None, tracked_params=None, lambda_min=None, float_precision="float32",
                  order="F", low_memory=True, dequantize_on_the_fly=False, threads=1,
-                 device=None, comm=None, math_mode="exact", e_step_fn=None, device_resident=True):
+                 device=None, comm=None, math_mode="exact", e_step_fn=None, device_resident=True,
+                 merge_chromosomes=True):
         """Same arguments as the reference (VIPRS.py:68-77) plus:
 
         :param device: HIP device index (default: ``comm.rank`` modulo the visible devices).
@@ -47,6 +48,10 @@ class VIPRS:
         :param device_resident: keep the whole EM iteration on the GPU (host prep, zeta, M-step / ELBO
             sums as device kernels; only ~11 scalars per chromosome cross PCIe per iteration).  The
             NumPy state attributes are refreshed when ``fit()`` returns or on ``sync_host()``.
+        :param merge_chromosomes: device-resident mode only -- put the LD blocks of all local chromosomes
+            into ONE device plan (blocks are independent, chromosomes only matter for the ``update_pi``
+            mean, kept through per-SNP weights): one set of launches and one reduction per EM iteration
+            instead of one per chromosome.
         """
         if gdl.genotype is None and (gdl.ld is None or gdl.sumstats_table is None):
             raise AssertionError("The data loader must contain summary statistics and LD matrices.")
@@ -108,15 +113,37 @@ class VIPRS:
             if ndev < 1:
                 raise RuntimeError("VIPRS needs a HIP device: the E-step has no CPU fallback")
             self.device = int(device) if device is not None else self.comm.rank % ndev
-            for c in self.chromosomes:
-                self._plans[c] = LDPlan(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], low_memory,
-                                        device=self.device, math_mode=math_mode)
-                self._dstate[c] = self._make_device_state(self._plans[c])
-                self._dstate[c].upload("std_beta", self.std_beta[c])
-        self._resident = bool(device_resident) and e_step_fn is None and self._supports_resident()
-        if self._resident:
-            for c in self.chromosomes:
-                self._dstate[c].set_n_per_snp(self.n_per_snp[c])
+            self._resident = bool(device_resident) and self._supports_resident()
+            self._merged = (self._resident and bool(merge_chromosomes) and self._supports_merged()
+                            and len(self.chromosomes) > 1)
+            if self._merged:
+                # one plan over the concatenated chromosomes: windows and row offsets shifted into place
+                chroms = self.chromosomes
+                snp_off = np.concatenate([[0], np.cumsum([self.shapes[c] for c in chroms])]).astype(np.int64)
+                nnz_off = np.concatenate([[0], np.cumsum([int(self.ld_indptr[c][-1]) for c in chroms])]).astype(np.int64)
+                self._seg = {c: (int(snp_off[i]), int(snp_off[i + 1])) for i, c in enumerate(chroms)}
+                lb = np.concatenate([np.asarray(self.ld_left_bound[c], dtype=np.int64) + snp_off[i]
+                                     for i, c in enumerate(chroms)]).astype(np.int32)
+                ip = np.concatenate([np.asarray(self.ld_indptr[c][:-1], dtype=np.int64) + nnz_off[i]
+                                     for i, c in enumerate(chroms)] + [nnz_off[-1:]])
+                data = np.concatenate([self.ld_data[c] for c in chroms])
+                self._plans["*"] = LDPlan(lb, ip, data, low_memory, device=self.device, math_mode=math_mode)
+                del data
+                ds = self._dstate["*"] = self._make_device_state(self._plans["*"])
+                ds.upload("std_beta", np.concatenate([self.std_beta[c] for c in chroms]))
+                ds.set_n_per_snp(np.concatenate([np.asarray(self.n_per_snp[c], dtype=np.float64).ravel() for c in chroms]))
+                ds.set_snp_weights(np.concatenate([np.full(self.shapes[c], 1.0 / self.shapes[c]) for c in chroms]))
+            else:
+                for c in self.chromosomes:
+                    self._plans[c] = LDPlan(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], low_memory,
+                                            device=self.device, math_mode=math_mode)
+                    self._dstate[c] = self._make_device_state(self._plans[c])
+                    self._dstate[c].upload("std_beta", self.std_beta[c])
+                if self._resident:
+                    for c in self.chromosomes:
+                        self._dstate[c].set_n_per_snp(self.n_per_snp[c])
+        else:
+            self._resident = self._merged = False
         self._host_stale = False
         self._last_prep = None
 
@@ -154,6 +181,9 @@ class VIPRS:
         return DeviceState(plan, self.float_precision, "spike_slab")
 
     def _supports_resident(self):
+        return True
+
+    def _supports_merged(self):
         return True
 
     # ---- initialisation (VIPRS.py:213-359) -------------------------------------------------------
@@ -246,11 +276,23 @@ class VIPRS:
     _STATE = ("var_gamma", "var_mu", "eta", "q", "eta_diff")
 
     def _push_state(self):
+        if self._merged:
+            ds = self._dstate["*"]
+            for name in self._STATE:
+                ds.upload(name, np.concatenate([np.ascontiguousarray(getattr(self, name)[c]) for c in self.chromosomes]))
+            return
         for c, ds in self._dstate.items():
             for name in self._STATE:
                 ds.upload(name, np.ascontiguousarray(getattr(self, name)[c]))
 
     def _pull_state(self):
+        if self._merged:
+            ds = self._dstate["*"]
+            for name in self._STATE:
+                full = ds.download(name)
+                for c, (a, b) in self._seg.items():
+                    getattr(self, name)[c][...] = full[a:b]
+            return
         for c, ds in self._dstate.items():
             for name in self._STATE:
                 ds.download(name, out=getattr(self, name)[c])
@@ -291,8 +333,7 @@ class VIPRS:
             # whole iteration on the device: prep kernel + sweep per chromosome, nothing crosses PCIe
             pi, tau_beta = self.pi, self.tau_beta
             logit_pi = float(np.log(pi) - np.log(1.0 - pi))          # scalar dtype semantics of VIPRS.py:405
-            for c in self.chromosomes:
-                ds = self._dstate[c]
+            for ds in self._dstate.values():         # one plan per chromosome, or one for all of them
                 ds.prep(logit_pi, float(np.log(tau_beta)), self.sigma_epsilon, tau_beta, 1.0 + self.lambda_min)
                 ds.e_step(self.dequantize_scale, sync=False)
             self._last_prep = (self.sigma_epsilon, tau_beta, self.lambda_min)
@@ -381,11 +422,11 @@ class VIPRS:
         if self._resident and self._host_stale:
             s = np.zeros(10, dtype=np.float64)
             self._dev_max_eta_diff = 0.0
-            for c in self.chromosomes:               # every chromosome's reduction in flight ...
-                self._dstate[c].sums_begin(1.0 + lam)
-            for c in self.chromosomes:               # ... then collected in order
-                v = self._dstate[c].sums_end()
-                s[0] += v[0] / self.shapes[c]
+            for ds in self._dstate.values():         # every plan's reduction in flight ...
+                ds.sums_begin(1.0 + lam)
+            for c, ds in self._dstate.items():       # ... then collected in order
+                v = ds.sums_end()
+                s[0] += v[0] if self._merged else v[0] / self.shapes[c]     # merged: weights 1 / m_c on the device
                 s[1:5] += v[1:5]
                 s[5:9] += v[5:9]
                 s[9] += v[9]

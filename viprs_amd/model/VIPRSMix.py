@@ -33,6 +33,9 @@ class VIPRSMix(VIPRS):
     def _supports_resident(self):
         return False          # mixture M-step sums still run on the host
 
+    def _supports_merged(self):
+        return False
+
     # ---- hyper-parameter initialisation (VIPRSMix.py:60-167) --------------------------------------
     def initialize_theta(self, theta_0=None):
         th = self._merge_theta(theta_0)

@@ -35,6 +35,9 @@ class VIPRSGrid(VIPRS):
         super().__init__(gdl, **kwargs)
         self._grid_state = {}
 
+    def _supports_merged(self):
+        return False          # the grid state is built per chromosome plan (self._plans[c])
+
     # ---- bookkeeping (VIPRSGrid.py:65-126) --------------------------------------------------------
     @property
     def converged_models(self):

@@ -239,6 +239,17 @@ class DeviceState:
             raise ValueError(f"n_per_snp: expected shape ({self.plan.m},), got {n.shape}")
         L.check(L.lib.viprs_state_set_n_per_snp(self._h, _ptr(n)))
 
+    def set_snp_weights(self, weights):
+        """Per-SNP weights of sum [0] (None clears): 1 / (SNPs of the chromosome) when several chromosomes
+        share this plan, so that sum [0] is the reference's sum of per-chromosome means of gamma."""
+        if weights is None:
+            L.check(L.lib.viprs_state_set_snp_weights(self._h, None))
+            return
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if w.shape != (self.plan.m,):
+            raise ValueError(f"weights: expected shape ({self.plan.m},), got {w.shape}")
+        L.check(L.lib.viprs_state_set_snp_weights(self._h, _ptr(w)))
+
     def prep(self, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda):
         """VIPRS.py:400-418 on the device (asynchronous on the plan's stream).  The scalars are
         evaluated by the caller (reference dtype semantics)."""
