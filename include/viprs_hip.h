@@ -199,6 +199,14 @@ int viprs_state_sums_end(viprs_state* state, double* out);
 int viprs_state_prep_column(viprs_state* state, int g, double logit_pi, double log_tau_beta, double sigma_epsilon,
                             double tau_beta, double one_plus_lambda);
 int viprs_state_sums_column(viprs_state* state, int g, double one_plus_lambda, double* out);
+/* Several models per launch (the batched grid fit touches every active model in every EM iteration):
+ *   params : n rows of 6 doubles  (column, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda)
+ *   cols   : n rows of 2 doubles  (column, one_plus_lambda)
+ *   out    : n rows of VIPRS_N_SUMS doubles, in the order of `cols`
+ * `begin` is asynchronous on the plan's stream, `end` waits for it. */
+int viprs_state_prep_columns(viprs_state* state, int n, const double* params);
+int viprs_state_sums_columns_begin(viprs_state* state, int n, const double* cols);
+int viprs_state_sums_columns_end(viprs_state* state, double* out);
 /* Per-column re-initialisation of a grid state: var_gamma[:, g] = pi_g, everything else 0.         */
 int viprs_state_reset_column(viprs_state* state, int g, double pi);
 

@@ -22,10 +22,25 @@ def main():
     ap.add_argument("--chroms", type=int, default=1, help="split the blocks over this many chromosomes")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--host-mirrored", action="store_true")
+    ap.add_argument("--grid", type=int, default=0, help="batched grid fit (VIPRSGrid) with this many (pi, sigma_epsilon) points")
     args = ap.parse_args()
     sizes = syn.block_sizes(args.config)
     parts = np.array_split(np.arange(len(sizes)), args.chroms)
     gdl = ArrayDataLoader.synthetic({c + 1: sizes[p] for c, p in enumerate(parts)}, forms=("symmetric",))
+    if args.grid:
+        from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+        from viprs_amd.model.gridsearch.VIPRSGrid import VIPRSGrid
+        side = max(2, int(round(args.grid ** 0.5)))
+        grid = HyperparameterGrid(n_snps=gdl.m)
+        grid.generate_pi_grid(steps=(args.grid + side - 1) // side)
+        grid.generate_sigma_epsilon_grid(steps=side)
+        model = VIPRSGrid(gdl, grid, low_memory=False)
+        t0 = time.perf_counter()
+        model.fit(max_iter=args.iters, min_iter=args.iters, batched=True)
+        t1 = time.perf_counter()
+        print(f"{args.config} x{args.chroms} chromosomes, batched grid fit of {model.n_models} models: "
+              f"{(t1 - t0) / args.iters * 1e3:.3f} ms per EM iteration incl. set-up ({args.iters} iterations)")
+        return
     model = VIPRS(gdl, low_memory=False, device_resident=not args.host_mirrored)
     t0 = time.perf_counter()
     model.fit(max_iter=3, min_iter=3)                       # warm-up (plans, first launches)

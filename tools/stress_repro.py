@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Stress: N sweeps of the spike-and-slab E-step on cfg3 from the same start must be bit-identical
+(development tool; reports the blocks whose state differs from the first sweep)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from viprs_amd.plan import DeviceState, LDPlan          # noqa: E402
+from viprs_amd.utils import synthetic as syn            # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+low_memory = "--low-memory" in sys.argv
+ld, ss, inp = syn.make_problem("cfg3", low_memory=low_memory)
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory)
+st = DeviceState(plan)
+for k in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+    st.upload(k, getattr(inp, k))
+ref = None
+bad = 0
+for i in range(n):
+    st.reset(inp.pi)
+    st.e_step(ld.dq_scale)
+    out = {k: st.download(k) for k in ("var_gamma", "var_mu", "eta", "q", "eta_diff")}
+    if ref is None:
+        ref = out
+        continue
+    diff = np.zeros(ld.m, bool)
+    for k in out:
+        diff |= out[k] != ref[k]
+    if diff.any():
+        bad += 1
+        blocks = np.unique(np.searchsorted(ld.block_start, np.nonzero(diff)[0], side="right") - 1)
+        sizes = np.diff(ld.block_start)[blocks]
+        first = np.nonzero(diff)[0][:5]
+        print(f"sweep {i}: {int(diff.sum())} SNPs differ in blocks {blocks[:8]} (sizes {sizes[:8]}); first SNPs {first}; "
+              f"q there {out['q'][first]} vs {ref['q'][first]}", flush=True)
+print(f"{bad} of {n - 1} sweeps differ from the first")

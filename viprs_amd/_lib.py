@@ -79,6 +79,9 @@ _PROTOS = {
     "viprs_state_sums_end": (_i, [_vp, ctypes.POINTER(_d)]),
     "viprs_state_prep_column": (_i, [_vp, _i, _d, _d, _d, _d, _d]),
     "viprs_state_sums_column": (_i, [_vp, _i, _d, ctypes.POINTER(_d)]),
+    "viprs_state_prep_columns": (_i, [_vp, _i, _vp]),
+    "viprs_state_sums_columns_begin": (_i, [_vp, _i, _vp]),
+    "viprs_state_sums_columns_end": (_i, [_vp, _vp]),
     "viprs_state_reset_column": (_i, [_vp, _i, _d]),
     "viprs_plan_last_kernel_ms": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "viprs_plan_last_skipped": (_i, [_vp, _pi64]),

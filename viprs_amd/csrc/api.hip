@@ -109,6 +109,24 @@ __global__ void prep_kernel(const double* __restrict__ n, int64_t m, double logi
     shvt[i] = half_not_sqrt ? (T)(0.5 * vt) : (T)sqrt(0.5 * vt);     // e_step_grid takes var_tau / 2 (e_step.hpp:616)
 }
 
+// the same for several columns of a grid state in one launch: blockIdx.y picks a row of `params`
+// (column, logit_pi, log_tau_beta, sigma_eps, tau_beta, one_plus_lambda)
+template <typename T>
+__global__ void prep_columns_kernel(const double* __restrict__ n, int64_t m, const double* __restrict__ params,
+                                    T* __restrict__ mu_mult, T* __restrict__ u_logs, T* __restrict__ shvt,
+                                    double* __restrict__ var_tau_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double* __restrict__ p = params + 6 * (int64_t)blockIdx.y;
+    const int64_t off = (int64_t)p[0] * m;
+    const double logit_pi = p[1], log_tau_beta = p[2], sigma_eps = p[3], tau_beta = p[4], one_plus_lambda = p[5];
+    const double vt = n[i] * one_plus_lambda / sigma_eps + tau_beta;
+    var_tau_out[off + i] = vt;
+    mu_mult[off + i] = (T)(n[i] / (vt * sigma_eps));
+    u_logs[off + i] = (T)(logit_pi + 0.5 * (log_tau_beta - log(vt)));
+    shvt[off + i] = (T)(0.5 * vt);                                    // e_step_grid takes var_tau / 2 (e_step.hpp:616)
+}
+
 constexpr int kSumsBlock = 256;
 constexpr int kNSums = VIPRS_N_SUMS;
 
@@ -119,7 +137,15 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
                                                           const T* __restrict__ eta, const T* __restrict__ q,
                                                           const T* __restrict__ ed, const T* __restrict__ beta,
                                                           const double* __restrict__ var_tau, double one_plus_lambda,
-                                                          const double* __restrict__ weight, double* __restrict__ partials) {
+                                                          const double* __restrict__ weight, double* __restrict__ partials,
+                                                          const double* __restrict__ cols = nullptr) {
+    if (cols) {
+        // several columns of a grid state in one launch: blockIdx.y picks (column, one_plus_lambda)
+        const int64_t off = (int64_t)cols[2 * blockIdx.y] * m;
+        one_plus_lambda = cols[2 * blockIdx.y + 1];
+        gam += off; mu += off; eta += off; q += off; ed += off; var_tau += off;
+        partials += (int64_t)blockIdx.y * gridDim.x * kNSums;
+    }
     __shared__ double red[kNSums][kSumsBlock];
     double acc[kNSums];
 #pragma unroll
@@ -158,6 +184,8 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
 // one wave per sum: lane l adds the partials of blocks l, l + 64, ... in order, then a fixed xor-shuffle
 // tree combines the 64 lanes -- a deterministic order whatever the timing
 __global__ void sums_final_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
+    partials += (int64_t)blockIdx.x * n_blocks * kNSums;            // one workgroup per column (grid states)
+    out += (int64_t)blockIdx.x * kNSums;
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= kNSums) return;
     const bool is_max = (k == kNSums - 1);
@@ -247,9 +275,18 @@ struct viprs_state {
     DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
     DevBuf<double> d_n, d_var_tau, d_partials, d_sums;   // device-resident EM iteration
     DevBuf<double> d_weight;                // optional per-SNP weight of sum [0] (several chromosomes in one plan)
+    DevBuf<double> d_colparams, d_sumcols;  // grid: per-column parameters of the batched prep / of the batched sums
+    int sums_cols = 0;                      // columns of the reduction in flight (grid: sums_columns_begin)
+    size_t h_sums_cap = 0;
     double* h_sums = nullptr;               // pinned landing buffer of the device sums
     bool sums_pending = false, sums_empty = false;
-    ~viprs_state() { if (h_sums) (void)hipHostFree(h_sums); }
+    hipEvent_t ev_prep = nullptr;           // the last batched prep launch (it reads d_colparams)
+    double* h_params = nullptr;             // pinned staging of the batched prep (6 x width) / sums (2 x width) parameters
+    ~viprs_state() {
+        if (h_sums) (void)hipHostFree(h_sums);
+        if (h_params) (void)hipHostFree(h_params);
+        if (ev_prep) (void)hipEventDestroy(ev_prep);
+    }
     size_t field_elems(int field) const {
         const size_t m = (size_t)plan->m;
         switch (field) {
@@ -534,6 +571,9 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
         // raw copy no longer needed: every block was repacked
         HIP_TRY(P->d_ld_raw.alloc(0));
     }
+    // every copy / memset above went through the null stream; the plan's own streams are non-blocking
+    // (not ordered with it), so nothing may still be in flight when the first sweep is launched
+    HIP_TRY(hipDeviceSynchronize());
     *out = P.release();
     return VIPRS_OK;
 }
@@ -602,8 +642,11 @@ int viprs_state_create(viprs_state** out, viprs_plan* plan, int float_dtype, int
     for (int k = 0; k < VIPRS_FIELD_COUNT; ++k) {
         const size_t bytes = S->field_elems(k) * float_size(float_dtype);
         HIP_TRY(S->f[k].alloc(bytes));
-        if (bytes) HIP_TRY(hipMemset(S->f[k].p, 0, bytes));
+        // on the plan's stream (non-blocking: the null stream is NOT ordered with it -- a late null-stream
+        // memset would wipe data uploaded in the meantime)
+        if (bytes) HIP_TRY(hipMemsetAsync(S->f[k].p, 0, bytes, plan->stream));
     }
+    HIP_TRY(hipStreamSynchronize(plan->stream));
     *out = S.release();
     return VIPRS_OK;
 }
@@ -667,7 +710,8 @@ static int check_device_error(viprs_plan* P) {
     int32_t e = 0;
     HIP_TRY(hipMemcpy(&e, P->d_error.p, sizeof(e), hipMemcpyDeviceToHost));
     if (e != 0) {
-        HIP_TRY(hipMemset(P->d_error.p, 0, sizeof(e)));
+        HIP_TRY(hipMemsetAsync(P->d_error.p, 0, sizeof(e), P->stream));
+        HIP_TRY(hipStreamSynchronize(P->stream));
         return fail(VIPRS_EDEVICE, "E-step kernel: a team hand-off timed out (results of this sweep are invalid)");
     }
     return VIPRS_OK;
@@ -680,7 +724,10 @@ static int sums_enqueue(viprs_state* S, int64_t off, int64_t vt_off, double one_
     if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
     if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
     // pinned landing buffer: kNSums doubles + the plan's device error word (no second synchronisation)
-    if (!S->h_sums) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), (kNSums + 1) * sizeof(double), hipHostMallocDefault));
+    if (!S->h_sums) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), (kNSums + 1) * sizeof(double), hipHostMallocDefault));
+        S->h_sums_cap = kNSums + 1;
+    }
     sums_kernel<T><<<nb, kSumsBlock, 0, P->stream>>>(
         P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (const T*)S->f[VIPRS_FIELD_VAR_MU].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA].p + off, (const T*)S->f[VIPRS_FIELD_Q].p + off,
@@ -711,6 +758,34 @@ template <typename T>
 static int sums_launch(viprs_state* S, int64_t off, int64_t vt_off, double one_plus_lambda, double* out) {
     const int rc = sums_enqueue<T>(S, off, vt_off, one_plus_lambda);
     return rc != VIPRS_OK ? rc : sums_finish(S, out);
+}
+
+template <typename T>
+static int sums_columns_enqueue(viprs_state* S, int n) {
+    viprs_plan* P = S->plan;
+    const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 256);
+    const size_t need = (size_t)nb * kNSums * n;
+    if (S->d_partials.n < need) HIP_TRY(S->d_partials.alloc(need));
+    if (S->d_sums.n < (size_t)kNSums * S->width) HIP_TRY(S->d_sums.alloc((size_t)kNSums * S->width));
+    const size_t hcap = (size_t)kNSums * S->width + 1;
+    if (S->h_sums_cap < hcap) {
+        if (S->h_sums) HIP_TRY(hipHostFree(S->h_sums));
+        S->h_sums = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), hcap * sizeof(double), hipHostMallocDefault));
+        S->h_sums_cap = hcap;
+    }
+    sums_kernel<T><<<dim3(nb, n), kSumsBlock, 0, P->stream>>>(
+        P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const T*)S->f[VIPRS_FIELD_VAR_MU].p, (const T*)S->f[VIPRS_FIELD_ETA].p,
+        (const T*)S->f[VIPRS_FIELD_Q].p, (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const T*)S->f[VIPRS_FIELD_STD_BETA].p,
+        S->d_var_tau.p, 0.0, nullptr, S->d_partials.p, S->d_sumcols.p);
+    HIP_TRY(hipGetLastError());
+    sums_final_kernel<<<n, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(S->h_sums, S->d_sums.p, (size_t)kNSums * n * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(S->h_sums + (size_t)kNSums * n, P->d_error.p, sizeof(int32_t), hipMemcpyDeviceToHost, P->stream));
+    S->sums_cols = n;
+    S->sums_pending = true;
+    return VIPRS_OK;
 }
 
 extern "C" {
@@ -890,7 +965,8 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
             }
             while (r < grid) th[(size_t)r++] = A.n_blocks;
             HIP_TRY(P->d_admit.alloc((size_t)grid));
-            HIP_TRY(hipMemcpy(P->d_admit.p, th.data(), sizeof(int32_t) * (size_t)grid, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(P->d_admit.p, th.data(), sizeof(int32_t) * (size_t)grid, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));         // one-time set-up; `th` is a local buffer
             P->admit_grid = grid;
         }
         A.admit = P->d_admit.p;
@@ -1252,8 +1328,9 @@ int viprs_state_set_n_per_snp(viprs_state* S, const double* n) {
     if (m == 0) return VIPRS_OK;
     HIP_TRY(S->d_n.alloc(m));
     HIP_TRY(S->d_var_tau.alloc(m));
-    HIP_TRY(hipMemcpy(S->d_n.p, n, m * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(S->d_var_tau.p, 0, m * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(S->d_n.p, n, m * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    HIP_TRY(hipMemsetAsync(S->d_var_tau.p, 0, m * sizeof(double), P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
     return VIPRS_OK;
 }
 
@@ -1264,7 +1341,8 @@ int viprs_state_set_snp_weights(viprs_state* S, const double* w) {
     const size_t m = (size_t)P->m;
     if (!w || m == 0) { HIP_TRY(S->d_weight.alloc(0)); return VIPRS_OK; }
     HIP_TRY(S->d_weight.alloc(m));
-    HIP_TRY(hipMemcpy(S->d_weight.p, w, m * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(S->d_weight.p, w, m * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
     return VIPRS_OK;
 }
 
@@ -1360,6 +1438,78 @@ int viprs_state_prep_column(viprs_state* S, int g, double logit_pi, double log_t
                                                          S->d_var_tau.p + off, 1);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
+}
+
+int viprs_state_prep_columns(viprs_state* S, int n, const double* params) {
+    if (!S || !params) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_GRID) return fail(VIPRS_EINVAL, "not a grid state");
+    if (n < 0 || n > S->width) return fail(VIPRS_EINVAL, "bad column count");
+    for (int i = 0; i < n; ++i)
+        if (params[6 * i] < 0 || params[6 * i] >= S->width || params[6 * i] != floor(params[6 * i]))
+            return fail(VIPRS_EINVAL, "model index out of range");
+    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    viprs_plan* P = S->plan;
+    if (P->m == 0 || n == 0) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    if (S->d_var_tau.n < (size_t)P->m * S->width) HIP_TRY(S->d_var_tau.alloc((size_t)P->m * S->width));
+    if (S->d_colparams.n < (size_t)6 * S->width) HIP_TRY(S->d_colparams.alloc((size_t)6 * S->width));
+    if (!S->h_params) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_params), (size_t)8 * S->width * sizeof(double), hipHostMallocDefault));
+    if (!S->ev_prep) HIP_TRY(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(S->ev_prep));            // the previous launch has read its parameters
+    memcpy(S->h_params, params, (size_t)6 * n * sizeof(double));
+    // pinned staging + copy ON the plan's stream: ordered with the kernel below (the null stream is not)
+    HIP_TRY(hipMemcpyAsync(S->d_colparams.p, S->h_params, (size_t)6 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    const dim3 grid((unsigned)((P->m + 255) / 256), (unsigned)n);
+    if (S->float_dtype == VIPRS_F32)
+        prep_columns_kernel<float><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, S->d_colparams.p,
+                                                                (float*)S->f[VIPRS_FIELD_MU_MULT].p, (float*)S->f[VIPRS_FIELD_U_LOGS].p,
+                                                                (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+    else
+        prep_columns_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, S->d_colparams.p,
+                                                                 (double*)S->f[VIPRS_FIELD_MU_MULT].p, (double*)S->f[VIPRS_FIELD_U_LOGS].p,
+                                                                 (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(S->ev_prep, P->stream));
+    return VIPRS_OK;
+}
+
+int viprs_state_sums_columns_begin(viprs_state* S, int n, const double* cols) {
+    if (!S || !cols) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_GRID) return fail(VIPRS_EINVAL, "not a grid state");
+    if (n < 0 || n > S->width) return fail(VIPRS_EINVAL, "bad column count");
+    for (int i = 0; i < n; ++i)
+        if (cols[2 * i] < 0 || cols[2 * i] >= S->width || cols[2 * i] != floor(cols[2 * i]))
+            return fail(VIPRS_EINVAL, "model index out of range");
+    viprs_plan* P = S->plan;
+    S->sums_cols = n;
+    if (P->m == 0 || n == 0) { S->sums_pending = false; S->sums_empty = true; return VIPRS_OK; }
+    S->sums_empty = false;
+    if (S->d_var_tau.n < (size_t)P->m * S->width) return fail(VIPRS_EINVAL, "viprs_state_prep_column(s) has not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    // (own buffer: the previous reduction that read it has been collected, nothing else does)
+    if (S->d_sumcols.n < (size_t)2 * S->width) HIP_TRY(S->d_sumcols.alloc((size_t)2 * S->width));
+    if (!S->h_params) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_params), (size_t)8 * S->width * sizeof(double), hipHostMallocDefault));
+    memcpy(S->h_params + (size_t)6 * S->width, cols, (size_t)2 * n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(S->d_sumcols.p, S->h_params + (size_t)6 * S->width, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    return S->float_dtype == VIPRS_F32 ? sums_columns_enqueue<float>(S, n) : sums_columns_enqueue<double>(S, n);
+}
+
+int viprs_state_sums_columns_end(viprs_state* S, double* out) {
+    if (!S || !out) return fail(VIPRS_EINVAL, "null argument");
+    const int n = S->sums_cols;
+    if (S->sums_empty) {
+        for (int k = 0; k < kNSums * n; ++k) out[k] = 0.0;
+        return VIPRS_OK;
+    }
+    if (!S->sums_pending) return fail(VIPRS_EINVAL, "no device sums in flight (viprs_state_sums_columns_begin)");
+    viprs_plan* P = S->plan;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    S->sums_pending = false;
+    for (int k = 0; k < kNSums * n; ++k) out[k] = S->h_sums[k];
+    int32_t e = 0;
+    memcpy(&e, S->h_sums + (size_t)kNSums * n, sizeof(e));
+    return e != 0 ? check_device_error(P) : VIPRS_OK;
 }
 
 int viprs_state_sums_column(viprs_state* S, int g, double one_plus_lambda, double* out) {

@@ -146,14 +146,22 @@ class VIPRSGrid(VIPRS):
                 st.reset_column(g, float(th[g]["pi"]))
             states[c] = st
 
-        def sums(g):
-            s = np.zeros(11)
+        def prep_rows(models):
+            return np.array([[g, float(np.log(th[g]["pi"]) - np.log(1.0 - th[g]["pi"])), float(np.log(th[g]["tau_beta"])),
+                              th[g]["sigma_epsilon"], th[g]["tau_beta"], 1.0 + th[g]["lam"]] for g in models], dtype=np.float64)
+
+        def all_sums(models):
+            """{g: 11 sums} for the given models: one batched reduction per chromosome, all in flight at once"""
+            lam1 = np.array([1.0 + th[g]["lam"] for g in models])
             for c in self.chromosomes:
-                v = states[c].sums_column(g, 1.0 + th[g]["lam"])
-                s[0] += v[0] / self.shapes[c]
-                s[1:10] += v[1:10]
-                s[10] = max(s[10], v[10])
-            return s
+                states[c].sums_columns_begin(models, lam1)
+            tot = np.zeros((len(models), 11))
+            for c in self.chromosomes:
+                v = states[c].sums_columns_end()
+                tot[:, 0] += v[:, 0] / self.shapes[c]
+                tot[:, 1:10] += v[:, 1:10]
+                tot[:, 10] = np.maximum(tot[:, 10], v[:, 10])
+            return {int(g): tot[k] for k, g in enumerate(models)}
 
         def elbo(g, s, sigma_g):
             p = th[g]
@@ -177,11 +185,8 @@ class VIPRSGrid(VIPRS):
         dropping = [ConditionStreak() for _ in range(G)]
         elbos = np.zeros(G)
         active = np.arange(G, dtype=np.int32)
-        for g in range(G):                       # initial ELBO needs var_tau of the initial hyper-parameters
-            p = th[g]
-            for c in self.chromosomes:
-                states[c].prep_column(g, float(np.log(p["pi"]) - np.log(1.0 - p["pi"])), float(np.log(p["tau_beta"])),
-                                      p["sigma_epsilon"], p["tau_beta"], 1.0 + p["lam"])
+        for c in self.chromosomes:               # initial ELBO needs var_tau of the initial hyper-parameters
+            states[c].prep_columns(prep_rows(range(G)))
 
         for i in range(1, max_iter + 1):
             if active.size == 0:
@@ -189,15 +194,14 @@ class VIPRSGrid(VIPRS):
             for g in active:
                 p = th[g]
                 p["sigma_epsilon_e"], p["tau_beta_e"] = p["sigma_epsilon"], p["tau_beta"]   # what var_tau is built from
-                for c in self.chromosomes:
-                    states[c].prep_column(g, float(np.log(p["pi"]) - np.log(1.0 - p["pi"])),
-                                          float(np.log(p["tau_beta"])), p["sigma_epsilon"], p["tau_beta"],
-                                          1.0 + p["lam"])
-            for c in self.chromosomes:
+            rows = prep_rows(active)
+            for c in self.chromosomes:               # one prep launch, one sweep and one reduction per chromosome
+                states[c].prep_columns(rows)
                 states[c].e_step(self.dequantize_scale, active_model_idx=active, sync=False)
+            sums_of = all_sums(active)
             still = []
             for g in active:
-                p, s = th[g], sums(g)
+                p, s = th[g], sums_of[int(g)]
                 if "pi" not in p["fixed"]:                                   # VIPRS.m_step, per model
                     p["pi"] = T.type(s[0] / self._n_chroms_total)
                 if "tau_beta" not in p["fixed"]:

@@ -282,6 +282,24 @@ class DeviceState:
         L.check(L.lib.viprs_state_sums_column(self._h, int(g), float(one_plus_lambda), out))
         return np.array(out[:], dtype=np.float64)
 
+    def prep_columns(self, params):
+        """`prep_column` for several models in one launch: rows (column, logit_pi, log_tau_beta,
+        sigma_epsilon, tau_beta, one_plus_lambda)."""
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 6)
+        L.check(L.lib.viprs_state_prep_columns(self._h, int(p.shape[0]), _ptr(p)))
+
+    def sums_columns_begin(self, cols, one_plus_lambda):
+        c = np.ascontiguousarray(np.column_stack([np.asarray(cols, dtype=np.float64),
+                                                  np.broadcast_to(np.asarray(one_plus_lambda, dtype=np.float64),
+                                                                  (len(cols),))]))
+        self._n_sum_cols = int(c.shape[0])
+        L.check(L.lib.viprs_state_sums_columns_begin(self._h, self._n_sum_cols, _ptr(c)))
+
+    def sums_columns_end(self):
+        out = np.zeros((self._n_sum_cols, L.N_SUMS), dtype=np.float64)
+        L.check(L.lib.viprs_state_sums_columns_end(self._h, _ptr(out)))
+        return out
+
     def reset_column(self, g, pi):
         L.check(L.lib.viprs_state_reset_column(self._h, int(g), float(pi)))
 
