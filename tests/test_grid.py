@@ -119,3 +119,30 @@ def test_posterior_table_and_pseudo_validation_cpu():
     t1 = single.to_table()
     assert {"BETA", "PIP", "VAR_BETA"} <= set(t1.columns)
     assert np.isscalar(float(single.pseudo_validate(vb)))
+
+
+@pytest.mark.gpu
+def test_batched_grid_fit_merged_chromosomes_equals_per_chromosome_plans(gpu):
+    """Several chromosomes: the batched fit on ONE merged device plan (default) and on one plan per
+    chromosome end at the same models."""
+    from viprs_amd.data import ArrayDataLoader
+    from viprs_amd.model import VIPRSGrid
+    from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+    gdl = ArrayDataLoader.synthetic({20: [150, 90], 21: [210, 64, 33], 22: [400]}, seed=91, forms=("upper",))
+    grid = HyperparameterGrid(n_snps=gdl.m)
+    grid.generate_pi_grid(steps=3)
+    grid.generate_sigma_epsilon_grid(steps=2)
+    runs = []
+    for merge in (True, False):
+        m = VIPRSGrid(gdl, grid, low_memory=True, merge_chromosomes=merge)
+        m.fit(batched=True, max_iter=60)
+        runs.append(m)
+    a, b = runs
+    assert a._merged and not b._merged and set(a._grid_state) == {"*"} and set(b._grid_state) == {20, 21, 22}
+    ea = a.to_validation_table()["ELBO"].to_numpy().astype(np.float64)
+    eb = b.to_validation_table()["ELBO"].to_numpy().astype(np.float64)
+    np.testing.assert_allclose(ea, eb, rtol=1e-7, atol=1e-3)
+    for c in a.chromosomes:
+        np.testing.assert_allclose(a.pip[c], b.pip[c], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(a.post_mean_beta[c], b.post_mean_beta[c], rtol=1e-4, atol=1e-7)
+        assert a.eta_diff[c].shape == b.eta_diff[c].shape

@@ -732,7 +732,7 @@ static int sums_enqueue(viprs_state* S, int64_t off, int64_t vt_off, double one_
         P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p + off, (const T*)S->f[VIPRS_FIELD_VAR_MU].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA].p + off, (const T*)S->f[VIPRS_FIELD_Q].p + off,
         (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, (const T*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p + vt_off,
-        one_plus_lambda, (off == 0 && S->d_weight.p) ? S->d_weight.p : nullptr, S->d_partials.p);
+        one_plus_lambda, S->d_weight.p, S->d_partials.p);
     HIP_TRY(hipGetLastError());
     sums_final_kernel<<<1, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
     HIP_TRY(hipGetLastError());
@@ -777,7 +777,7 @@ static int sums_columns_enqueue(viprs_state* S, int n) {
     sums_kernel<T><<<dim3(nb, n), kSumsBlock, 0, P->stream>>>(
         P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const T*)S->f[VIPRS_FIELD_VAR_MU].p, (const T*)S->f[VIPRS_FIELD_ETA].p,
         (const T*)S->f[VIPRS_FIELD_Q].p, (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const T*)S->f[VIPRS_FIELD_STD_BETA].p,
-        S->d_var_tau.p, 0.0, nullptr, S->d_partials.p, S->d_sumcols.p);
+        S->d_var_tau.p, 0.0, S->d_weight.p, S->d_partials.p, S->d_sumcols.p);
     HIP_TRY(hipGetLastError());
     sums_final_kernel<<<n, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
     HIP_TRY(hipGetLastError());

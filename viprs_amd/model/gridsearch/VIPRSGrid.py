@@ -35,8 +35,8 @@ class VIPRSGrid(VIPRS):
         super().__init__(gdl, **kwargs)
         self._grid_state = {}
 
-    def _supports_merged(self):
-        return False          # the grid state is built per chromosome plan (self._plans[c])
+    # (VIPRS puts all local chromosomes into one device plan -- key "*" of self._plans; the batched fit
+    #  below builds its (m, G) grid state on whatever plans there are)
 
     # ---- bookkeeping (VIPRSGrid.py:65-126) --------------------------------------------------------
     @property
@@ -136,15 +136,22 @@ class VIPRSGrid(VIPRS):
                            lam=self.lambda_min, fixed=set(params[g])))
         self.fix_params = {}
         states = {}
-        for c in self.chromosomes:
-            st = self._grid_state.get(c)
+        merged = getattr(self, "_merged", False)
+        chroms = self.chromosomes
+        for key, plan in self._plans.items():       # one plan per chromosome, or "*" = all of them concatenated
+            st = self._grid_state.get(key)
             if st is None:
-                st = self._grid_state[c] = DeviceState(self._plans[c], self.float_precision, "grid", G)
-                st.upload("std_beta", self.std_beta[c])
-                st.set_n_per_snp(self.n_per_snp[c])
+                st = self._grid_state[key] = DeviceState(plan, self.float_precision, "grid", G)
+                if merged:
+                    st.upload("std_beta", np.concatenate([self.std_beta[c] for c in chroms]))
+                    st.set_n_per_snp(np.concatenate([np.asarray(self.n_per_snp[c], dtype=np.float64).ravel() for c in chroms]))
+                    st.set_snp_weights(np.concatenate([np.full(self.shapes[c], 1.0 / self.shapes[c]) for c in chroms]))
+                else:
+                    st.upload("std_beta", self.std_beta[key])
+                    st.set_n_per_snp(self.n_per_snp[key])
             for g in range(G):
                 st.reset_column(g, float(th[g]["pi"]))
-            states[c] = st
+            states[key] = st
 
         def prep_rows(models):
             return np.array([[g, float(np.log(th[g]["pi"]) - np.log(1.0 - th[g]["pi"])), float(np.log(th[g]["tau_beta"])),
@@ -153,12 +160,12 @@ class VIPRSGrid(VIPRS):
         def all_sums(models):
             """{g: 11 sums} for the given models: one batched reduction per chromosome, all in flight at once"""
             lam1 = np.array([1.0 + th[g]["lam"] for g in models])
-            for c in self.chromosomes:
-                states[c].sums_columns_begin(models, lam1)
+            for st in states.values():
+                st.sums_columns_begin(models, lam1)
             tot = np.zeros((len(models), 11))
-            for c in self.chromosomes:
-                v = states[c].sums_columns_end()
-                tot[:, 0] += v[:, 0] / self.shapes[c]
+            for key, st in states.items():
+                v = st.sums_columns_end()
+                tot[:, 0] += v[:, 0] if merged else v[:, 0] / self.shapes[key]      # merged: weights 1 / m_c on the device
                 tot[:, 1:10] += v[:, 1:10]
                 tot[:, 10] = np.maximum(tot[:, 10], v[:, 10])
             return {int(g): tot[k] for k, g in enumerate(models)}
@@ -185,8 +192,8 @@ class VIPRSGrid(VIPRS):
         dropping = [ConditionStreak() for _ in range(G)]
         elbos = np.zeros(G)
         active = np.arange(G, dtype=np.int32)
-        for c in self.chromosomes:               # initial ELBO needs var_tau of the initial hyper-parameters
-            states[c].prep_columns(prep_rows(range(G)))
+        for st in states.values():               # initial ELBO needs var_tau of the initial hyper-parameters
+            st.prep_columns(prep_rows(range(G)))
 
         for i in range(1, max_iter + 1):
             if active.size == 0:
@@ -195,9 +202,9 @@ class VIPRSGrid(VIPRS):
                 p = th[g]
                 p["sigma_epsilon_e"], p["tau_beta_e"] = p["sigma_epsilon"], p["tau_beta"]   # what var_tau is built from
             rows = prep_rows(active)
-            for c in self.chromosomes:               # one prep launch, one sweep and one reduction per chromosome
-                states[c].prep_columns(rows)
-                states[c].e_step(self.dequantize_scale, active_model_idx=active, sync=False)
+            for st in states.values():               # one prep launch, one sweep and one reduction per plan
+                st.prep_columns(rows)
+                st.e_step(self.dequantize_scale, active_model_idx=active, sync=False)
             sums_of = all_sums(active)
             still = []
             for g in active:
@@ -247,9 +254,18 @@ class VIPRSGrid(VIPRS):
 
         # ---- read the (m, G) state back in the reference's layout ---------------------------------------
         store = self._new_store()
+        seg = self._seg if merged else None
+
+        def pull(name):
+            if merged:
+                full = states["*"].download(name)
+                return {c: full[seg[c][0]:seg[c][1]] for c in chroms}
+            return {c: states[c].download(name) for c in chroms}
+
+        pulled = {name: pull(name) for name in ("var_gamma", "var_mu", "q")}
         for c in self.chromosomes:
             for name in ("var_gamma", "var_mu", "q"):
-                store[name][c][...] = states[c].download(name)
+                store[name][c][...] = pulled[name][c]
             for g in range(G):
                 p = th[g]
                 store["var_tau"][c][:, g] = (self.n_per_snp[c] * (1.0 + p["lam"]) / p["sigma_epsilon_e"]) + p["tau_beta_e"]
@@ -257,5 +273,5 @@ class VIPRSGrid(VIPRS):
             p = th[g]
             store["sigma_epsilon"][g], store["pi"][g] = p["sigma_epsilon"], p["pi"]
             store["tau_beta"][g], store["sigma_g"][g], store["elbo"][g] = p["tau_beta"], sigma_g[g], elbos[g]
-        self.eta_diff = {c: states[c].download("eta_diff") for c in self.chromosomes}
+        self.eta_diff = {c: np.asfortranarray(v) for c, v in pull("eta_diff").items()}
         return self._publish(store, results)
