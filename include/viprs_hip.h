@@ -199,6 +199,22 @@ int viprs_state_sums_end(viprs_state* state, double* out);
 int viprs_state_prep_column(viprs_state* state, int g, double logit_pi, double log_tau_beta, double sigma_epsilon,
                             double tau_beta, double one_plus_lambda);
 int viprs_state_sums_column(viprs_state* state, int g, double one_plus_lambda, double* out);
+/* ---- device-resident EM iteration of the mixture model (K <= 8), VIPRSMix.py:169-260 -------------------
+ * prep    : var_tau[j,k] = n_j * one_plus_lambda / sigma_epsilon + tau_beta[k] and the E-step inputs of the state
+ *           (u_logs, sqrt_half_var_tau, mu_mult, log_null_pi).  The K-vectors logit_pi = log(pi) - log(1 - pi),
+ *           log_tau_beta and tau_beta and the scalar log_null_pi are evaluated by the caller (reference dtype
+ *           semantics).  Needs viprs_state_set_n_per_snp.
+ * log_var_tau : (m, K) doubles, C order -- log of the INITIAL var_tau, which the reference's ELBO keeps using.
+ * sums    : 7 + 6 K doubles: sum zeta | sum((1+lambda) zeta + q eta) | sum std_beta eta | sum eta^2 |
+ *           sum null_gamma log null_gamma | sum null_gamma | then K-vectors sum gamma | sum gamma (mu^2 + 1/var_tau) |
+ *           sum gamma_c log gamma_c | sum gamma_c | sum gamma_c log_var_tau | sum gamma_c (mu^2 + 1/var_tau)
+ *           (gamma_c = gamma clipped to [1e-15, 1 - 1e-15]) | max |eta_diff|. */
+int viprs_state_set_log_var_tau(viprs_state* state, const double* log_var_tau);
+int viprs_state_prep_mixture(viprs_state* state, const double* logit_pi, const double* log_tau_beta,
+                             const double* tau_beta, double log_null_pi, double sigma_epsilon, double one_plus_lambda);
+int viprs_state_sums_mixture_begin(viprs_state* state, double one_plus_lambda);
+int viprs_state_sums_mixture_end(viprs_state* state, double* out);
+
 /* Several models per launch (the batched grid fit touches every active model in every EM iteration):
  *   params : n rows of 6 doubles  (column, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda)
  *   cols   : n rows of 2 doubles  (column, one_plus_lambda)

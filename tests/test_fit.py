@@ -50,7 +50,7 @@ def build_model(fx, comm=None, e_step="oracle"):
     return model, theta
 
 
-def check_against_fixture(model, fx, local_only=False):
+def check_against_fixture(model, fx, local_only=False, pi_rtol=2e-4):
     h = np.array(model.history["ELBO"])
     ref = fx["elbo_history"]
     assert len(h) == len(ref), f"{len(h)} ELBO entries, reference has {len(ref)}"
@@ -58,7 +58,7 @@ def check_against_fixture(model, fx, local_only=False):
     assert model.optim_result.nit == int(fx["nit"])
     assert model.optim_result.success == bool(fx["success"])
     assert model.optim_result.message == str(fx["message"])
-    np.testing.assert_allclose(np.asarray(model.pi, dtype=np.float64), fx["final_pi"], rtol=2e-4)
+    np.testing.assert_allclose(np.asarray(model.pi, dtype=np.float64), fx["final_pi"], rtol=pi_rtol)
     np.testing.assert_allclose(np.asarray(model.tau_beta, dtype=np.float64), fx["final_tau_beta"], rtol=2e-4)
     np.testing.assert_allclose(float(model.sigma_epsilon), float(fx["final_sigma_epsilon"]), rtol=1e-5)
     np.testing.assert_allclose(float(model._sigma_g), float(fx["final_sigma_g"]), rtol=1e-4)
@@ -86,7 +86,10 @@ def test_fit_trajectory_hip(gpu, path):
     fx = np.load(path)
     model, theta = build_model(fx, e_step="hip")
     model.fit(max_iter=60, theta_0=theta)
-    check_against_fixture(model, fx)
+    # device-resident mixture iteration: sum_j gamma_jk is accumulated in float64 on the device, while the
+    # reference (and the host path) sums the (m, K) float32 array row by row in float32 (error ~ m 2^-24,
+    # visible on the smallest components of pi) -- everything else keeps the common tolerances
+    check_against_fixture(model, fx, pi_rtol=2e-3 if int(fx["K"]) else 2e-4)
 
 
 def test_continued_fit_and_warm_start():

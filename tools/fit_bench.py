@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chroms", type=int, default=1, help="split the blocks over this many chromosomes")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--host-mirrored", action="store_true")
+    ap.add_argument("--mixture", type=int, default=0, help="VIPRSMix with this many components")
     ap.add_argument("--grid", type=int, default=0, help="batched grid fit (VIPRSGrid) with this many (pi, sigma_epsilon) points")
     args = ap.parse_args()
     sizes = syn.block_sizes(args.config)
@@ -41,14 +42,18 @@ def main():
         print(f"{args.config} x{args.chroms} chromosomes, batched grid fit of {model.n_models} models: "
               f"{(t1 - t0) / args.iters * 1e3:.3f} ms per EM iteration incl. set-up ({args.iters} iterations)")
         return
-    model = VIPRS(gdl, low_memory=False, device_resident=not args.host_mirrored)
+    if args.mixture:
+        from viprs_amd.model.VIPRSMix import VIPRSMix
+        model = VIPRSMix(gdl, K=args.mixture, low_memory=False, device_resident=not args.host_mirrored)
+    else:
+        model = VIPRS(gdl, low_memory=False, device_resident=not args.host_mirrored)
     t0 = time.perf_counter()
     model.fit(max_iter=3, min_iter=3)                       # warm-up (plans, first launches)
     t1 = time.perf_counter()
     model.fit(max_iter=args.iters, min_iter=args.iters, continued=True)
     t2 = time.perf_counter()
     n_it = len(model.history["ELBO"]) - 3
-    print(f"{args.config} x{args.chroms} chromosomes, device_resident={not args.host_mirrored}: warm-up {t1 - t0:.2f} s, "
+    print(f"{args.config} x{args.chroms} chromosomes, {'mixture K=%d, ' % args.mixture if args.mixture else ''}device_resident={model._resident}: warm-up {t1 - t0:.2f} s, "
           f"{(t2 - t1) / max(1, n_it) * 1e3:.3f} ms per EM iteration ({n_it} iterations), ELBO {model.history['ELBO'][-1]:.6g}; {model.optim_result.message}")
 
 

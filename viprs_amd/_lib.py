@@ -79,6 +79,10 @@ _PROTOS = {
     "viprs_state_sums_end": (_i, [_vp, ctypes.POINTER(_d)]),
     "viprs_state_prep_column": (_i, [_vp, _i, _d, _d, _d, _d, _d]),
     "viprs_state_sums_column": (_i, [_vp, _i, _d, ctypes.POINTER(_d)]),
+    "viprs_state_set_log_var_tau": (_i, [_vp, _vp]),
+    "viprs_state_prep_mixture": (_i, [_vp, _vp, _vp, _vp, _d, _d, _d]),
+    "viprs_state_sums_mixture_begin": (_i, [_vp, _d]),
+    "viprs_state_sums_mixture_end": (_i, [_vp, _vp]),
     "viprs_state_prep_columns": (_i, [_vp, _i, _vp]),
     "viprs_state_sums_columns_begin": (_i, [_vp, _i, _vp]),
     "viprs_state_sums_columns_end": (_i, [_vp, _vp]),

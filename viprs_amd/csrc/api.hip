@@ -201,6 +201,113 @@ __global__ void sums_final_kernel(const double* __restrict__ partials, int n_blo
     if (lane == 0) out[k] = a;
 }
 
+// ---- device-resident EM iteration of the mixture model (VIPRSMix.py:169-225 prep, :227-260 M-step, elbo) ----
+constexpr int kMixResidentK = 8;                                  // = kPanelMaxK: the lane-parallel panel chain
+constexpr int kMixSums(int K) { return 7 + 6 * K; }               // s[0..5] | kv[6][K] | max |eta_diff|
+struct MixPrepArgs { double logit_pi[kMixResidentK], log_tau[kMixResidentK], tau[kMixResidentK]; };
+
+// per SNP and component (C-order (m, K)): var_tau = n (1 + lambda) / sigma_eps + tau_k and the three E-step inputs
+template <typename T>
+__global__ void prep_mixture_kernel(const double* __restrict__ n, int64_t m, int K, MixPrepArgs a, double sigma_eps,
+                                    double one_plus_lambda, double log_null_pi, T* __restrict__ mu_mult,
+                                    T* __restrict__ u_logs, T* __restrict__ shvt, T* __restrict__ lnp,
+                                    double* __restrict__ var_tau_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    lnp[i] = (T)log_null_pi;
+    for (int k = 0; k < K; ++k) {
+        const double vt = n[i] * one_plus_lambda / sigma_eps + a.tau[k];
+        var_tau_out[i * K + k] = vt;
+        mu_mult[i * K + k] = (T)(n[i] / (vt * sigma_eps));
+        u_logs[i * K + k] = (T)(a.logit_pi[k] + 0.5 * (a.log_tau[k] - log(vt)));
+        shvt[i * K + k] = (T)sqrt(0.5 * vt);
+    }
+}
+
+// VIPRSMix._partial_sums on the device (float64): per-workgroup partials, fixed order
+template <typename T>
+__global__ __launch_bounds__(kSumsBlock) void sums_mixture_kernel(int64_t m, int K, const T* __restrict__ gam,
+                                                                  const T* __restrict__ mu, const T* __restrict__ eta,
+                                                                  const T* __restrict__ q, const T* __restrict__ ed,
+                                                                  const T* __restrict__ beta, const double* __restrict__ var_tau,
+                                                                  const double* __restrict__ log_var_tau0, double one_plus_lambda,
+                                                                  double* __restrict__ partials) {
+    constexpr int NMAX = kMixSums(kMixResidentK);
+    const int N = kMixSums(K);
+    double acc[NMAX];
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) acc[k] = 0.0;
+    const double lo = 1e-15, hi = 1.0 - 1e-15;
+    for (int64_t i = (int64_t)blockIdx.x * kSumsBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kSumsBlock) {
+        double zeta = 0.0, gsum = 0.0;
+#pragma unroll
+        for (int k = 0; k < kMixResidentK; ++k) {
+            if (k < K) {
+                const double g = (double)gam[i * K + k], mud = (double)mu[i * K + k], vt = var_tau[i * K + k];
+                const double z = g * (mud * mud + 1.0 / vt);
+                zeta += z;
+                gsum += g;
+                const double gc = fmin(fmax(g, lo), hi);
+                acc[6 + 0 * kMixResidentK + k] += g;
+                acc[6 + 1 * kMixResidentK + k] += z;
+                acc[6 + 2 * kMixResidentK + k] += gc * log(gc);
+                acc[6 + 3 * kMixResidentK + k] += gc;
+                acc[6 + 4 * kMixResidentK + k] += gc * log_var_tau0[i * K + k];
+                acc[6 + 5 * kMixResidentK + k] += gc * (mud * mud + 1.0 / vt);
+            }
+        }
+        acc[0] += zeta;
+        acc[1] += one_plus_lambda * zeta + (double)(q[i] * eta[i]);
+        acc[2] += (double)beta[i] * (double)eta[i];
+        acc[3] += (double)eta[i] * (double)eta[i];
+        const double ng = fmin(fmax(1.0 - gsum, lo), hi);
+        acc[4] += ng * log(ng);
+        acc[5] += ng;
+        acc[NMAX - 1] = fmax(acc[NMAX - 1], fabs((double)ed[i]));
+    }
+    // wave shuffle tree, then the 4 waves in order: fixed summation order
+    __shared__ double red[NMAX][kSumsBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        double a = acc[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(a, off, 64);
+            a = (k == NMAX - 1) ? fmax(a, o) : a + o;
+        }
+        if (lane == 0) red[k][wave] = a;
+    }
+    __syncthreads();
+    // compact to the K actually used: out index n -> internal index
+    if ((int)threadIdx.x < N) {
+        const int nidx = threadIdx.x;
+        int src;
+        if (nidx < 6) src = nidx;
+        else if (nidx == N - 1) src = NMAX - 1;
+        else src = 6 + ((nidx - 6) / K) * kMixResidentK + (nidx - 6) % K;
+        double a = red[src][0];
+        for (int w = 1; w < kSumsBlock / 64; ++w) a = (src == NMAX - 1) ? fmax(a, red[src][w]) : a + red[src][w];
+        partials[(int64_t)blockIdx.x * N + nidx] = a;
+    }
+}
+
+// one workgroup (one wave) per sum over the per-block partials; the last sum is a maximum
+__global__ void sums_final_generic_kernel(const double* __restrict__ partials, int n_blocks, int n_sums,
+                                          double* __restrict__ out) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const bool is_max = (k == n_sums - 1);
+    double a = 0.0;
+    for (int b = lane; b < n_blocks; b += 64) {
+        const double v = partials[(int64_t)b * n_sums + k];
+        a = is_max ? fmax(a, v) : a + v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(a, off, 64);
+        a = is_max ? fmax(a, o) : a + o;
+    }
+    if (lane == 0) out[k] = a;
+}
+
 // zeroes the work-queue heads, the skip counter and the team hand-off granules in ONE launch
 __global__ void sweep_prologue_kernel(int32_t* counters, int n_counters, unsigned long long* skipped,
                                       unsigned long long* granules, int64_t n_granules) {
@@ -275,6 +382,7 @@ struct viprs_state {
     DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
     DevBuf<double> d_n, d_var_tau, d_partials, d_sums;   // device-resident EM iteration
     DevBuf<double> d_weight;                // optional per-SNP weight of sum [0] (several chromosomes in one plan)
+    DevBuf<double> d_log_var_tau0;          // mixture: the log var_tau of the initial state (the reference's ELBO never refreshes it)
     DevBuf<double> d_colparams, d_sumcols;  // grid: per-column parameters of the batched prep / of the batched sums
     int sums_cols = 0;                      // columns of the reduction in flight (grid: sums_columns_begin)
     size_t h_sums_cap = 0;
@@ -1438,6 +1546,109 @@ int viprs_state_prep_column(viprs_state* S, int g, double logit_pi, double log_t
                                                          S->d_var_tau.p + off, 1);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
+}
+
+int viprs_state_set_log_var_tau(viprs_state* S, const double* log_var_tau) {
+    if (!S || !log_var_tau) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    viprs_plan* P = S->plan;
+    const size_t n = (size_t)P->m * S->width;
+    if (n == 0) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(S->d_log_var_tau0.alloc(n));
+    HIP_TRY(hipMemcpyAsync(S->d_log_var_tau0.p, log_var_tau, n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    return VIPRS_OK;
+}
+
+int viprs_state_prep_mixture(viprs_state* S, const double* logit_pi, const double* log_tau_beta, const double* tau_beta,
+                             double log_null_pi, double sigma_epsilon, double one_plus_lambda) {
+    if (!S || !logit_pi || !log_tau_beta || !tau_beta) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    if (S->width > kMixResidentK) return fail(VIPRS_EUNSUPPORTED, "device-resident mixture iteration: K <= 8");
+    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    viprs_plan* P = S->plan;
+    if (P->m == 0) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    const int K = S->width;
+    if (S->d_var_tau.n < (size_t)P->m * K) {
+        HIP_TRY(hipStreamSynchronize(P->stream));
+        HIP_TRY(S->d_var_tau.alloc((size_t)P->m * K));
+    }
+    MixPrepArgs a{};
+    for (int k = 0; k < K; ++k) { a.logit_pi[k] = logit_pi[k]; a.log_tau[k] = log_tau_beta[k]; a.tau[k] = tau_beta[k]; }
+    const unsigned grid = (unsigned)((P->m + 255) / 256);
+    if (S->float_dtype == VIPRS_F32)
+        prep_mixture_kernel<float><<<grid, 256, 0, P->stream>>>(
+            S->d_n.p, P->m, K, a, sigma_epsilon, one_plus_lambda, log_null_pi, (float*)S->f[VIPRS_FIELD_MU_MULT].p,
+            (float*)S->f[VIPRS_FIELD_U_LOGS].p, (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p,
+            (float*)S->f[VIPRS_FIELD_LOG_NULL_PI].p, S->d_var_tau.p);
+    else
+        prep_mixture_kernel<double><<<grid, 256, 0, P->stream>>>(
+            S->d_n.p, P->m, K, a, sigma_epsilon, one_plus_lambda, log_null_pi, (double*)S->f[VIPRS_FIELD_MU_MULT].p,
+            (double*)S->f[VIPRS_FIELD_U_LOGS].p, (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p,
+            (double*)S->f[VIPRS_FIELD_LOG_NULL_PI].p, S->d_var_tau.p);
+    HIP_TRY(hipGetLastError());
+    return VIPRS_OK;
+}
+
+int viprs_state_sums_mixture_begin(viprs_state* S, double one_plus_lambda) {
+    if (!S) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    if (S->width > kMixResidentK) return fail(VIPRS_EUNSUPPORTED, "device-resident mixture iteration: K <= 8");
+    viprs_plan* P = S->plan;
+    const int K = S->width, N = kMixSums(K);
+    S->sums_cols = N;
+    if (P->m == 0) { S->sums_pending = false; S->sums_empty = true; return VIPRS_OK; }
+    S->sums_empty = false;
+    if (S->d_var_tau.n < (size_t)P->m * K || !S->d_log_var_tau0.p)
+        return fail(VIPRS_EINVAL, "viprs_state_prep_mixture / viprs_state_set_log_var_tau have not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
+    if (S->d_partials.n < (size_t)nb * N) HIP_TRY(S->d_partials.alloc((size_t)nb * N));
+    if (S->d_sums.n < (size_t)N) HIP_TRY(S->d_sums.alloc((size_t)N));
+    if (S->h_sums_cap < (size_t)N + 1) {
+        if (S->h_sums) HIP_TRY(hipHostFree(S->h_sums));
+        S->h_sums = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), ((size_t)N + 1) * sizeof(double), hipHostMallocDefault));
+        S->h_sums_cap = (size_t)N + 1;
+    }
+    if (S->float_dtype == VIPRS_F32)
+        sums_mixture_kernel<float><<<nb, kSumsBlock, 0, P->stream>>>(
+            P->m, K, (const float*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const float*)S->f[VIPRS_FIELD_VAR_MU].p,
+            (const float*)S->f[VIPRS_FIELD_ETA].p, (const float*)S->f[VIPRS_FIELD_Q].p, (const float*)S->f[VIPRS_FIELD_ETA_DIFF].p,
+            (const float*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p, S->d_log_var_tau0.p, one_plus_lambda, S->d_partials.p);
+    else
+        sums_mixture_kernel<double><<<nb, kSumsBlock, 0, P->stream>>>(
+            P->m, K, (const double*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const double*)S->f[VIPRS_FIELD_VAR_MU].p,
+            (const double*)S->f[VIPRS_FIELD_ETA].p, (const double*)S->f[VIPRS_FIELD_Q].p, (const double*)S->f[VIPRS_FIELD_ETA_DIFF].p,
+            (const double*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p, S->d_log_var_tau0.p, one_plus_lambda, S->d_partials.p);
+    HIP_TRY(hipGetLastError());
+    sums_final_generic_kernel<<<N, 64, 0, P->stream>>>(S->d_partials.p, nb, N, S->d_sums.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(S->h_sums, S->d_sums.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(S->h_sums + N, P->d_error.p, sizeof(int32_t), hipMemcpyDeviceToHost, P->stream));
+    S->sums_pending = true;
+    return VIPRS_OK;
+}
+
+int viprs_state_sums_mixture_end(viprs_state* S, double* out) {
+    if (!S || !out) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    const int N = kMixSums(S->width);
+    if (S->sums_empty) {
+        for (int k = 0; k < N; ++k) out[k] = 0.0;
+        return VIPRS_OK;
+    }
+    if (!S->sums_pending) return fail(VIPRS_EINVAL, "no device sums in flight (viprs_state_sums_mixture_begin)");
+    viprs_plan* P = S->plan;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    S->sums_pending = false;
+    for (int k = 0; k < N; ++k) out[k] = S->h_sums[k];
+    int32_t e = 0;
+    memcpy(&e, S->h_sums + N, sizeof(e));
+    return e != 0 ? check_device_error(P) : VIPRS_OK;
 }
 
 int viprs_state_prep_columns(viprs_state* S, int n, const double* params) {

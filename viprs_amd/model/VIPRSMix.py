@@ -31,10 +31,10 @@ class VIPRSMix(VIPRS):
         return DeviceState(plan, self.float_precision, "mixture", self.K)
 
     def _supports_resident(self):
-        return False          # mixture M-step sums still run on the host
+        return self.K <= 8    # device prep / sums kernels cover the panel kernels' K range
 
     def _supports_merged(self):
-        return False
+        return True
 
     # ---- hyper-parameter initialisation (VIPRSMix.py:60-167) --------------------------------------
     def initialize_theta(self, theta_0=None):
@@ -64,6 +64,26 @@ class VIPRSMix(VIPRS):
             self.tau_beta = self.d * (self.n_snps * np.dot(1.0 / self.d, self.pi) / h2)
         self._cast_theta()
 
+    def initialize_variational_parameters(self, param_0=None):
+        super().initialize_variational_parameters(param_0)
+        if self._resident:
+            # the reference's ELBO keeps the log var_tau of the initial state: device copy
+            for key, ds in self._dstate.items():
+                chroms = self.chromosomes if key == "*" else [key]
+                ds.set_log_var_tau(np.concatenate([np.asarray(self._log_var_tau[c], dtype=np.float64)
+                                                   * np.ones(self._shape(c)) for c in chroms]))
+
+    def sync_host(self):
+        """Refresh the NumPy state from the GPU; `_log_var_tau` stays the initial one (as on the host path)."""
+        if self._resident and self._host_stale:
+            self._pull_state()
+            if self._last_prep is not None:
+                sigma_epsilon, tau_beta, lam = self._last_prep
+                for c in self.chromosomes:
+                    self.var_tau[c] = (self.n_per_snp[c] * (1.0 + lam) / sigma_epsilon) + tau_beta
+            self.zeta = self.compute_zeta()
+            self._host_stale = False
+
     def get_null_pi(self, chrom=None):
         return 1.0 - np.sum(self.get_pi(chrom))
 
@@ -83,6 +103,19 @@ class VIPRSMix(VIPRS):
         return log_null_pi, u_logs, shvt, mu_mult
 
     def e_step(self):
+        if self._resident:
+            # whole iteration on the device: prep kernel + sweep per plan, nothing crosses PCIe
+            pi, tau_beta = np.asarray(self.pi), np.asarray(self.tau_beta)
+            logit_pi = np.log(pi) - np.log(1.0 - pi)                     # dtype semantics of VIPRSMix.py:211
+            log_null_pi = np.log(1.0 - self.pi.sum())
+            for ds in self._dstate.values():
+                ds.prep_mixture(logit_pi, np.log(tau_beta), tau_beta, log_null_pi, self.sigma_epsilon,
+                                1.0 + self.lambda_min)
+                ds.e_step(self.dequantize_scale, sync=False)
+            self._last_prep = (self.sigma_epsilon, tau_beta, self.lambda_min)
+            self._host_stale = True
+            self._sums_valid = False
+            return
         if self._e_step_fn is not None:
             for c in self.chromosomes:
                 log_null_pi, u_logs, shvt, mu_mult = self._prep(c)
@@ -121,6 +154,16 @@ class VIPRSMix(VIPRS):
         then K-vectors: sum_j gamma_jk | sum_j zeta_jk | sum gamma log gamma | sum gamma (clipped)
         | sum gamma log_var_tau (stale, VIPRSMix never refreshes it: SURVEY Appendix A) | sum gamma (mu^2 + 1/tau)"""
         K, lam = self.K, self.lambda_min
+        if self._resident and self._host_stale:
+            tot = np.zeros(6 + 6 * K, dtype=np.float64)
+            self._dev_max_eta_diff = 0.0
+            for ds in self._dstate.values():
+                ds.sums_mixture_begin(1.0 + lam)
+            for ds in self._dstate.values():
+                v = ds.sums_mixture_end()
+                tot += v[:-1]
+                self._dev_max_eta_diff = max(self._dev_max_eta_diff, float(v[-1]))
+            return tot
         s = np.zeros(6, dtype=np.float64)
         kv = np.zeros((6, K), dtype=np.float64)
         for c in self.chromosomes:

@@ -282,6 +282,27 @@ class DeviceState:
         L.check(L.lib.viprs_state_sums_column(self._h, int(g), float(one_plus_lambda), out))
         return np.array(out[:], dtype=np.float64)
 
+    # -- device-resident EM iteration of a mixture state (K <= 8) --------------------------------------
+    def set_log_var_tau(self, log_var_tau):
+        a = np.ascontiguousarray(log_var_tau, dtype=np.float64)
+        if a.shape != (self.plan.m, self.width):
+            raise ValueError(f"log_var_tau: expected shape ({self.plan.m}, {self.width}), got {a.shape}")
+        L.check(L.lib.viprs_state_set_log_var_tau(self._h, _ptr(a)))
+
+    def prep_mixture(self, logit_pi, log_tau_beta, tau_beta, log_null_pi, sigma_epsilon, one_plus_lambda):
+        v = [np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (self.width,))) for x in
+             (logit_pi, log_tau_beta, tau_beta)]
+        L.check(L.lib.viprs_state_prep_mixture(self._h, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), float(log_null_pi),
+                                               float(sigma_epsilon), float(one_plus_lambda)))
+
+    def sums_mixture_begin(self, one_plus_lambda):
+        L.check(L.lib.viprs_state_sums_mixture_begin(self._h, float(one_plus_lambda)))
+
+    def sums_mixture_end(self):
+        out = np.zeros(7 + 6 * self.width, dtype=np.float64)
+        L.check(L.lib.viprs_state_sums_mixture_end(self._h, _ptr(out)))
+        return out
+
     def prep_columns(self, params):
         """`prep_column` for several models in one launch: rows (column, logit_pi, log_tau_beta,
         sigma_epsilon, tau_beta, one_plus_lambda)."""
