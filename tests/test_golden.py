@@ -79,5 +79,5 @@ def test_hip_reproduces_golden(gpu, path):
             else:
                 for k in STATE:
                     H.assert_close(st[k], ref[k], 1e-5 if f32 else 1e-10, k)
-            if f32 and not bool(fx["low_memory"]):
-                H.assert_state_equal(st, ref)      # symmetric form, exact math: bit for bit (all three models)
+            if f32:
+                H.assert_state_equal(st, ref)      # exact math: bit for bit, both LD forms, all three models

@@ -34,8 +34,7 @@ def test_team_blocks_bit_exact(gpu, ld_dtype, low_memory):
     ref = H.run_oracle(ld, inp, st0, sweeps=2)
     got = H.run_hip(ld, inp, st0, sweeps=2)
     H.assert_state_close(got, ref)
-    if not low_memory:
-        H.assert_state_equal(got, ref)
+    H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms
 
 
 def test_fast_math_mode_within_tolerance(gpu):
@@ -86,8 +85,7 @@ def test_cfg2_full_size_against_oracle(gpu):
         ref = H.run_oracle(ld, inp, st0, sweeps=3)
         got = H.run_hip(ld, inp, st0, sweeps=3)
         H.assert_state_close(got, ref)
-        if not low_memory:
-            H.assert_state_equal(got, ref)
+        H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms
 
 
 def test_cfg3_full_size_properties(gpu):

@@ -30,8 +30,7 @@ def test_mixture_matches_oracle(gpu, K, low_memory):
     got = _run_mix(S, ld, inp, mix, st0, 2)
     for k in STATE:
         H.assert_close(got[k], ref[k], 1e-5, k)
-    if not low_memory:
-        H.assert_state_equal(got, ref)
+    H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms
 
 
 @pytest.mark.parametrize("mfma", ["0", "1"])          # per-(block, model) panel items / batched matrix-core kernel
@@ -52,8 +51,7 @@ def test_grid_matches_oracle(gpu, low_memory, mfma, monkeypatch):
         out[name] = st
     for k in STATE:
         H.assert_close(out["hip"][k], out["ref"][k], 1e-5, k)
-    if not low_memory:
-        H.assert_state_equal(out["hip"], out["ref"])
+    H.assert_state_equal(out["hip"], out["ref"])     # bit-for-bit in both LD forms
     untouched = [c for c in range(32) if c not in active]
     assert np.all(out["hip"]["eta"][:, untouched] == 0)
 
@@ -80,8 +78,7 @@ def test_grid_mfma_model_counts(gpu, G, n_active, low_memory, monkeypatch):
     got = _run_grid(S, ld, inp, g, st0, active)
     for k in STATE:
         H.assert_close(got[k], ref[k], 1e-5, k)
-    if not low_memory:
-        H.assert_state_equal(got, ref)
+    H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms
 
 
 @pytest.mark.parametrize("ld_dtype", [np.int8, np.int16])
@@ -96,8 +93,7 @@ def test_grid_mfma_quantised_ld(gpu, ld_dtype, low_memory, monkeypatch):
     got = _run_grid(S, ld, inp, g, st0, active)
     for k in STATE:
         H.assert_close(got[k], ref[k], 1e-5, k)
-    if not low_memory:
-        H.assert_state_equal(got, ref)
+    H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms
 
 
 def test_grid_mfma_block_shapes(gpu, monkeypatch):

@@ -22,8 +22,7 @@ def test_first_sweep_matches_oracle(gpu, sizes, low_memory):
     ref = H.run_oracle(ld, inp, st0)
     got = H.run_hip(ld, inp, st0)
     H.assert_state_close(got, ref)
-    if not low_memory:
-        H.assert_state_equal(got, ref)     # exact mode: bit-for-bit in symmetric form
+    H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms
 
 
 @pytest.mark.parametrize("low_memory", [False, True])
@@ -43,3 +42,4 @@ def test_quantised_ld(gpu, ld_dtype, low_memory):
     ref = H.run_oracle(ld, inp, st0, sweeps=2)
     got = H.run_hip(ld, inp, st0, sweeps=2)
     H.assert_state_close(got, ref)
+    H.assert_state_equal(got, ref)
