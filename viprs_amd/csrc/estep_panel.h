@@ -29,6 +29,10 @@
 #include "device_math.h"
 #include "kernels_common.h"
 
+#ifndef PANEL_MIN_WAVES
+#define PANEL_MIN_WAVES 1      // waves per SIMD the panel kernel is compiled for (register budget 512 / n)
+#endif
+
 namespace viprs {
 
 #ifdef VIPRS_PANEL_PROFILE
@@ -375,7 +379,7 @@ struct MixtureModel {
 };
 
 template <typename U, typename MODEL, bool SYM, int NW, bool TEAM, int CPL>
-__global__ __launch_bounds__(NW * 64) void estep_panel_kernel(EStepArgs<float> A0, int qcap) {
+__global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(EStepArgs<float> A0, int qcap) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lq = smem;
     float* la = smem + qcap;
