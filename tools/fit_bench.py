@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--chroms", type=int, default=1, help="split the blocks over this many chromosomes")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--host-mirrored", action="store_true")
+    ap.add_argument("--no-merge", action="store_true", help="one device plan per chromosome")
     ap.add_argument("--mixture", type=int, default=0, help="VIPRSMix with this many components")
     ap.add_argument("--grid", type=int, default=0, help="batched grid fit (VIPRSGrid) with this many (pi, sigma_epsilon) points")
     args = ap.parse_args()
@@ -44,9 +45,10 @@ def main():
         return
     if args.mixture:
         from viprs_amd.model.VIPRSMix import VIPRSMix
-        model = VIPRSMix(gdl, K=args.mixture, low_memory=False, device_resident=not args.host_mirrored)
+        model = VIPRSMix(gdl, K=args.mixture, low_memory=False, device_resident=not args.host_mirrored,
+                         merge_chromosomes=not args.no_merge)
     else:
-        model = VIPRS(gdl, low_memory=False, device_resident=not args.host_mirrored)
+        model = VIPRS(gdl, low_memory=False, device_resident=not args.host_mirrored, merge_chromosomes=not args.no_merge)
     t0 = time.perf_counter()
     model.fit(max_iter=3, min_iter=3)                       # warm-up (plans, first launches)
     t1 = time.perf_counter()

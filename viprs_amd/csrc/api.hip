@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <mutex>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -412,7 +415,7 @@ viprs_plan::~viprs_plan() {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto& e : ev_join) if (e) (void)hipEventDestroy(e);
-    for (auto& st : class_stream) if (st) (void)hipStreamDestroy(st);
+    if (class_stream[2]) (void)hipStreamDestroy(class_stream[2]);       // [0], [1]: shared per device, never destroyed
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -508,9 +511,24 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     {   // team classes get the highest stream priority: their workgroups must become co-resident quickly
         int prio_lo = 0, prio_hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        for (int c = 0; c < 3; ++c)
-            HIP_TRY(hipStreamCreateWithPriority(&P->class_stream[c], hipStreamNonBlocking,
-                                                c < 2 ? prio_hi : prio_lo));
+        // The two team classes run on streams SHARED by all plans of a device: a team kernel needs all its
+        // workgroups resident at once (members spin on each other's hand-offs), so two team kernels of the
+        // same class from different plans must never be half-resident together.  The shared streams
+        // serialise them; the streams live as long as the process.
+        static std::mutex team_mu;
+        static std::map<int, std::array<hipStream_t, 2>> team_streams;
+        {
+            std::lock_guard<std::mutex> lock(team_mu);
+            auto it = team_streams.find(device);
+            if (it == team_streams.end()) {
+                std::array<hipStream_t, 2> st{};
+                for (int c = 0; c < 2; ++c) HIP_TRY(hipStreamCreateWithPriority(&st[c], hipStreamNonBlocking, prio_hi));
+                it = team_streams.emplace(device, st).first;
+            }
+            P->class_stream[0] = it->second[0];
+            P->class_stream[1] = it->second[1];
+        }
+        HIP_TRY(hipStreamCreateWithPriority(&P->class_stream[2], hipStreamNonBlocking, prio_lo));
     }
     HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
     for (auto& e : P->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
