@@ -56,6 +56,9 @@ size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0);
 static int kLargeBlock = 2304, kMediumBlock = 1280;
 constexpr int kClassWaves[3] = {4, 4, 4};
 static int kClassTeam[3] = {8, 2, 1};       // workgroups (CUs) sharing one block of the class (0/1: teams)
+// mixture: the chain step is ~4x the spike-and-slab one, every team member replicates it -- smaller teams
+static int kClassTeamMix[3] = {4, 1, 1};
+static bool g_team_env = false;             // VIPRS_TEAM0/1 given: they apply to every model
 constexpr int kEpiWaves = 4;
 
 template <typename V> struct DevBuf {
@@ -492,8 +495,8 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     if (const char* f = getenv("VIPRS_LARGE_BLOCK")) kLargeBlock = atoi(f);
     if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) kMediumBlock = atoi(f);
     if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
-    if (const char* f = getenv("VIPRS_TEAM0")) kClassTeam[0] = std::max(1, atoi(f));
-    if (const char* f = getenv("VIPRS_TEAM1")) kClassTeam[1] = std::max(1, atoi(f));
+    if (const char* f = getenv("VIPRS_TEAM0")) { kClassTeam[0] = std::max(1, atoi(f)); g_team_env = true; }
+    if (const char* f = getenv("VIPRS_TEAM1")) { kClassTeam[1] = std::max(1, atoi(f)); g_team_env = true; }
     P->low_memory = low_memory != 0;
     P->ld_dtype = ld_dtype;
     P->device = device;
@@ -1050,7 +1053,8 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     const int n_models = std::max(1, A.n_active);
     const int64_t n_items = (int64_t)A.n_blocks * n_models;
     int grid = (int)std::min<int64_t>(n_items, (int64_t)P->n_cu * per_cu);
-    const int TS = TEAM ? kClassTeam[cls] : 1;
+    const int* team_of = (model == kPanelMixture && !g_team_env) ? kClassTeamMix : kClassTeam;
+    const int TS = TEAM ? team_of[cls] : 1;
     A.team_size = TS;
     if (!TEAM) {
         // leave room for the team workgroups of the larger classes: they must all become resident
@@ -1059,7 +1063,7 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
         for (int c = 0; c < 3; ++c) {
             const int nb = P->class_begin[c + 1] - P->class_begin[c];
             if (c < 2 && nb > 0)
-                reserved += (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nb * n_models, P->n_cu / kClassTeam[c])) * kClassTeam[c];
+                reserved += (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)nb * n_models, P->n_cu / team_of[c])) * team_of[c];
         }
         grid = (int)std::min<int64_t>(n_items, std::max(P->n_cu / 2, P->n_cu * per_cu - reserved));
     }
