@@ -554,14 +554,26 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
                         float dvec = 0.0f, avec = 0.0f;                    // lane j: eta_diff / dq * eta_diff of SNP j
                         auto run_panel = [&](auto rounds_c) {
                         constexpr int ROUNDS = decltype(rounds_c)::value;
+                        // Rolled in 4 groups of kChainPrefetch = 16 steps (the fully unrolled mixture chain does
+                        // not fit the instruction cache): the row consumed at step 16 g + k was loaded 16 steps
+                        // earlier into the same register win[k]; the last group loads the first rows of the NEXT
+                        // panel's diagonal tile, which are handed over through dnext.
+                        static_assert(kChainPrefetch == 16 && kPanel == 64, "window indexing");
+                        float win[kChainPrefetch];
 #pragma unroll
-                        for (int jj = 0; jj < kPanel; ++jj) {
-                            if (jj + kChainPrefetch < kPanel)
-                                drow[jj + kChainPrefetch] =
-                                    static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
-                            else
-                                dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
-                                    nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
+                        for (int k = 0; k < kChainPrefetch; ++k) win[k] = drow[k];
+#pragma unroll 1
+                        for (int g = 0; g < kPanel / kChainPrefetch; ++g) {
+#pragma unroll
+                        for (int k = 0; k < kChainPrefetch; ++k) {
+                            const int jj = kChainPrefetch * g + k;                             // wave-uniform
+                            const float drow_jj = win[k];
+                            {
+                                const U* __restrict__ src = (g < kPanel / kChainPrefetch - 1)
+                                    ? dptr + (int64_t)min(jj + kChainPrefetch, last) * stride
+                                    : nptr + (int64_t)min(k, b - 1 - rn0) * stride;
+                                win[k] = static_cast<float>(*src);
+                            }
                             const int jn = (jj + 1 < kPanel) ? jj + 1 : jj;
                             const float nmm = Lmm[jn * K + kc], nsv = Lsv[jn * K + kc], nul = Lul[jn * K + kc];
                             const float qj = rl(qc, jj), lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
@@ -605,10 +617,13 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
                             const bool me = (l == jj);
                             dvec = me ? d : dvec;
                             avec = me ? a : avec;
-                            qc = __builtin_fmaf(drow[jj], a, qc);
+                            qc = __builtin_fmaf(drow_jj, a, qc);
                             if (SYM) qc = (me && livej) ? qc - d : qc;                         // :527
                             cmm = nmm; csv = nsv; cul = nul;
                         }
+                        }
+#pragma unroll
+                        for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[k];
                         };
                         if (K <= 4) run_panel(std::integral_constant<int, 4>{});
                         else run_panel(std::integral_constant<int, kPanelMaxK>{});
