@@ -83,3 +83,29 @@ def test_empty_and_validation_errors():
         plan_blocks(lb.astype(np.int64), np.array([0, 3, 6, 9], np.int64), False)
     with pytest.raises(ValueError):
         plan_blocks(lb, np.array([0, 3, 6, 9], np.float64), False)
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_merged_chromosomes_plan_is_the_union_of_the_per_chromosome_plans(low_memory):
+    """VIPRS puts all local chromosomes into one device plan: the merged index arrays must describe
+    exactly the per-chromosome LD blocks, shifted into place."""
+    from viprs_amd.data import merge_ld_arrays
+    from viprs_amd.plan import plan_blocks
+    from viprs_amd.utils import synthetic as syn
+    sizes = {20: [150, 90], 21: [1], 22: [64, 65, 333]}
+    lds = {c: syn.make_ld(np.array(s), low_memory=low_memory, seed=40 + c) for c, s in sizes.items()}
+    chroms = sorted(sizes)
+    lb, ip, data, seg = merge_ld_arrays(chroms, {c: lds[c].m for c in chroms}, {c: lds[c].ld_left_bound for c in chroms},
+                                        {c: lds[c].ld_indptr for c in chroms}, {c: lds[c].ld_data for c in chroms})
+    assert lb.dtype == np.int32 and ip.dtype == np.int64 and ip[0] == 0 and ip[-1] == data.shape[0]
+    starts, kinds = plan_blocks(lb, ip, low_memory)
+    exp_starts, exp_kinds = [], []
+    for c in chroms:
+        st, kd = plan_blocks(lds[c].ld_left_bound, lds[c].ld_indptr, low_memory)
+        exp_starts.append(st[:-1] + seg[c][0])
+        exp_kinds.append(kd)
+    assert np.array_equal(starts, np.concatenate(exp_starts + [[seg[chroms[-1]][1]]]))
+    assert np.array_equal(kinds, np.concatenate(exp_kinds))
+    for c in chroms:                                   # the data of every chromosome sits at its offset
+        a, b = seg[c]
+        assert np.array_equal(data[ip[a]:ip[b]], lds[c].ld_data)

@@ -89,3 +89,18 @@ class ArrayDataLoader:
                 stored_dtype=ld_dtype, dq_scale=sym.dq_scale)
             ss[chrom] = SumstatsArrays(s.std_beta, s.n_per_snp)
         return cls(ld, ss, n=n)
+
+
+def merge_ld_arrays(chroms, shapes, ld_left_bound, ld_indptr, ld_data):
+    """Concatenate the per-chromosome CSR-like LD arrays into one (LD blocks never span chromosomes, so
+    the merged matrix is block diagonal): window starts shifted by the SNP offset of their chromosome,
+    row pointers by its entry offset.  Returns (left_bound int32, indptr int64, data, {chrom: (start, end)})."""
+    snp_off = np.concatenate([[0], np.cumsum([int(shapes[c]) for c in chroms])]).astype(np.int64)
+    nnz_off = np.concatenate([[0], np.cumsum([int(ld_indptr[c][-1]) for c in chroms])]).astype(np.int64)
+    seg = {c: (int(snp_off[i]), int(snp_off[i + 1])) for i, c in enumerate(chroms)}
+    lb = np.concatenate([np.asarray(ld_left_bound[c], dtype=np.int64) + snp_off[i]
+                         for i, c in enumerate(chroms)]).astype(np.int32)
+    ip = np.concatenate([np.asarray(ld_indptr[c][:-1], dtype=np.int64) + nnz_off[i]
+                         for i, c in enumerate(chroms)] + [nnz_off[-1:]])
+    data = np.concatenate([ld_data[c] for c in chroms])
+    return lb, ip, data, seg

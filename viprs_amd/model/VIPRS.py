@@ -118,15 +118,10 @@ class VIPRS:
                             and len(self.chromosomes) > 1)
             if self._merged:
                 # one plan over the concatenated chromosomes: windows and row offsets shifted into place
+                from ..data import merge_ld_arrays
                 chroms = self.chromosomes
-                snp_off = np.concatenate([[0], np.cumsum([self.shapes[c] for c in chroms])]).astype(np.int64)
-                nnz_off = np.concatenate([[0], np.cumsum([int(self.ld_indptr[c][-1]) for c in chroms])]).astype(np.int64)
-                self._seg = {c: (int(snp_off[i]), int(snp_off[i + 1])) for i, c in enumerate(chroms)}
-                lb = np.concatenate([np.asarray(self.ld_left_bound[c], dtype=np.int64) + snp_off[i]
-                                     for i, c in enumerate(chroms)]).astype(np.int32)
-                ip = np.concatenate([np.asarray(self.ld_indptr[c][:-1], dtype=np.int64) + nnz_off[i]
-                                     for i, c in enumerate(chroms)] + [nnz_off[-1:]])
-                data = np.concatenate([self.ld_data[c] for c in chroms])
+                lb, ip, data, self._seg = merge_ld_arrays(chroms, self.shapes, self.ld_left_bound, self.ld_indptr,
+                                                          self.ld_data)
                 self._plans["*"] = LDPlan(lb, ip, data, low_memory, device=self.device, math_mode=math_mode)
                 del data
                 ds = self._dstate["*"] = self._make_device_state(self._plans["*"])
