@@ -267,8 +267,8 @@ def main():
                             + {"spike_slab": ", spike-and-slab", "mixture": f", sparse mixture prior K={width} (configs[3])",
                                "grid": f", grid of {width} (pi, sigma_eps) models batched per SNP (configs[4])"}[args.model]
                             + ", AR(1) block LD",
-                "model": args.model, "width": width, "snp_model_updates_per_s": total_snps * width * args.steps / elapsed
-                if args.model == "grid" else None,
+                "prior": args.model, "prior_width": width,
+                "snp_x_grid_point_updates_per_s": total_snps * width * args.steps / elapsed if args.model == "grid" else None,
                 "snps_per_gpu": int(ld.m), "ld_blocks_per_gpu": int(len(sizes)),
                 "ld_entries_per_gpu": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype,
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
