@@ -361,3 +361,44 @@ def test_device_resident_mixture_fit_equals_host_mirrored_fit(gpu):
     for c in a.chromosomes:
         np.testing.assert_allclose(a.pip[c], b.pip[c], rtol=5e-3, atol=2e-6)
         np.testing.assert_allclose(a.post_mean_beta[c], b.post_mean_beta[c], rtol=5e-3, atol=2e-7)
+
+
+def test_device_resident_entry_points_reject_misuse(gpu):
+    """Error behaviour of the device-resident EM entry points: wrong model kind, missing set-up calls,
+    bad column indices, `end` without `begin` -- every misuse is a Python exception, never a crash."""
+    from viprs_amd._lib import ViprsHipError
+    bad = (ValueError, ViprsHipError)          # VIPRS_EINVAL -> ValueError, everything else -> ViprsHipError
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld, ss, inp = syn.make_problem(sizes=[100, 70], low_memory=False, seed=3)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+    ss_state = DeviceState(plan)
+    mix = DeviceState(plan, "float32", "mixture", 4)
+    grid = DeviceState(plan, "float32", "grid", 6)
+    with pytest.raises(bad):
+        ss_state.prep_mixture(np.zeros(1), np.zeros(1), np.ones(1), -0.1, 0.8, 1.0)      # not a mixture state
+    with pytest.raises(bad):
+        mix.prep_mixture(np.zeros(4), np.zeros(4), np.ones(4), -0.1, 0.8, 1.0)           # n_per_snp not set
+    with pytest.raises(bad):
+        mix.sums_mixture_end()                                                           # nothing in flight
+    mix.set_n_per_snp(ss.n_per_snp)
+    mix.prep_mixture(np.zeros(4), np.zeros(4), np.ones(4), -0.1, 0.8, 1.0)
+    with pytest.raises(bad):
+        mix.sums_mixture_begin(1.0)                                                      # log_var_tau not set
+    with pytest.raises(bad):
+        ss_state.sums_end()                                                              # nothing in flight
+    with pytest.raises(bad):
+        grid.prep_columns(np.array([[0, 0.0, 0.0, 0.8, 1.0, 1.0]]))                      # n_per_snp not set
+    grid.set_n_per_snp(ss.n_per_snp)
+    with pytest.raises(bad):
+        grid.prep_columns(np.array([[6, 0.0, 0.0, 0.8, 1.0, 1.0]]))                      # column out of range
+    with pytest.raises(bad):
+        grid.sums_columns_begin([0, 1], 1.0)                                             # prep not called
+    grid.prep_columns(np.array([[g, -4.0, 9.0, 0.8, 8000.0, 1.0] for g in range(6)]))
+    grid.sums_columns_begin([5, 0], 1.0)
+    out = grid.sums_columns_end()
+    assert out.shape == (2, 11) and np.all(np.isfinite(out))
+    with pytest.raises(bad):
+        grid.sums_columns_end()                                                          # already collected
+    with pytest.raises(ValueError):
+        ss_state.set_snp_weights(np.ones(3))                                             # wrong length
+    plan.close()
