@@ -133,3 +133,37 @@ def test_two_rank_gloo_fit_matches_single_process(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]
+
+
+@pytest.mark.parametrize("name", ["fit_ss_2chr_upper", "fit_mix_k4_upper"])
+def test_reporting_methods_match_their_definitions(name):
+    """entropy / loglikelihood / log_prior (the ELBO's parts), theta and history tables: evaluated from the
+    reduced partial sums, checked against a direct NumPy evaluation of VIPRS.py:583-687 on the state arrays."""
+    fx = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    model, theta = build_model(fx)
+    model.fit(max_iter=12, theta_0=dict(theta))
+    res = np.finfo(np.float64).resolution
+    cat = lambda d: np.concatenate([np.asarray(d[c], dtype=np.float64) for c in model.chromosomes])
+    g = np.clip(cat(model.var_gamma), res, 1 - res)
+    pip = cat(model.compute_pip())
+    ng = np.clip(1.0 - pip, res, 1 - res)
+    lvt = cat(model._log_var_tau)
+    pi, tau = np.asarray(model.pi, dtype=np.float64), np.asarray(model.tau_beta, dtype=np.float64)
+    m = model.n_snps
+    ent = 0.5 * m * (np.log(2 * np.pi) + 1) - (g * np.log(g)).sum() - (ng * np.log(ng)).sum() - 0.5 * (g * lvt).sum()
+    np.testing.assert_allclose(model.entropy(), ent, rtol=1e-9)
+    eta, beta = cat(model.eta), cat(model.std_beta)
+    ll = -0.5 * model.n * (np.log(2 * np.pi * model.sigma_epsilon)
+                           + (1.0 / model.sigma_epsilon) * (1.0 - 2.0 * beta.dot(eta) + model._sigma_g))
+    np.testing.assert_allclose(model.loglikelihood(), ll, rtol=1e-7)
+    mu, vt = cat(model.var_mu), cat(model.var_tau)
+    lp = 0.5 * (g * np.log(tau)).sum() + (g * np.log(pi)).sum() + (ng * np.log(model.get_null_pi())).sum()
+    lp -= 0.5 * (g * tau * (mu ** 2 + 1.0 / vt)).sum() + 0.5 * m * np.log(2 * np.pi)
+    np.testing.assert_allclose(model.log_prior(), lp, rtol=1e-5)
+    np.testing.assert_allclose(model.complete_loglikelihood(), model.loglikelihood() + model.log_prior())
+    tt = model.to_theta_table()
+    assert list(tt.columns) == ["Parameter", "Value"] and {"ELBO", "Residual_variance", "Heritability"} <= set(tt["Parameter"])
+    assert ("pi_1" in set(tt["Parameter"])) == bool(int(fx["K"]))
+    ht = model.to_history_table()
+    assert len(ht) == len(model.history["ELBO"]) and "ELBO" in ht.columns
+    assert model.get_average_effect_size_variance() > 0

@@ -119,6 +119,28 @@ def test_posterior_table_and_pseudo_validation_cpu():
     t1 = single.to_table()
     assert {"BETA", "PIP", "VAR_BETA"} <= set(t1.columns)
     assert np.isscalar(float(single.pseudo_validate(vb)))
+    # per-model summaries of the fitted grid (the reference's test_basic.py calls these after a grid fit)
+    G = grid.n_models
+    for v in (grid.mse(), grid.log_prior(), grid.loglikelihood(), grid.entropy()):
+        assert np.shape(v) == (G,) and np.all(np.isfinite(v))
+    # model k of the grid = a single model with the same parameters and state: same numbers
+    k = 2
+    single.var_gamma[22], single.var_mu[22] = grid.var_gamma[22][:, k].copy(), grid.var_mu[22][:, k].copy()
+    single.var_tau[22], single.q[22] = grid.var_tau[22][:, k].copy(), grid.q[22][:, k].copy()
+    single._log_var_tau[22] = np.log(single.var_tau[22])
+    single.eta, single.zeta = single.compute_eta(), single.compute_zeta()
+    single.pi, single.tau_beta = grid.pi[k], grid.tau_beta[k]
+    single.sigma_epsilon, single._sigma_g = grid.sigma_epsilon[k], grid._sigma_g[k]
+    single._sums_valid = False
+    single._host_stale = False
+    np.testing.assert_allclose(grid.entropy()[k], single.entropy(), rtol=1e-7)
+    np.testing.assert_allclose(grid.log_prior()[k], single.log_prior(), rtol=1e-7)
+    np.testing.assert_allclose(grid.loglikelihood()[k], single.loglikelihood(), rtol=1e-7)
+    tt = grid.to_theta_table()
+    assert set(tt["Model"]) == set(range(G)) and "Heritability" in set(tt["Parameter"])
+    grid.write_validation_result(os.devnull)
+    grid._reset_search()
+    assert grid.validation_result is None and grid.optim_results == []
 
 
 @pytest.mark.gpu

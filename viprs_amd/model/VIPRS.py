@@ -498,11 +498,62 @@ class VIPRS:
         s = self._sums
         return 1.0 - 2.0 * s[3] + (self._sigma_g - s[1] + s[4])
 
+    # ---- the ELBO's parts (VIPRS.py:583-687), from the same partial sums as `elbo` -----------------------
+    def _current_sums(self):
+        return self._sums if (self._sums is not None and self._sums_valid) else self._reduce()
+
+    def entropy(self, sum_axis=None):
+        """Entropy of the variational distribution (VIPRS.py:583-612)."""
+        s = self._current_sums()
+        return float(0.5 * self.n_snps * (np.log(2.0 * np.pi) + 1.0) - s[5] - s[6] - 0.5 * s[9])
+
+    def loglikelihood(self):
+        """Expected log-likelihood of the summary statistics (VIPRS.py:614-628)."""
+        s = self._current_sums()
+        return float(-0.5 * self.n * (np.log(2.0 * np.pi * self.sigma_epsilon)
+                                      + (1.0 / self.sigma_epsilon) * (1.0 - 2.0 * s[3] + self._sigma_g)))
+
+    def log_prior(self, sum_axis=None):
+        """Expected log prior under the variational density (VIPRS.py:630-676)."""
+        s = self._current_sums()
+        lp = 0.5 * np.log(self.tau_beta) * s[7] + np.log(self.pi) * s[7] + np.log(self.get_null_pi()) * s[8]
+        lp -= 0.5 * self.tau_beta * s[1]
+        return float(lp - 0.5 * self.n_snps * np.log(2.0 * np.pi))
+
+    def complete_loglikelihood(self):
+        return self.loglikelihood() + self.log_prior()
+
     def get_heritability(self):
         return self._sigma_g / (self._sigma_g + self.sigma_epsilon)
 
     def get_proportion_causal(self):
         return self.pi
+
+    def get_average_effect_size_variance(self):
+        """Average per-SNP prior variance of the effect sizes, sum(pi / tau_beta) (VIPRS.py:764-778)."""
+        return float(np.sum(np.asarray(self.pi, dtype=np.float64) / np.asarray(self.tau_beta, dtype=np.float64)))
+
+    # ---- reporting (VIPRS.py:787-835) ------------------------------------------------------------------
+    def to_theta_table(self):
+        import pandas as pd
+        rows = [("ELBO", self.elbo()), ("Residual_variance", self.sigma_epsilon), ("Heritability", self.get_heritability()),
+                ("Proportion_causal", self.get_proportion_causal()),
+                ("Average_effect_variance", self.get_average_effect_size_variance())]
+        if np.isscalar(self.lambda_min):
+            rows.append(("Lambda_min", self.lambda_min))
+        taus = np.atleast_1d(np.asarray(self.tau_beta, dtype=np.float64))
+        if taus.size == 1:
+            rows.append(("tau_beta", float(taus[0])))
+        else:
+            rows += [(f"tau_beta_{i + 1}", float(t)) for i, t in enumerate(taus)]
+        return pd.DataFrame([{"Parameter": k, "Value": v} for k, v in rows])
+
+    def to_history_table(self):
+        import pandas as pd
+        return pd.DataFrame(self.history)
+
+    def write_inferred_theta(self, f_name, sep="\t"):
+        self.to_theta_table().to_csv(f_name, sep=sep, index=False)
 
     def update_theta_history(self):
         self._reduce()

@@ -224,6 +224,32 @@ class VIPRSMix(VIPRS):
 
     objective = elbo
 
+    # ---- the ELBO's parts for K components (VIPRS.py:583-687 with (m, K) arrays) ------------------------
+    def entropy(self, sum_axis=None):
+        s = self._current_sums()
+        return float(0.5 * self.n_snps * (np.log(2.0 * np.pi) + 1.0) - self._kv(2).sum() - s[4] - 0.5 * self._kv(4).sum())
+
+    def loglikelihood(self):
+        s = self._current_sums()
+        return float(-0.5 * self.n * (np.log(2.0 * np.pi * self.sigma_epsilon)
+                                      + (1.0 / self.sigma_epsilon) * (1.0 - 2.0 * s[2] + self._sigma_g)))
+
+    def log_prior(self, sum_axis=None):
+        s = self._current_sums()
+        pi, tau_beta = np.asarray(self.pi, dtype=np.float64), np.asarray(self.tau_beta, dtype=np.float64)
+        lp = (0.5 * np.log(tau_beta) * self._kv(3)).sum() + (np.log(pi) * self._kv(3)).sum()
+        lp += np.log(self.get_null_pi()) * s[5]
+        lp -= 0.5 * (tau_beta * self._kv(5)).sum()
+        return float(lp - 0.5 * self.n_snps * np.log(2.0 * np.pi))
+
+    def get_average_effect_size_variance(self):
+        return float(np.sum(np.asarray(self.pi, dtype=np.float64) / np.asarray(self.tau_beta, dtype=np.float64)))
+
+    def to_theta_table(self):                                                          # VIPRSMix.py:318-335
+        import pandas as pd
+        extra = pd.DataFrame([{"Parameter": f"pi_{i + 1}", "Value": float(p)} for i, p in enumerate(np.asarray(self.pi))])
+        return pd.concat([super().to_theta_table(), extra])
+
     def mse(self, sum_axis=None):
         s = self._sums
         return 1.0 - 2.0 * s[2] + (self._sigma_g - s[0] + s[3])

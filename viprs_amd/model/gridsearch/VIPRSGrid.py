@@ -60,9 +60,87 @@ class VIPRSGrid(VIPRS):
             raise ValueError("Validation result is not set!")
         return pd.DataFrame(self.validation_result)
 
+    def write_validation_result(self, v_filename, sep="\t"):
+        self.to_validation_table().to_csv(v_filename, index=False, sep=sep)
+
+    def _reset_search(self):
+        """Start the grid search over (VIPRSGrid.py:56-65), e.g. after model selection / averaging."""
+        self.n_models = len(self.grid_table)
+        assert self.n_models > 1, "Grid search requires at least 2 models."
+        self.validation_result = None
+        self.optim_results = []
+
     def init_optim_meta(self):
         super().init_optim_meta()
         self.optim_results = []
+
+    # ---- per-model ELBO parts / summaries after a grid fit: vectors of length n_models -------------------
+    def _model_sums(self):
+        """Per-model sums over the published (m, n_models) arrays (float64), VIPRS._partial_sums layout."""
+        res = np.finfo(np.float64).resolution
+        G = self.n_models
+        s = np.zeros((11, G))
+        for c in self.chromosomes:
+            g = np.asarray(self.var_gamma[c], dtype=np.float64)
+            mu, vt = np.asarray(self.var_mu[c], dtype=np.float64), np.asarray(self.var_tau[c], dtype=np.float64)
+            eta, q = np.asarray(self.eta[c], dtype=np.float64), np.asarray(self.q[c], dtype=np.float64)
+            zeta = g * (mu ** 2 + 1.0 / vt)
+            gc, ng = np.clip(g, res, 1 - res), np.clip(1.0 - g, res, 1 - res)
+            s[1] += zeta.sum(axis=0)
+            s[2] += ((1.0 + self.lambda_min) * zeta + q * eta).sum(axis=0)
+            s[3] += np.asarray(self.std_beta[c], dtype=np.float64) @ eta
+            s[4] += (eta ** 2).sum(axis=0)
+            s[5] += (gc * np.log(gc)).sum(axis=0)
+            s[6] += (ng * np.log(ng)).sum(axis=0)
+            s[7] += gc.sum(axis=0)
+            s[8] += ng.sum(axis=0)
+            s[9] += (gc * np.log(vt)).sum(axis=0)
+        return s
+
+    def _grid_params(self):
+        f = lambda x: np.asarray(x, dtype=np.float64) * np.ones(self.n_models)
+        return f(self.pi), f(self.tau_beta), f(self.sigma_epsilon), f(self._sigma_g)
+
+    def entropy(self, sum_axis=0):
+        if np.ndim(self.pi) == 0:
+            return super().entropy()
+        s = self._model_sums()
+        return 0.5 * self.n_snps * (np.log(2.0 * np.pi) + 1.0) - s[5] - s[6] - 0.5 * s[9]
+
+    def loglikelihood(self):
+        if np.ndim(self.pi) == 0:
+            return super().loglikelihood()
+        s = self._model_sums()
+        _, _, sig, sg = self._grid_params()
+        return -0.5 * self.n * (np.log(2.0 * np.pi * sig) + (1.0 / sig) * (1.0 - 2.0 * s[3] + sg))
+
+    def log_prior(self, sum_axis=0):
+        if np.ndim(self.pi) == 0:
+            return super().log_prior()
+        s = self._model_sums()
+        pi, tau, _, _ = self._grid_params()
+        return (0.5 * np.log(tau) * s[7] + np.log(pi) * s[7] + np.log(1.0 - pi) * s[8] - 0.5 * tau * s[1]
+                - 0.5 * self.n_snps * np.log(2.0 * np.pi))
+
+    def mse(self, sum_axis=0):
+        if np.ndim(self.pi) == 0:
+            return super().mse()
+        s = self._model_sums()
+        _, _, _, sg = self._grid_params()
+        return 1.0 - 2.0 * s[3] + (sg - s[1] + s[4])
+
+    def to_theta_table(self):
+        """Long table: one block of hyper-parameter rows per grid model."""
+        if np.ndim(self.pi) == 0:
+            return super().to_theta_table()
+        pi, tau, sig, sg = self._grid_params()
+        rows = []
+        for g in range(self.n_models):
+            for k, v in (("ELBO", float(self.model_elbos[g])), ("Residual_variance", sig[g]),
+                         ("Heritability", sg[g] / (sg[g] + sig[g])), ("Proportion_causal", pi[g]),
+                         ("Average_effect_variance", pi[g] / tau[g]), ("tau_beta", tau[g])):
+                rows.append({"Model": g, "Parameter": k, "Value": v})
+        return pd.DataFrame(rows)
 
     # ---- fitting -------------------------------------------------------------------------------------
     def fit(self, pathwise=True, batched=False, **fit_kwargs):
