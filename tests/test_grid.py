@@ -139,6 +139,19 @@ def test_posterior_table_and_pseudo_validation_cpu():
     tt = grid.to_theta_table()
     assert set(tt["Model"]) == set(range(G)) and "Heritability" in set(tt["Parameter"])
     grid.write_validation_result(os.devnull)
+    # pseudo-validation criterion (grid_utils.py:57-62): the model with the best pseudo-R^2 is kept
+    import copy
+    from viprs_amd.model.gridsearch import select_best_model
+    g2 = copy.copy(grid)
+    for name in ("pip", "post_mean_beta", "post_var_beta", "var_gamma", "var_mu", "var_tau", "eta", "zeta", "q",
+                 "_log_var_tau", "eta_diff"):
+        setattr(g2, name, {c: v.copy() for c, v in getattr(grid, name).items()})
+    g2.validation_result = grid.validation_result.copy()
+    g2.validation_std_beta = vb
+    want_best = int(np.argmax(np.where(grid.valid_terminated_models, r2, -np.inf)))
+    select_best_model(g2, criterion="pseudo_validation")
+    assert g2.best_model_idx == want_best and g2.pip[22].shape == (gdl.m,)
+    assert "Pseudo_Validation_R2" in g2.validation_result.columns
     grid._reset_search()
     assert grid.validation_result is None and grid.optim_results == []
 

@@ -1,7 +1,7 @@
 """Model selection / averaging over a fitted ``VIPRSGrid`` (viprs/model/gridsearch/grid_utils.py).
 
-``select_best_model`` supports the ELBO criterion; the validation criteria of the reference need its
-evaluation / prediction stack (out of scope).  Deviation, on purpose: models are ranked by
+``select_best_model`` supports the ELBO and the pseudo-validation criteria; the `validation` criterion of the
+reference needs its genotype prediction stack (out of scope).  Deviation, on purpose: models are ranked by
 their own final ELBOs (``VIPRSGrid.model_elbos`` = the ``ELBO`` column of ``validation_result``).  The
 reference calls ``VIPRS.elbo()`` on the (m, n_models) arrays (grid_utils.py:38), which sums the
 variational terms over ALL models and therefore only differs between models through the
@@ -13,15 +13,31 @@ import numpy as np
 
 
 def select_best_model(viprs_grid_model, validation_gdl=None, criterion="ELBO"):
-    if criterion != "ELBO":
-        raise NotImplementedError("only the ELBO criterion is available (validation metrics are out of scope)")
+    """grid_utils.py:8-100.  `pseudo_validation`: the model with the highest summary-statistics pseudo-R^2 on
+    held-out standardized betas -- `validation_gdl` may be a `{chromosome: std_beta}` dict (or an object with
+    that dict as `.std_beta`); otherwise `viprs_grid_model.validation_std_beta` is used."""
+    if criterion not in ("ELBO", "validation", "pseudo_validation"):
+        raise AssertionError(f"unknown criterion {criterion!r}")
+    if criterion == "validation":
+        raise NotImplementedError("the genotype-based validation criterion needs the reference's prediction stack")
     m = viprs_grid_model
     ok = m.valid_terminated_models
     if np.sum(ok) < 2:
         raise ValueError("Less than two models converged successfully. Cannot perform model selection.")
-    elbo = np.array(m.model_elbos, dtype=np.float64)
-    elbo[~ok] = -np.inf
-    best = int(np.argmax(elbo))
+    if criterion == "ELBO":
+        score = np.array(m.model_elbos, dtype=np.float64)
+    else:
+        vb = validation_gdl if isinstance(validation_gdl, dict) else getattr(validation_gdl, "std_beta", None)
+        if vb is None:
+            vb = getattr(m, "validation_std_beta", None)
+        if vb is None:
+            raise ValueError("Validation GWADataLoader or standardized betas from a validation set must be "
+                             "initialized for the pseudo_validation criterion.")
+        score = np.nan_to_num(np.asarray(m.pseudo_validate(vb), dtype=np.float64), nan=0.0, neginf=0.0, posinf=0.0)
+        m.validation_result["Pseudo_Validation_R2"] = score
+    score = score.copy()
+    score[~ok] = -np.inf
+    best = int(np.argmax(score))
     for param in (m.pip, m.post_mean_beta, m.post_var_beta, m.var_gamma, m.var_mu, m.var_tau, m.eta, m.zeta, m.q,
                   m._log_var_tau):
         for c in param:
