@@ -145,6 +145,8 @@ class VIPRSGrid(VIPRS):
     # ---- fitting -------------------------------------------------------------------------------------
     def fit(self, pathwise=True, batched=False, **fit_kwargs):
         fit_kwargs.pop("disable_pbar", None)
+        if self.n_models == 1:                   # after model selection / averaging: an ordinary VIPRS model
+            return super().fit(**fit_kwargs)
         if batched:
             return self._fit_batched(**fit_kwargs)
         return self._fit_serial(pathwise, **fit_kwargs)
