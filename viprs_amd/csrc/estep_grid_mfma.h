@@ -12,21 +12,22 @@
 //                      comes from the owning half through v_permlane32_swap) and apply row j of the
 //                      diagonal tile -- staged in LDS as fp32, read as broadcast ds_read_b128 -- to
 //                      their 32 columns.
-//   waves 1..7         the trailing rank-64 update of every other 64-column tile as a GEMM on the
-//                      matrix cores:  Q[32 models x 32 cols] += A[32 models x 64 rows] . R[64 rows x 32 cols]
-//                      with v_mfma_f32_32x32x2_f32, 32 MFMAs per 32-column tile.  On gfx950 that
-//                      instruction is bit-for-bit a k-ordered chain of fp32 fma (one rounding per
-//                      product, no wider accumulator), i.e. exactly the reference's sequence
-//                      q = fma(R[j][c], a_j, q) for j ascending -- so the batched kernel stays
-//                      bit-identical to e_step_grid in symmetric form (tools/mfma_check.py measures
-//                      that property on the device; tests/test_gpu_models.py holds the parity).
-//                      Rows are loaded once per 64-column tile (256 B per row) and split into the two
-//                      32-column B operands with one v_permlane32_swap per row pair.  They also stage
-//                      the next panel's inputs / diagonal tile and flush the previous panel's outputs.
+//   waves 1..7         the trailing rank-64 update of the tiles RIGHT of the chain as a GEMM on the matrix
+//                      cores:  Q[32 models x cols] += A[32 models x 64 rows] . R[64 rows x cols]  with
+//                      v_mfma_f32_32x32x2_f32.  On gfx950 that instruction is bit-for-bit a k-ordered chain
+//                      of fp32 fma (one rounding per product, no wider accumulator), i.e. exactly the
+//                      reference's sequence q = fma(R[j][c], a_j, q) for j ascending -- so the batched
+//                      kernel stays bit-identical to e_step_grid (tests/test_gpu_models.py and the golden
+//                      fixtures hold the parity, both LD forms).  128-column tiles: one 16-byte load per
+//                      lane is directly the B operand of four MFMAs (wtile_*); wave 1 additionally carries
+//                      the 64-column tile the chain needs next across the barrier (tile_*).  They also
+//                      stage the next panel's inputs / diagonal tile and flush the previous panel's outputs.
 //
-// q of the block stays in global memory (the (m, G) state itself, L2-resident for the workgroup):
-// per phase the MFMA tiles read and write 128 B per column and model, the same order of traffic
-// as the LD rows.  One workgroup per LD block, blocks pulled from a queue in descending size.
+// q of the block stays in global memory (the (m, G) state itself): per phase the tiles right of the chain
+// are read and written once.  The columns LEFT of the chain (symmetric form) are finished after the sweep by
+// estep_grid_lower_pass_kernel with the accumulators resident in registers; the upper-triangular form's
+// second pass is estep_grid_upper_epilogue_kernel.  One workgroup per LD block, blocks pulled from a queue
+// in descending size.
 #pragma once
 #include "device_math.h"
 #include "estep_panel.h"
