@@ -806,21 +806,28 @@ __global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs
         const int nrows = min(kPanel, b - r0);
         float s = 0.0f;
 
-        // all 64 row loads of a tile are issued before the previous tile is consumed: one tile
-        // (16 KB per wave) is always in flight
-        float cur[kPanel], nxt[kPanel];
-        const U* __restrict__ p0 = base + (int64_t)r0 * stride + lane;
+        // A 64 x 64 tile = 16 row-group loads of 4 rows x 64 columns (16 B per lane for fp32), raw bytes kept in
+        // registers; the next tile's loads are all issued before the current one is consumed (the vector
+        // memory queue holds 63 loads per wave: 4-byte loads would throttle here).
+        const int trow = lane >> 4, tcol = (lane & 15) * 4;
+        RawRow<U, 4> cur[kPanel / 4], nxt[kPanel / 4];
+        const U* __restrict__ p0 = base + (int64_t)r0 * stride + tcol;
 #pragma unroll
-        for (int k = 0; k < kPanel; ++k) cur[k] = static_cast<float>(p0[(int64_t)min(k, nrows - 1) * stride + r0]);
+        for (int i = 0; i < kPanel / 4; ++i)
+            cur[i] = load_raw<U, 4>(p0 + (int64_t)min(4 * i + trow, nrows - 1) * stride + r0);
         for (int c0 = r0; c0 < b; c0 += kPanel) {
             const int cn = (c0 + kPanel < b) ? c0 + kPanel : c0;            // next tile (or this one again)
 #pragma unroll
-            for (int k = 0; k < kPanel; ++k) nxt[k] = static_cast<float>(p0[(int64_t)min(k, nrows - 1) * stride + cn]);
+            for (int i = 0; i < kPanel / 4; ++i)
+                nxt[i] = load_raw<U, 4>(p0 + (int64_t)min(4 * i + trow, nrows - 1) * stride + cn);
             const int col = c0 + lane;
             const float dv = (col < b) ? A.eta_diff[s0 + col] : 0.0f;
+            asm volatile("" ::: "memory");                                  // loads stay up here (hipcc would sink them)
             // transpose through LDS (pitch 65: conflict-free both ways): lane r walks row r
 #pragma unroll
-            for (int k = 0; k < kPanel; ++k) tl[k * (kPanel + 1) + lane] = cur[k];
+            for (int i = 0; i < kPanel / 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tl[(4 * i + trow) * (kPanel + 1) + tcol + e] = cur[i].get(e);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll 16
             for (int i = 0; i < kPanel; ++i) {
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < kPanel; ++k) cur[k] = nxt[k];
+            for (int i = 0; i < kPanel / 4; ++i) cur[i] = nxt[i];
         }
         if (lane < nrows) A.q[s0 + r0 + lane] += A.dq * s;
     }
