@@ -97,6 +97,18 @@ int viprs_plan_blocks(int64_t m, const int32_t* ld_left_bound, const void* ld_in
 int viprs_plan_create(viprs_plan** plan, int64_t m, const int32_t* ld_left_bound,
                       const void* ld_indptr, int indptr_dtype, const void* ld_data, int ld_dtype,
                       int low_memory, int device);
+/* Symmetric plan (the `low_memory = False` arithmetic, e_step.hpp:421-428) built from the compact
+ * UPPER-TRIANGULAR store: row j of `upper_data` holds the correlations with SNPs j+1 .. j+len_j
+ * (`upper_indptr`, m + 1 entries), as LD matrices are kept on disk.  The store is uploaded once and
+ * mirrored into the symmetric windows on the device; `diag_value` fills the diagonal (1 for float
+ * LD, the quantisation maximum -- 127 / 32767 -- for integer LD).  Replaces the host-side
+ * `ld_mat.load(return_symmetric=True)` of VIPRS.py:167-172: the symmetric copy never exists in host
+ * memory and half the bytes cross PCIe.  The right ends j + len_j must not decrease (otherwise the
+ * mirrored rows would not be contiguous windows): VIPRS_EINVAL.
+ * viprs_plan_get_windows returns the (left_bound, indptr) arrays of the plan's rows (any plan). */
+int viprs_plan_create_expanded(viprs_plan** plan, int64_t m, const void* upper_indptr, int indptr_dtype,
+                               const void* upper_data, int ld_dtype, double diag_value, int device);
+int viprs_plan_get_windows(const viprs_plan* plan, int32_t* left_bound, int64_t* indptr);
 int viprs_plan_destroy(viprs_plan* plan);
 
 enum viprs_plan_info_key {

@@ -57,6 +57,8 @@ _PROTOS = {
     "viprs_check_omp_support": (_i, []),
     "viprs_plan_blocks": (_i, [_i64, _vp, _vp, _i, _i, _pi64, _vp, _vp]),
     "viprs_plan_create": (_i, [ctypes.POINTER(_vp), _i64, _vp, _vp, _i, _vp, _i, _i, _i]),
+    "viprs_plan_create_expanded": (_i, [ctypes.POINTER(_vp), _i64, _vp, _i, _vp, _i, ctypes.c_double, _i]),
+    "viprs_plan_get_windows": (_i, [_vp, _vp, _vp]),
     "viprs_plan_destroy": (_i, [_vp]),
     "viprs_plan_info": (_i, [_vp, _i, _pi64]),
     "viprs_plan_get_blocks": (_i, [_vp, _vp, _vp]),

@@ -91,6 +91,37 @@ __global__ void repack_dense_kernel(const U* __restrict__ src, const int64_t* __
     }
 }
 
+// symmetric expansion on the device: row j of the symmetric store = [mirror of the upper rows that
+// reach j | diagonal | row j of the upper store].  Replaces the host-side symmetric load of
+// VIPRS.py:167-172 (`ld_mat.load(return_symmetric=True)`): the compact store crosses PCIe once and
+// the symmetric copy never exists in host memory.  Pure data movement, values are not touched.
+template <typename U>
+__global__ void expand_symmetric_kernel(const U* __restrict__ up, const int64_t* __restrict__ ipu,
+                                        const int32_t* __restrict__ lb, const int64_t* __restrict__ ip,
+                                        U* __restrict__ out, int64_t m, U diag) {
+    for (int64_t j = blockIdx.x; j < m; j += gridDim.x) {
+        const int64_t o = ip[j];
+        const int len = (int)(ip[j + 1] - o);
+        const int64_t c0 = lb[j];
+        const int64_t uj = ipu[j];
+        for (int p = threadIdx.x; p < len; p += blockDim.x) {
+            const int64_t c = c0 + p;
+            U v = diag;
+            if (c > j) v = up[uj + (c - j - 1)];
+            else if (c < j) v = up[ipu[c] + (j - c - 1)];
+            out[o + p] = v;
+        }
+    }
+}
+
+template <typename U>
+static hipError_t launch_expand(const void* up, const int64_t* ipu, const int32_t* lb, const int64_t* ip, void* out,
+                                int64_t m, double diag) {
+    const unsigned grid = (unsigned)std::min<int64_t>(m, 1 << 16);
+    expand_symmetric_kernel<U><<<grid, 256>>>((const U*)up, ipu, lb, ip, (U*)out, m, (U)diag);
+    return hipGetLastError();
+}
+
 // device-side re-initialisation to the standard start (VIPRS.py:344-358) in ONE launch
 template <typename T>
 __global__ void reset_state_kernel(T* var_gamma, T* var_mu, int64_t n_wide, T* eta, T* q, T* eta_diff, int64_t n_vec,
@@ -425,61 +456,16 @@ viprs_plan::~viprs_plan() {
 // ------------------------------------------------------------------------------------------------
 static int check_device_error(viprs_plan* P);
 
-extern "C" {
+// what viprs_plan_create_expanded hands to the common path: the compact upper-triangular store the
+// symmetric rows are built from on the device
+struct ExpandSource {
+    std::vector<int64_t> ip_upper;
+    const void* data = nullptr;
+    double diag = 1.0;
+};
 
-const char* viprs_last_error(void) { return g_err.c_str(); }
-const char* viprs_version(void) { return "viprs_amd 0.1.0 (gfx950)"; }
-
-int viprs_device_count(int* count) {
-    if (!count) return fail(VIPRS_EINVAL, "count is null");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *count = 0; return fail(VIPRS_EDEVICE, hipGetErrorString(e)); }
-    *count = n;
-    return VIPRS_OK;
-}
-
-int viprs_check_blas_support(void) { return 0; }
-int viprs_check_omp_support(void) { return 0; }
-
-int viprs_plan_blocks(int64_t m, const int32_t* lb, const void* indptr, int indptr_dtype, int low_memory,
-                      int64_t* n_blocks, int64_t* block_start, int32_t* block_kind) {
-    if (!n_blocks || !block_start) return fail(VIPRS_EINVAL, "null output");
-    if (m > 0 && (!lb || !indptr)) return fail(VIPRS_EINVAL, "null LD index array");
-    std::vector<int64_t> ip64;
-    const int64_t* ip = nullptr;
-    if (indptr_dtype == VIPRS_IP_I64) {
-        ip = static_cast<const int64_t*>(indptr);
-    } else if (indptr_dtype == VIPRS_IP_I32) {
-        const int32_t* p = static_cast<const int32_t*>(indptr);
-        ip64.assign(p, p + m + 1);
-        ip = ip64.data();
-    } else {
-        return fail(VIPRS_EINVAL, "bad indptr dtype code");
-    }
-    std::vector<Block> blocks;
-    std::string err;
-    int rc = plan_blocks(m, lb, ip, low_memory != 0, blocks, err);
-    if (rc != VIPRS_OK) return fail(rc, err);
-    *n_blocks = (int64_t)blocks.size();
-    for (size_t i = 0; i < blocks.size(); ++i) {
-        block_start[i] = blocks[i].start;
-        if (block_kind) block_kind[i] = blocks[i].kind;
-    }
-    block_start[blocks.size()] = m;
-    return VIPRS_OK;
-}
-
-int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void* indptr, int indptr_dtype,
-                      const void* ld_data, int ld_dtype, int low_memory, int device) {
-    if (!out) return fail(VIPRS_EINVAL, "plan output is null");
-    *out = nullptr;
-    const size_t es = ld_elem_size(ld_dtype);
-    if (es == 0) return fail(VIPRS_EINVAL, "bad LD dtype code");
-    if (m < 0 || m > INT32_MAX) return fail(VIPRS_EINVAL, "m out of range");
-    if (m > 0 && (!lb || !indptr)) return fail(VIPRS_EINVAL, "null LD index array");
-
-    std::vector<int64_t> ip64((size_t)m + 1, 0);
+static int widen_indptr(int64_t m, const void* indptr, int indptr_dtype, std::vector<int64_t>& ip64) {
+    ip64.assign((size_t)m + 1, 0);
     if (indptr_dtype == VIPRS_IP_I64) {
         if (m > 0) std::memcpy(ip64.data(), indptr, sizeof(int64_t) * ((size_t)m + 1));
     } else if (indptr_dtype == VIPRS_IP_I32) {
@@ -488,7 +474,12 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     } else {
         return fail(VIPRS_EINVAL, "bad indptr dtype code");
     }
+    return VIPRS_OK;
+}
 
+static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, const std::vector<int64_t>& ip64,
+                            const void* ld_data, int ld_dtype, int low_memory, int device, const ExpandSource* ex) {
+    const size_t es = ld_elem_size(ld_dtype);
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
     if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
@@ -504,7 +495,7 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     int rc = plan_blocks(m, lb, ip64.data(), low_memory != 0, P->blocks, err);
     if (rc != VIPRS_OK) return fail(rc, err);
     P->nnz = m > 0 ? ip64[(size_t)m] : 0;
-    if (P->nnz > 0 && !ld_data) return fail(VIPRS_EINVAL, "ld_data is null");
+    if (P->nnz > 0 && !ld_data && !ex) return fail(VIPRS_EINVAL, "ld_data is null");
 
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -614,7 +605,29 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     }
     if (P->nnz > 0) {
         HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es));
-        HIP_TRY(hipMemcpy(P->d_ld_raw.p, ld_data, (size_t)P->nnz * es, hipMemcpyHostToDevice));
+        if (!ex) {
+            HIP_TRY(hipMemcpy(P->d_ld_raw.p, ld_data, (size_t)P->nnz * es, hipMemcpyHostToDevice));
+        } else {
+            // upload the compact store, mirror it into the symmetric rows on the device, drop it
+            const size_t nnz_u = (size_t)ex->ip_upper[(size_t)m];
+            DevBuf<char> d_up;
+            DevBuf<int64_t> d_ipu;
+            HIP_TRY(d_up.alloc(std::max<size_t>(nnz_u, 1) * es));
+            HIP_TRY(d_ipu.alloc((size_t)m + 1));
+            if (nnz_u) HIP_TRY(hipMemcpy(d_up.p, ex->data, nnz_u * es, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_ipu.p, ex->ip_upper.data(), sizeof(int64_t) * ((size_t)m + 1), hipMemcpyHostToDevice));
+            hipError_t e = hipSuccess;
+            switch (ld_dtype) {
+                case VIPRS_LD_I8:  e = launch_expand<int8_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_I16: e = launch_expand<int16_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_I32: e = launch_expand<int32_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_I64: e = launch_expand<int64_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_F32: e = launch_expand<float>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                default:           e = launch_expand<double>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+            }
+            HIP_TRY(e);
+            HIP_TRY(hipDeviceSynchronize());
+        }
     }
     if (P->n_granule_rows > 0) HIP_TRY(P->d_granules.alloc((size_t)P->n_granule_rows * kPanel));
     if (!P->dense_h.empty()) {
@@ -707,6 +720,107 @@ int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void
     return VIPRS_OK;
 }
 
+
+extern "C" {
+
+const char* viprs_last_error(void) { return g_err.c_str(); }
+const char* viprs_version(void) { return "viprs_amd 0.1.0 (gfx950)"; }
+
+int viprs_device_count(int* count) {
+    if (!count) return fail(VIPRS_EINVAL, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(VIPRS_EDEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return VIPRS_OK;
+}
+
+int viprs_check_blas_support(void) { return 0; }
+int viprs_check_omp_support(void) { return 0; }
+
+int viprs_plan_blocks(int64_t m, const int32_t* lb, const void* indptr, int indptr_dtype, int low_memory,
+                      int64_t* n_blocks, int64_t* block_start, int32_t* block_kind) {
+    if (!n_blocks || !block_start) return fail(VIPRS_EINVAL, "null output");
+    if (m > 0 && (!lb || !indptr)) return fail(VIPRS_EINVAL, "null LD index array");
+    std::vector<int64_t> ip64;
+    const int64_t* ip = nullptr;
+    if (indptr_dtype == VIPRS_IP_I64) {
+        ip = static_cast<const int64_t*>(indptr);
+    } else if (indptr_dtype == VIPRS_IP_I32) {
+        const int32_t* p = static_cast<const int32_t*>(indptr);
+        ip64.assign(p, p + m + 1);
+        ip = ip64.data();
+    } else {
+        return fail(VIPRS_EINVAL, "bad indptr dtype code");
+    }
+    std::vector<Block> blocks;
+    std::string err;
+    int rc = plan_blocks(m, lb, ip, low_memory != 0, blocks, err);
+    if (rc != VIPRS_OK) return fail(rc, err);
+    *n_blocks = (int64_t)blocks.size();
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        block_start[i] = blocks[i].start;
+        if (block_kind) block_kind[i] = blocks[i].kind;
+    }
+    block_start[blocks.size()] = m;
+    return VIPRS_OK;
+}
+
+int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void* indptr, int indptr_dtype,
+                      const void* ld_data, int ld_dtype, int low_memory, int device) {
+    if (!out) return fail(VIPRS_EINVAL, "plan output is null");
+    *out = nullptr;
+    if (ld_elem_size(ld_dtype) == 0) return fail(VIPRS_EINVAL, "bad LD dtype code");
+    if (m < 0 || m > INT32_MAX) return fail(VIPRS_EINVAL, "m out of range");
+    if (m > 0 && (!lb || !indptr)) return fail(VIPRS_EINVAL, "null LD index array");
+    std::vector<int64_t> ip64;
+    int rc = widen_indptr(m, indptr, indptr_dtype, ip64);
+    if (rc != VIPRS_OK) return rc;
+    return plan_create_impl(out, m, lb, ip64, ld_data, ld_dtype, low_memory, device, nullptr);
+}
+
+int viprs_plan_create_expanded(viprs_plan** out, int64_t m, const void* upper_indptr, int indptr_dtype,
+                               const void* upper_data, int ld_dtype, double diag_value, int device) {
+    if (!out) return fail(VIPRS_EINVAL, "plan output is null");
+    *out = nullptr;
+    if (ld_elem_size(ld_dtype) == 0) return fail(VIPRS_EINVAL, "bad LD dtype code");
+    if (m < 0 || m > INT32_MAX) return fail(VIPRS_EINVAL, "m out of range");
+    if (m > 0 && !upper_indptr) return fail(VIPRS_EINVAL, "null LD index array");
+    ExpandSource ex;
+    int rc = widen_indptr(m, upper_indptr, indptr_dtype, ex.ip_upper);
+    if (rc != VIPRS_OK) return rc;
+    ex.data = upper_data;
+    ex.diag = diag_value;
+    if (m > 0 && ex.ip_upper[(size_t)m] > 0 && !upper_data) return fail(VIPRS_EINVAL, "ld_data is null");
+    // symmetric windows: row j = [first row that reaches j .. j + len_j].  They are contiguous (the
+    // layout e_step.hpp:389-392 needs) iff the right ends j + len_j never decrease.
+    std::vector<int32_t> lb((size_t)m, 0);
+    std::vector<int64_t> ip((size_t)m + 1, 0);
+    int64_t first = 0, prev_reach = -1;
+    for (int64_t j = 0; j < m; ++j) {
+        const int64_t len = ex.ip_upper[(size_t)j + 1] - ex.ip_upper[(size_t)j];
+        if (len < 0) return fail(VIPRS_EINVAL, "ld_indptr is not non-decreasing");
+        const int64_t reach = j + len;
+        if (reach >= m) return fail(VIPRS_EINVAL, "an upper-triangular LD row runs past the last SNP");
+        if (reach < prev_reach) return fail(VIPRS_EINVAL, "the upper-triangular windows do not mirror into contiguous symmetric windows");
+        prev_reach = reach;
+        while (first < j && first + (ex.ip_upper[(size_t)first + 1] - ex.ip_upper[(size_t)first]) < j) ++first;
+        lb[(size_t)j] = (int32_t)first;
+        ip[(size_t)j + 1] = ip[(size_t)j] + (j - first) + 1 + len;
+    }
+    return plan_create_impl(out, m, lb.data(), ip, nullptr, ld_dtype, 0, device, &ex);
+}
+
+int viprs_plan_get_windows(const viprs_plan* P, int32_t* left_bound, int64_t* indptr) {
+    if (!P || !left_bound || !indptr) return fail(VIPRS_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(P->device));
+    indptr[0] = 0;
+    if (P->m > 0) {
+        HIP_TRY(hipMemcpy(left_bound, P->d_lb.p, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(indptr, P->d_ip.p, sizeof(int64_t) * ((size_t)P->m + 1), hipMemcpyDeviceToHost));
+    }
+    return VIPRS_OK;
+}
 int viprs_plan_destroy(viprs_plan* plan) {
     if (!plan) return VIPRS_OK;
     (void)hipSetDevice(plan->device);

@@ -104,3 +104,33 @@ def merge_ld_arrays(chroms, shapes, ld_left_bound, ld_indptr, ld_data):
                          for i, c in enumerate(chroms)] + [nnz_off[-1:]])
     data = np.concatenate([ld_data[c] for c in chroms])
     return lb, ip, data, seg
+
+
+def mirror_upper_ld(ld_indptr, ld_data, diag_value=None):
+    """Host model of ``LDPlan.from_upper`` / ``viprs_plan_create_expanded``: the symmetric windowed
+    arrays ``(left_bound int32, indptr int64, data)`` of the compact upper-triangular store (row j =
+    correlations with SNPs j+1 .. j+len_j).  Row j of the result is [mirror of the rows that reach j |
+    diagonal | row j].  Used by the CPU tests and the ``e_step_fn`` test hook; the device path never
+    builds the symmetric copy on the host."""
+    ip_u = np.asarray(ld_indptr, dtype=np.int64)
+    m = ip_u.shape[0] - 1
+    if diag_value is None:
+        diag_value = np.iinfo(ld_data.dtype).max if np.issubdtype(ld_data.dtype, np.integer) else 1
+    length = np.diff(ip_u)
+    reach = np.arange(m, dtype=np.int64) + length
+    if m and (np.any(np.diff(reach) < 0) or reach[-1] >= m):
+        raise ValueError("the upper-triangular windows do not mirror into contiguous symmetric windows")
+    # first row whose window reaches j (reach is non-decreasing)
+    first = np.minimum(np.searchsorted(reach, np.arange(m), side="left"), np.arange(m))
+    lb = first.astype(np.int32)
+    ip = np.concatenate([[0], np.cumsum(np.arange(m) - first + 1 + length)]).astype(np.int64)
+    data = np.empty(int(ip[-1]), dtype=ld_data.dtype)
+    for j in range(m):
+        o = int(ip[j])
+        n_left = j - int(first[j])
+        if n_left:
+            rows = np.arange(first[j], j)
+            data[o:o + n_left] = ld_data[ip_u[rows] + (j - rows - 1)]
+        data[o + n_left] = diag_value
+        data[o + n_left + 1:int(ip[j + 1])] = ld_data[ip_u[j]:ip_u[j + 1]]
+    return lb, ip, data

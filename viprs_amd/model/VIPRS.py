@@ -37,7 +37,7 @@ class VIPRS:
     def __init__(self, gdl, fix_params=None, tracked_params=None, lambda_min=None, float_precision="float32",
                  order="F", low_memory=True, dequantize_on_the_fly=False, threads=1,
                  device=None, comm=None, math_mode="exact", e_step_fn=None, device_resident=True,
-                 merge_chromosomes=True):
+                 merge_chromosomes=True, expand_ld_on_device=None):
         """Same arguments as the reference (VIPRS.py:68-77) plus:
 
         :param device: HIP device index (default: ``comm.rank`` modulo the visible devices).
@@ -52,6 +52,12 @@ class VIPRS:
             into ONE device plan (blocks are independent, chromosomes only matter for the ``update_pi``
             mean, kept through per-SNP weights): one set of launches and one reduction per EM iteration
             instead of one per chromosome.
+        :param expand_ld_on_device: ``low_memory=False`` only -- load the compact upper-triangular store
+            and mirror it into the symmetric windows on the GPU (``LDPlan.from_upper``) instead of asking
+            the LD matrix for ``load(return_symmetric=True)``: the symmetric copy never exists in host
+            memory and half the bytes cross PCIe.  ``None`` (default): only when the LD matrix cannot
+            hand out the symmetric form itself.  The host attributes ``ld_data / ld_indptr /
+            ld_left_bound`` then hold the upper-triangular arrays.
         """
         if gdl.genotype is None and (gdl.ld is None or gdl.sumstats_table is None):
             raise AssertionError("The data loader must contain summary statistics and LD matrices.")
@@ -84,6 +90,7 @@ class VIPRS:
         # ---- LD: load, then make it device-resident (VIPRS.py:151-191) -------------------------
         self.ld_data, self.ld_indptr, self.ld_left_bound = {}, {}, {}
         self.lambda_min = 0.0
+        self._expanded = False
         for c in self.chromosomes:
             ld_mat = ld_mats[c]
             if dequantize_on_the_fly and np.issubdtype(ld_mat.stored_dtype, np.integer):
@@ -91,7 +98,17 @@ class VIPRS:
             else:
                 dtype = float_precision
                 dequantize_on_the_fly = False
-            lop = ld_mat.load(return_symmetric=not low_memory, dtype=dtype)
+            expand = bool(expand_ld_on_device) and not low_memory
+            if not expand:
+                try:
+                    lop = ld_mat.load(return_symmetric=not low_memory, dtype=dtype)
+                except ValueError:
+                    if low_memory or expand_ld_on_device is False:
+                        raise
+                    expand = True
+            if expand:
+                lop = ld_mat.load(return_symmetric=False, dtype=dtype)
+                self._expanded = True
             self.ld_data[c], self.ld_indptr[c], self.ld_left_bound[c] = lop.ld_data, lop.ld_indptr, lop.leftmost_idx
             if lambda_min is None:
                 self.lambda_min = 0.0
@@ -122,7 +139,10 @@ class VIPRS:
                 chroms = self.chromosomes
                 lb, ip, data, self._seg = merge_ld_arrays(chroms, self.shapes, self.ld_left_bound, self.ld_indptr,
                                                           self.ld_data)
-                self._plans["*"] = LDPlan(lb, ip, data, low_memory, device=self.device, math_mode=math_mode)
+                if self._expanded:
+                    self._plans["*"] = LDPlan.from_upper(ip, data, device=self.device, math_mode=math_mode)
+                else:
+                    self._plans["*"] = LDPlan(lb, ip, data, low_memory, device=self.device, math_mode=math_mode)
                 del data
                 ds = self._dstate["*"] = self._make_device_state(self._plans["*"])
                 ds.upload("std_beta", np.concatenate([self.std_beta[c] for c in chroms]))
@@ -130,8 +150,12 @@ class VIPRS:
                 ds.set_snp_weights(np.concatenate([np.full(self.shapes[c], 1.0 / self.shapes[c]) for c in chroms]))
             else:
                 for c in self.chromosomes:
-                    self._plans[c] = LDPlan(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], low_memory,
-                                            device=self.device, math_mode=math_mode)
+                    if self._expanded:
+                        self._plans[c] = LDPlan.from_upper(self.ld_indptr[c], self.ld_data[c], device=self.device,
+                                                           math_mode=math_mode)
+                    else:
+                        self._plans[c] = LDPlan(self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c], low_memory,
+                                                device=self.device, math_mode=math_mode)
                     self._dstate[c] = self._make_device_state(self._plans[c])
                     self._dstate[c].upload("std_beta", self.std_beta[c])
                 if self._resident:
@@ -139,6 +163,12 @@ class VIPRS:
                         self._dstate[c].set_n_per_snp(self.n_per_snp[c])
         else:
             self._resident = self._merged = False
+            if self._expanded:          # test hook: the host model of the device-side expansion
+                from ..data import mirror_upper_ld
+                for c in self.chromosomes:
+                    self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c] = mirror_upper_ld(
+                        self.ld_indptr[c], self.ld_data[c])
+                self._expanded = False
         self._host_stale = False
         self._last_prep = None
 

@@ -74,6 +74,46 @@ class LDPlan:
                                         int(self.low_memory), self.device))
         self.set_math_mode(math_mode)
 
+    @classmethod
+    def from_upper(cls, ld_indptr, ld_data, diag_value=None, device=0, math_mode="exact"):
+        """Symmetric plan (``low_memory=False`` arithmetic) from the compact upper-triangular store
+        (row j = correlations with SNPs j+1 .. j+len_j): uploaded once and mirrored into the symmetric
+        windows on the device -- the host never builds ``ld_mat.load(return_symmetric=True)``
+        (VIPRS.py:167-172).  ``diag_value`` defaults to 1 for float LD and to the quantisation maximum
+        (``np.iinfo(dtype).max``) for integer LD."""
+        if not isinstance(ld_indptr, np.ndarray) or ld_indptr.dtype not in _IP_CODE:
+            raise ValueError("Buffer dtype mismatch, expected int32/int64 ld_indptr but got "
+                             f"'{getattr(ld_indptr, 'dtype', type(ld_indptr))}'")
+        if ld_indptr.ndim != 1 or not ld_indptr.flags.c_contiguous or ld_indptr.shape[0] < 1:
+            raise ValueError("ld_indptr must be a C-contiguous 1-d array with m + 1 entries")
+        if not isinstance(ld_data, np.ndarray) or ld_data.dtype not in _LD_CODE:
+            raise ValueError("Buffer dtype mismatch for ld_data: "
+                             f"'{getattr(ld_data, 'dtype', type(ld_data))}' is not a supported LD dtype")
+        if ld_data.ndim != 1 or not ld_data.flags.c_contiguous:
+            raise ValueError("ld_data must be a C-contiguous 1-d array")
+        self = cls.__new__(cls)
+        self.m = int(ld_indptr.shape[0]) - 1
+        if self.m and int(ld_indptr[-1]) != ld_data.shape[0]:
+            raise ValueError("ld_indptr[-1] must equal len(ld_data)")
+        if diag_value is None:
+            diag_value = float(np.iinfo(ld_data.dtype).max) if np.issubdtype(ld_data.dtype, np.integer) else 1.0
+        self.low_memory = False
+        self.ld_dtype = ld_data.dtype
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        L.check(L.lib.viprs_plan_create_expanded(ctypes.byref(self._h), self.m, _ptr(ld_indptr),
+                                                 _IP_CODE[ld_indptr.dtype], _ptr(ld_data), _LD_CODE[ld_data.dtype],
+                                                 float(diag_value), self.device))
+        self.set_math_mode(math_mode)
+        return self
+
+    def windows(self):
+        """``(ld_left_bound int32, ld_indptr int64)`` of the plan's rows."""
+        lb = np.zeros(self.m, dtype=np.int32)
+        ip = np.zeros(self.m + 1, dtype=np.int64)
+        L.check(L.lib.viprs_plan_get_windows(self.handle, _ptr(lb), _ptr(ip)))
+        return lb, ip
+
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
