@@ -122,3 +122,19 @@ def test_grid_upper_batched_equals_item_path(gpu, ld_dtype, monkeypatch):
         g, st0 = _grid_inputs(ld, ss, 11)
         res[mfma] = _run_grid(S, ld, inp, g, st0, np.arange(11, dtype=np.int32), sweeps=3)
     H.assert_state_equal(res["1"], res["0"])
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_very_large_blocks_all_models(gpu, low_memory, monkeypatch):
+    """LD blocks far beyond BASELINE's largest (6 000 SNPs): 13 000- and 9 001-SNP blocks through the
+    8-CU teams, the mixture teams and the batched grid kernel -- bit-for-bit against the oracle."""
+    from viprs_amd.vi import e_step_hip as S
+    ld, ss, inp = syn.make_problem(sizes=[13000, 9001, 65], low_memory=low_memory, seed=47)
+    st0 = inp.state_copy()
+    H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=1), H.run_oracle(ld, inp, st0, sweeps=1))
+    mix, mst0 = _mixture_inputs(ld, ss, 4)
+    H.assert_state_equal(_run_mix(S, ld, inp, mix, mst0, 1), _run_mix(O, ld, inp, mix, mst0, 1))
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    g, gst0 = _grid_inputs(ld, ss, 8)
+    active = np.arange(8, dtype=np.int32)
+    H.assert_state_equal(_run_grid(S, ld, inp, g, gst0, active, sweeps=1), _run_grid(O, ld, inp, g, gst0, active, sweeps=1))

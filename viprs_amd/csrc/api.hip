@@ -15,6 +15,7 @@
 #include "../../include/viprs_hip.h"
 #include "estep_generic.h"
 #include "estep_grid_mfma.h"
+#include "estep_band.h"
 #include "estep_panel.h"
 #include "planner.h"
 
@@ -397,6 +398,7 @@ struct viprs_plan {
     DevBuf<char> d_ld_dense;
     int64_t dense_elems = 0;
     int max_dense = 0, max_ragged = 0;
+    int max_band_panels = 0;                // ragged blocks: widest (band_left + band_right + 2), sizes the band kernel's q ring
     DevBuf<int32_t> d_counters;             // [0] dense queue head, [1] ragged queue head
     DevBuf<unsigned long long> d_skipped;
     // HIP-event ring: per sweep {sweep start, sweep end, panel start, panel end}, recorded on
@@ -541,6 +543,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         d.stride = 0;
         d.ld_off = 0;
         d.gr_off = 0;
+        d.band_left = d.band_right = 0;
         const bool dense = panel_ld && (b.kind == VIPRS_BLOCK_DENSE_SYM || b.kind == VIPRS_BLOCK_DENSE_UPPER);
         if (dense) {
             d.stride = (d.size + kPanel - 1) / kPanel * kPanel;
@@ -550,6 +553,17 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
             P->dense_h.push_back(d);
             P->max_dense = std::max(P->max_dense, d.size);
         } else {
+            // reach of the row windows around the diagonal, in panels (band kernel, estep_band.h)
+            int64_t wl = 0, wr = 0;
+            for (int64_t j = b.start; j < b.end; ++j) {
+                const int64_t len = ip64[(size_t)j + 1] - ip64[(size_t)j];
+                if (len <= 0) continue;
+                wl = std::max<int64_t>(wl, j - lb[j]);
+                wr = std::max<int64_t>(wr, lb[j] + len - 1 - j);
+            }
+            d.band_left = (int32_t)(wl / kPanel + 1);
+            d.band_right = (int32_t)(wr / kPanel + 1);
+            P->max_band_panels = std::max(P->max_band_panels, d.band_left + d.band_right + 2);
             P->ragged_h.push_back(d);
             P->max_ragged = std::max(P->max_ragged, d.size);
         }
@@ -604,7 +618,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         }
     }
     if (P->nnz > 0) {
-        HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es));
+        HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es + 64));      // + slack: the band kernel clamps empty rows to their start
         if (!ex) {
             HIP_TRY(hipMemcpy(P->d_ld_raw.p, ld_data, (size_t)P->nnz * es, hipMemcpyHostToDevice));
         } else {
@@ -1252,6 +1266,59 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A, int model = kPanelSpikeSlab)
     return VIPRS_OK;
 }
 
+// Windowed (ragged) components, fp32 state, f32 / int8 / int16 LD, lane-per-SNP model policies: the band
+// kernel (estep_band.h).  VIPRS_BAND=0 sends them back to the generic kernel.
+enum { kBandSpikeSlab = 0, kBandGridColumn = 1 };
+
+static int band_ring_panels(const viprs_plan* P) {
+    int rp = 4;
+    while (rp < P->max_band_panels) rp *= 2;
+    return rp;
+}
+
+static bool use_band(const viprs_plan* P) {
+    const char* f = getenv("VIPRS_BAND");
+    if ((f && !atoi(f)) || P->ragged_h.empty()) return false;
+    if (P->ld_dtype != VIPRS_LD_F32 && P->ld_dtype != VIPRS_LD_I8 && P->ld_dtype != VIPRS_LD_I16) return false;
+    return band_ring_panels(P) <= kBandMaxRingPanels;
+}
+
+template <typename U>
+int launch_band(viprs_plan* P, EStepArgs<float> A, int model) {
+    A.blocks = P->d_ragged.p;
+    A.n_blocks = (int)P->ragged_h.size();
+    A.counter = P->d_counters.p + 1;
+    const int ring = band_ring_panels(P);
+    const size_t shmem = (size_t)band_lds_floats(ring) * sizeof(float);
+    const bool exact = P->math_mode == VIPRS_MATH_EXACT;
+    const bool upper = P->low_memory != 0;
+    void (*kfn)(EStepArgs<float>, int) = nullptr;
+#define BK(MODEL) (upper ? estep_band_kernel<U, MODEL, false> : estep_band_kernel<U, MODEL, true>)
+    if (model == kBandGridColumn) kfn = BK(GridColumnModel);
+    else kfn = exact ? BK(SpikeSlabModel<true>) : BK(SpikeSlabModel<false>);
+#undef BK
+    HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const int items = A.n_blocks * std::max(A.n_active, 1);
+    const int grid = std::min(items, 2 * P->n_cu);
+    kfn<<<grid, 64 * kBandWaves, shmem, P->stream>>>(A, ring);
+    HIP_TRY(hipGetLastError());
+    if (upper) {
+        const dim3 egrid((unsigned)std::min(256, (P->max_ragged + 255) / 256), (unsigned)items);
+        band_upper_epilogue_kernel<U><<<egrid, 256, 0, P->stream>>>(A);
+        HIP_TRY(hipGetLastError());
+    }
+    return VIPRS_OK;
+}
+
+static int launch_band_u(viprs_plan* P, const EStepArgs<float>& A, int model) {
+    switch (P->ld_dtype) {
+        case VIPRS_LD_F32: return launch_band<float>(P, A, model);
+        case VIPRS_LD_I8: return launch_band<int8_t>(P, A, model);
+        case VIPRS_LD_I16: return launch_band<int16_t>(P, A, model);
+        default: return fail(VIPRS_EINVAL, "band schedule with unsupported LD dtype");
+    }
+}
+
 int run_spike_slab(viprs_state* S, double dq) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
@@ -1277,7 +1344,8 @@ int run_spike_slab(viprs_state* S, double dq) {
             if (rc != VIPRS_OK) return rc;
             HIP_TRY(hipEventRecord(ev[3], P->stream));
         }
-        if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A, kGenSpikeSlab, false);
+        if (use_band(P)) rc = launch_band_u(P, A, kBandSpikeSlab);
+        else if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A, kGenSpikeSlab, false);
     } else {
         // float64 state: the panel kernels specialise float; every block takes the generic kernel
         EStepArgs<double> A = make_args<double>(S, dq);
@@ -1403,7 +1471,10 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         } else {
             rc = launch_generic_u<float>(P, A, model, true);
         }
-        if (rc == VIPRS_OK) rc = launch_generic_u<float>(P, A, model, false);
+        if (rc == VIPRS_OK) {
+            if (model == kGenGrid && use_band(P)) rc = launch_band_u(P, A, kBandGridColumn);
+            else rc = launch_generic_u<float>(P, A, model, false);
+        }
     } else {
         EStepArgs<double> A = make_args<double>(S, dq);
         A.active = d_active;

@@ -16,6 +16,8 @@ struct BlockDesc {
     int32_t kind;       // viprs_block_kind
     int64_t ld_off;     // element offset of the repacked block inside the dense LD buffer
     int64_t gr_off;     // team kernels: first granule row (one row of 64 granules per panel) of this block
+    int32_t band_left;  // windowed (ragged) components, estep_band.h: panels a row reaches to the left ...
+    int32_t band_right; //   ... and to the right of its own panel (>= 1)
 };
 
 // Per-call argument pack for the spike-and-slab kernels (T = state float type).
