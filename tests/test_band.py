@@ -99,3 +99,14 @@ def test_banded_grid_models(gpu, low_memory):
                                 active, 1, low_memory)
         out[name] = st
     H.assert_state_equal(out["hip"], out["ref"])
+
+
+@pytest.mark.parametrize("ld_dtype", [np.float32, np.int8])
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_band_kernel_on_dense_blocks(gpu, low_memory, ld_dtype, monkeypatch):
+    """VIPRS_NO_DENSE=1 classifies every LD block as a windowed component: the band kernel then serves
+    LDetect-style dense blocks (window = whole block) and must reproduce the oracle bit for bit."""
+    monkeypatch.setenv("VIPRS_NO_DENSE", "1")
+    ld, ss, inp = syn.make_problem(sizes=[700, 64, 1, 333, 1300, 65], low_memory=low_memory, ld_dtype=ld_dtype, seed=13)
+    st0 = inp.state_copy()
+    H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=2), H.run_oracle(ld, inp, st0, sweeps=2))

@@ -533,7 +533,8 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
 
     // ---- schedule: dense blocks -> panel kernels, everything else -> generic kernel ----------
     // The panel kernels specialise T = float and U in {f32, i8, i16}; other LD dtypes run generic.
-    const bool panel_ld = (ld_dtype == VIPRS_LD_F32 || ld_dtype == VIPRS_LD_I8 || ld_dtype == VIPRS_LD_I16);
+    bool panel_ld = (ld_dtype == VIPRS_LD_F32 || ld_dtype == VIPRS_LD_I8 || ld_dtype == VIPRS_LD_I16);
+    if (const char* f = getenv("VIPRS_NO_DENSE")) panel_ld = panel_ld && !atoi(f);      // experiments: every block as a windowed component
     int64_t dense_off = 0;
     for (const Block& b : P->blocks) {
         BlockDesc d;
