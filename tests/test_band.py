@@ -110,3 +110,31 @@ def test_band_kernel_on_dense_blocks(gpu, low_memory, ld_dtype, monkeypatch):
     ld, ss, inp = syn.make_problem(sizes=[700, 64, 1, 333, 1300, 65], low_memory=low_memory, ld_dtype=ld_dtype, seed=13)
     st0 = inp.state_copy()
     H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=2), H.run_oracle(ld, inp, st0, sweeps=2))
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_fit_on_windowed_ld(gpu, low_memory):
+    """VIPRS.fit with the whole EM iteration on the device, two chromosomes of banded LD in one merged plan
+    (band kernel), against the same fit driven by the oracle through the host logic."""
+    from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
+    from viprs_amd.model import VIPRS
+    ld, ss = {}, {}
+    for chrom, m in ((21, 900), (22, 1500)):
+        band = banded_ld(m, 45, 45, low_memory, np.float32, seed=chrom)
+        form = (band.ld_left_bound, band.ld_indptr, band.ld_data)
+        ld[chrom] = LDArrays(symmetric=None if low_memory else form, upper=form if low_memory else None,
+                             stored_dtype=np.float32)
+        s, _ = _inputs(m, seed=chrom)
+        ss[chrom] = SumstatsArrays(s.std_beta, s.n_per_snp)
+    gdl = ArrayDataLoader(ld, ss, n=1e5)
+    theta = {"pi": 0.02, "sigma_epsilon": 0.9}
+    hip = VIPRS(gdl, low_memory=low_memory)
+    hip.fit(max_iter=25, theta_0=dict(theta))
+    assert hip._merged and hip._plans["*"].info(__import__("viprs_amd._lib", fromlist=["x"]).INFO_N_RAGGED) == 2
+    ref = VIPRS(gdl, low_memory=low_memory, e_step_fn=O.cpp_e_step)
+    ref.fit(max_iter=25, theta_0=dict(theta))
+    assert hip.optim_result.nit == ref.optim_result.nit
+    np.testing.assert_allclose(hip.history["ELBO"], ref.history["ELBO"], rtol=1e-7, atol=0.02)
+    for c in hip.chromosomes:
+        np.testing.assert_allclose(hip.pip[c], ref.pip[c], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(hip.post_mean_beta[c], ref.post_mean_beta[c], rtol=1e-3, atol=1e-7)
