@@ -21,7 +21,9 @@ namespace viprs {
 
 constexpr int kBandWaves = 8;                  // 1 chain wave + 2 stagers + 5 strip waves (8 waves: 256 VGPRs for the chain)
 constexpr int kBandStagers = 2;                // waves 1 .. 2: next diagonal + off-diagonal tile -> LDS
-constexpr int kBandUpdaters = kBandWaves - 1 - kBandStagers;   // the rest: one target panel each per round
+constexpr int kBandIdleWave = 4;               // shares its SIMD with the chain wave (waves go round-robin over the 4
+                                               // SIMDs): it only keeps the barriers, so the chain issues alone
+constexpr int kBandUpdaters = kBandWaves - 2 - kBandStagers;   // the rest: kBandTargets target panels each per round
 constexpr int kBandTargets = 2;                // target panels per strip wave and round
 constexpr int kBandMaxRingPanels = 256;        // 64 KB of q
 
@@ -223,7 +225,9 @@ __global__ __launch_bounds__(64 * kBandWaves) void estep_band_kernel(EStepArgs<f
                         band_stage_tiles<U>(ld, d_cur, d_next, p + 1, lT + ((p + 1) & 1) * kPanel * kPanel,
                                             lD + ((p + 1) & 1) * kPanel * kPanel, wave - 1, lane);
                 } else if (p > 0) {
-                    const int uw = wave - 1 - kBandStagers;
+                    // strip waves 3, 5, 6, 7 -> 0 .. 3; wave 4 (the chain's SIMD) joins as number 4 only when a
+                    // phase has more targets than the other four take in one round (wide bands: strip-bound anyway)
+                    const int uw = (wave == kBandIdleWave) ? kBandUpdaters : wave - 1 - kBandStagers - (wave > kBandIdleWave ? 1 : 0);
                     const int pp = p - 1;
                     const float avec = la[(pp & 1) * kPanel + lane];
                     const bool any_a = __ballot(avec != 0.0f) != 0;
@@ -232,7 +236,8 @@ __global__ __launch_bounds__(64 * kBandWaves) void estep_band_kernel(EStepArgs<f
                     const int first = SYM ? max(0, pp - WL) : p + 1;
                     const int last = min(np - 1, pp + WR);
                     const int n_targets = last - first + 1 - ((SYM && p < np) ? 2 : (SYM ? 1 : 0));
-                    for (int t0 = uw * kBandTargets; t0 < n_targets; t0 += kBandUpdaters * kBandTargets) {
+                    const int n_upd = (n_targets > kBandUpdaters * kBandTargets) ? kBandUpdaters + 1 : kBandUpdaters;
+                    for (int t0 = uw * kBandTargets; t0 < n_targets && uw < n_upd; t0 += n_upd * kBandTargets) {
                         int cp[kBandTargets], c[kBandTargets];
                         float qv[kBandTargets];
 #pragma unroll
