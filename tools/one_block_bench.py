@@ -3,7 +3,9 @@ import sys, time, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from viprs_amd.plan import DeviceState, LDPlan
 from viprs_amd.utils import synthetic as syn
-for sizes in ([1200], [2200], [6000], [1200]*256, [6000]*32):
+import os
+CONFIGS = ([1200], [2200], [6000], [1200]*256, [6000]*32) if not os.environ.get('MANY') else ([600]*1700, [300]*3400, [1200]*850)
+for sizes in CONFIGS:
     ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=False, seed=3)
     plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
     ds = DeviceState(plan)
