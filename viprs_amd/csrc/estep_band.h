@@ -19,7 +19,7 @@
 
 namespace viprs {
 
-constexpr int kBandWaves = 8;                  // 1 chain wave + 2 stagers + 5 strip waves (8 waves: 256 VGPRs for the chain)
+constexpr int kBandWaves = 8;                  // chain wave, 2 stagers, 4 strip waves, 1 spare (8 waves: 256 VGPRs for the chain)
 constexpr int kBandStagers = 2;                // waves 1 .. 2: next diagonal + off-diagonal tile -> LDS
 constexpr int kBandIdleWave = 4;               // shares its SIMD with the chain wave (waves go round-robin over the 4
                                                // SIMDs): it only keeps the barriers, so the chain issues alone
