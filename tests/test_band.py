@@ -140,13 +140,17 @@ def test_fit_on_windowed_ld(gpu, low_memory):
         np.testing.assert_allclose(hip.post_mean_beta[c], ref.post_mean_beta[c], rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("K", [1, 3, 8, 10])          # K <= 8: band kernel (components serial per lane); K = 10: generic kernel
 @pytest.mark.parametrize("low_memory", [False, True])
-def test_banded_mixture_takes_the_generic_kernel(gpu, low_memory):
-    """The mixture model on windowed components (row-by-row generic kernel): same bits as the oracle."""
+def test_banded_mixture(gpu, low_memory, K, monkeypatch):
+    """The mixture model on windowed components: same bits as the oracle and as the row-by-row generic kernel."""
     from tests.test_gpu_models import _run_mix
     from tests.test_oracle_vs_ref import _mixture_inputs
     from viprs_amd.vi import e_step_hip as S
     ld = banded_ld(600, 30, 30, low_memory, np.float32, seed=12)
     ss, inp = _inputs(600, seed=14)
-    mix, st0 = _mixture_inputs(ld, ss, 3)
-    H.assert_state_equal(_run_mix(S, ld, inp, mix, st0, 2), _run_mix(O, ld, inp, mix, st0, 2))
+    mix, st0 = _mixture_inputs(ld, ss, K)
+    got = _run_mix(S, ld, inp, mix, st0, 2)
+    H.assert_state_equal(got, _run_mix(O, ld, inp, mix, st0, 2))
+    monkeypatch.setenv("VIPRS_BAND", "0")
+    H.assert_state_equal(got, _run_mix(S, ld, inp, mix, st0, 2))

@@ -1273,7 +1273,7 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A, int model = kPanelSpikeSlab)
 
 // Windowed (ragged) components, fp32 state, f32 / int8 / int16 LD, lane-per-SNP model policies: the band
 // kernel (estep_band.h).  VIPRS_BAND=0 sends them back to the generic kernel.
-enum { kBandSpikeSlab = 0, kBandGridColumn = 1 };
+enum { kBandSpikeSlab = 0, kBandGridColumn = 1, kBandMixture = 2 };
 
 static int band_ring_panels(const viprs_plan* P) {
     int rp = 4;
@@ -1300,6 +1300,7 @@ int launch_band(viprs_plan* P, EStepArgs<float> A, int model) {
     void (*kfn)(EStepArgs<float>, int) = nullptr;
 #define BK(MODEL) (upper ? estep_band_kernel<U, MODEL, false> : estep_band_kernel<U, MODEL, true>)
     if (model == kBandGridColumn) kfn = BK(GridColumnModel);
+    else if (model == kBandMixture) kfn = BK(MixtureSerialModel);
     else kfn = exact ? BK(SpikeSlabModel<true>) : BK(SpikeSlabModel<false>);
 #undef BK
     HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1478,6 +1479,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         }
         if (rc == VIPRS_OK) {
             if (model == kGenGrid && use_band(P)) rc = launch_band_u(P, A, kBandGridColumn);
+            else if (model == kGenMixture && S->width <= kPanelMaxK && use_band(P)) rc = launch_band_u(P, A, kBandMixture);
             else rc = launch_generic_u<float>(P, A, model, false);
         }
     } else {

@@ -120,6 +120,13 @@ __device__ __forceinline__ void band_strip(const U* __restrict__ ld, const BandR
     }
 }
 
+// The mixture model with the K components of a SNP evaluated one after the other in the SNP's own lane
+// (MixtureModel's lane-per-SNP update / finish: the same arithmetic as its lane-parallel chain in the
+// panel kernels, K + 1 expf and K divides per step instead of one each).
+struct MixtureSerialModel : MixtureModel {
+    static constexpr bool kLaneParallel = false;
+};
+
 template <typename U, typename MODEL, bool SYM>
 __global__ __launch_bounds__(64 * kBandWaves) void estep_band_kernel(EStepArgs<float> A0, int ring_panels) {
     static_assert(!MODEL::kLaneParallel, "band kernel: lane-per-SNP model policies only");
