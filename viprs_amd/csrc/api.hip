@@ -1254,6 +1254,12 @@ int launch_panel_class(viprs_plan* P, EStepArgs<float> A, int cls, hipStream_t s
     return VIPRS_OK;
 }
 
+// one wave that holds its stream for `ticks` of the 100 MHz wall clock (see launch_panel)
+__global__ void stream_delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 // Panel kernels of the three size classes run concurrently on their own streams (forked from /
 // joined back into the plan's stream with events); the upper-triangular second pass follows.
 template <typename U>
@@ -1263,6 +1269,20 @@ int launch_panel(viprs_plan* P, EStepArgs<float> A, int model = kPanelSpikeSlab)
     for (int c = 0; c < 3; ++c) HIP_TRY(hipStreamWaitEvent(P->class_stream[c], P->ev_fork, 0));
     if ((rc = launch_panel_class<U, kClassWaves[0], true, panel_cols<U>()>(P, A, 0, P->class_stream[0], model)) != VIPRS_OK) return rc;
     if ((rc = launch_panel_class<U, kClassWaves[1], true, panel_cols<U>()>(P, A, 1, P->class_stream[1], model)) != VIPRS_OK) return rc;
+    {
+        // The team kernels are the critical path and need all their workgroups resident; when the persistent
+        // workgroups of the small-block queue reach the CUs first, a sweep takes 1.15-1.2 ms instead of
+        // 0.87-0.9 ms (cfg3; it happened in about every third sweep).  One wave holds the small-block stream
+        // for a few microseconds so that the team kernels are placed first.  Only when the small-block queue
+        // is long enough to fill the chip, and only for fp32 LD: with int8 / int16 LD the small-block queue is
+        // itself the critical path (1.12 -> 1.17 ms with the delay).  VIPRS_SMALL_DELAY_US overrides, 0 = off.
+        static const int env_us = [] { const char* f = getenv("VIPRS_SMALL_DELAY_US"); return f ? atoi(f) : -1; }();
+        const int delay_us = env_us >= 0 ? env_us : (P->ld_dtype == VIPRS_LD_F32 ? 15 : 0);
+        if (delay_us > 0 && P->class_begin[2] > 0 && P->class_begin[3] - P->class_begin[2] >= P->n_cu) {
+            stream_delay_kernel<<<1, 64, 0, P->class_stream[2]>>>((long long)delay_us * 100);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     if ((rc = launch_panel_class<U, kClassWaves[2], false, panel_cols<U>()>(P, A, 2, P->class_stream[2], model)) != VIPRS_OK) return rc;
     for (int c = 0; c < 3; ++c) {
         HIP_TRY(hipEventRecord(P->ev_join[c], P->class_stream[c]));
