@@ -238,6 +238,42 @@ int viprs_state_sums_columns_end(viprs_state* state, double* out);
 /* Per-column re-initialisation of a grid state: var_gamma[:, g] = pi_g, everything else 0.         */
 int viprs_state_reset_column(viprs_state* state, int g, double pi);
 
+/* ---- multi-GPU: RCCL over xGMI for the scalar reductions of the EM iteration -------------------------
+ * One process per GPU; LD blocks are sharded over the ranks (independent units: within one E-step call
+ * the hyper-parameters are fixed and blocks share no q entries, so the data path has NO collective).
+ * What the ranks must agree on per EM iteration are the ~10-300 float64 partial sums of the M-step, the
+ * ELBO and the stopping rules (VIPRS.py:426-484, :497-581, :997) -- the reference itself has no collective
+ * at all (one process, OpenMP inside the kernel, joblib over chromosomes: bin/viprs_fit:1080-1086).
+ *
+ * The communicator wraps an RCCL (ncclComm_t) communicator; librccl is opened at run time, so processes
+ * that never create a communicator do not load it.  Every reduction is ONE ncclAllGather of the small
+ * vector followed by a rank-ordered reduction on the device: sums are added in rank order 0..n-1 (so every
+ * rank gets bit-identical results, run to run), the last element of every `group` consecutive elements is
+ * reduced with max (that slot carries max |eta_diff|).
+ *
+ *   viprs_comm_unique_id   rank 0: fills `id` (VIPRS_COMM_ID_BYTES) -- hand it to the other ranks out of band
+ *                          (viprs_amd.parallel does it through the file system / the launcher's environment)
+ *   viprs_comm_create      collective over all `world_size` processes; `device` = this rank's HIP device
+ *   viprs_comm_allreduce   host vector in/out (control plane: hyper-parameter broadcast, bench timing);
+ *                          group = 0: plain sum, group = -1: plain max, group > 0: see above
+ *   viprs_comm_barrier     all ranks' devices idle + all ranks arrived
+ *   viprs_state_set_comm   from now on viprs_state_sums*_begin/_end of this state return the ALL-RANK sums:
+ *                          the all-gather + ordered reduction run on the plan's stream between the local
+ *                          reduction kernels and the copy to the host -- one collective per EM iteration,
+ *                          no host round trip in front of it.  NULL detaches.  A rank whose plan is empty
+ *                          still takes part (it contributes zeros).                                          */
+#define VIPRS_COMM_ID_BYTES 128
+typedef struct viprs_comm viprs_comm;
+int viprs_comm_unique_id(void* id);
+int viprs_comm_create(viprs_comm** comm, const void* id, int rank, int world_size, int device);
+int viprs_comm_destroy(viprs_comm* comm);
+int viprs_comm_rank(const viprs_comm* comm, int* rank, int* world_size);
+int viprs_comm_allreduce(viprs_comm* comm, double* vec, int n, int group);
+int viprs_comm_barrier(viprs_comm* comm);
+int viprs_state_set_comm(viprs_state* state, viprs_comm* comm);
+/* hipDeviceSynchronize() on `device` (what the bench brackets its timed region with).                   */
+int viprs_device_synchronize(int device);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last viprs_state_e_step / viprs_e_step* call on
  * this plan, measured on the stream they were launched on.  `which`: 0 = all kernels of the

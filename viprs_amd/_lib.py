@@ -25,6 +25,7 @@ MODEL_SPIKE_SLAB, MODEL_MIXTURE, MODEL_GRID = 0, 1, 2
 
 OK, EINVAL, ELAYOUT, EDEVICE, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 N_SUMS = 11
+COMM_ID_BYTES = 128
 
 
 class ViprsHipError(RuntimeError):
@@ -89,6 +90,14 @@ _PROTOS = {
     "viprs_state_sums_columns_begin": (_i, [_vp, _i, _vp]),
     "viprs_state_sums_columns_end": (_i, [_vp, _vp]),
     "viprs_state_reset_column": (_i, [_vp, _i, _d]),
+    "viprs_comm_unique_id": (_i, [_vp]),
+    "viprs_comm_create": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
+    "viprs_comm_destroy": (_i, [_vp]),
+    "viprs_comm_rank": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "viprs_comm_allreduce": (_i, [_vp, _vp, _i, _i]),
+    "viprs_comm_barrier": (_i, [_vp]),
+    "viprs_state_set_comm": (_i, [_vp, _vp]),
+    "viprs_device_synchronize": (_i, [_i]),
     "viprs_plan_last_kernel_ms": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "viprs_plan_last_skipped": (_i, [_vp, _pi64]),
     "viprs_plan_timing_reset": (_i, [_vp]),

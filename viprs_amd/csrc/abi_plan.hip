@@ -1,0 +1,508 @@
+// C ABI, part 1 (include/viprs_hip.h): error reporting, device query, the LD plan -- validation, block
+// discovery, upload and re-lay-out of the LD data ("load LD to memory", VIPRS.__init__, VIPRS.py:151-172).
+#include "internal.h"
+
+using namespace viprs;
+
+namespace {
+thread_local std::string g_err;
+}
+
+namespace viprs {
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+SchedConfig& sched_config() {
+    static SchedConfig c;
+    return c;
+}
+}  // namespace viprs
+
+namespace {
+
+// repack one dense block from the caller's row-concatenated layout into the padded row-major
+// device layout (pure data movement; values are not touched)
+template <typename U>
+__global__ void repack_dense_kernel(const U* __restrict__ src, const int64_t* __restrict__ ip, U* __restrict__ dst,
+                                    const BlockDesc* __restrict__ blocks, int upper) {
+    const BlockDesc bd = blocks[blockIdx.y];
+    const int b = bd.size;
+    for (int r = blockIdx.x; r < b; r += gridDim.x) {
+        const int64_t rs = ip[bd.start + r];
+        U* __restrict__ drow = dst + bd.ld_off + (int64_t)r * bd.stride;
+        if (upper) {
+            for (int c = r + 1 + threadIdx.x; c < b; c += blockDim.x) drow[c] = src[rs + (c - r - 1)];
+        } else {
+            for (int c = threadIdx.x; c < b; c += blockDim.x) drow[c] = src[rs + c];
+        }
+    }
+}
+
+// symmetric expansion on the device: row j of the symmetric store = [mirror of the upper rows that
+// reach j | diagonal | row j of the upper store].  Replaces the host-side symmetric load of
+// VIPRS.py:167-172 (`ld_mat.load(return_symmetric=True)`): the compact store crosses PCIe once and
+// the symmetric copy never exists in host memory.  Pure data movement, values are not touched.
+template <typename U>
+__global__ void expand_symmetric_kernel(const U* __restrict__ up, const int64_t* __restrict__ ipu,
+                                        const int32_t* __restrict__ lb, const int64_t* __restrict__ ip,
+                                        U* __restrict__ out, int64_t m, U diag) {
+    for (int64_t j = blockIdx.x; j < m; j += gridDim.x) {
+        const int64_t o = ip[j];
+        const int len = (int)(ip[j + 1] - o);
+        const int64_t c0 = lb[j];
+        const int64_t uj = ipu[j];
+        for (int p = threadIdx.x; p < len; p += blockDim.x) {
+            const int64_t c = c0 + p;
+            U v = diag;
+            if (c > j) v = up[uj + (c - j - 1)];
+            else if (c < j) v = up[ipu[c] + (j - c - 1)];
+            out[o + p] = v;
+        }
+    }
+}
+
+template <typename U>
+static hipError_t launch_expand(const void* up, const int64_t* ipu, const int32_t* lb, const int64_t* ip, void* out,
+                                int64_t m, double diag) {
+    const unsigned grid = (unsigned)std::min<int64_t>(m, 1 << 16);
+    expand_symmetric_kernel<U><<<grid, 256>>>((const U*)up, ipu, lb, ip, (U*)out, m, (U)diag);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+viprs_plan::~viprs_plan() {
+    delete scratch;
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (auto& e : ev_join) if (e) (void)hipEventDestroy(e);
+    if (class_stream[2]) (void)hipStreamDestroy(class_stream[2]);       // [0], [1]: shared per device, never destroyed
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// what viprs_plan_create_expanded hands to the common path: the compact upper-triangular store the
+// symmetric rows are built from on the device
+struct ExpandSource {
+    std::vector<int64_t> ip_upper;
+    const void* data = nullptr;
+    double diag = 1.0;
+};
+
+static int widen_indptr(int64_t m, const void* indptr, int indptr_dtype, std::vector<int64_t>& ip64) {
+    ip64.assign((size_t)m + 1, 0);
+    if (indptr_dtype == VIPRS_IP_I64) {
+        if (m > 0) std::memcpy(ip64.data(), indptr, sizeof(int64_t) * ((size_t)m + 1));
+    } else if (indptr_dtype == VIPRS_IP_I32) {
+        const int32_t* p = static_cast<const int32_t*>(indptr);
+        for (int64_t i = 0; i <= m && m > 0; ++i) ip64[(size_t)i] = p[i];
+    } else {
+        return fail(VIPRS_EINVAL, "bad indptr dtype code");
+    }
+    return VIPRS_OK;
+}
+
+static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, const std::vector<int64_t>& ip64,
+                            const void* ld_data, int ld_dtype, int low_memory, int device, const ExpandSource* ex) {
+    const size_t es = ld_elem_size(ld_dtype);
+    std::unique_ptr<viprs_plan> P(new viprs_plan());
+    P->m = m;
+    if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
+    if (const char* f = getenv("VIPRS_LARGE_BLOCK")) sched_config().large_block = atoi(f);
+    if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) sched_config().medium_block = atoi(f);
+    if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
+    if (const char* f = getenv("VIPRS_TEAM0")) { sched_config().class_team[0] = std::max(1, atoi(f)); sched_config().team_env = true; }
+    if (const char* f = getenv("VIPRS_TEAM1")) { sched_config().class_team[1] = std::max(1, atoi(f)); sched_config().team_env = true; }
+    P->low_memory = low_memory != 0;
+    P->ld_dtype = ld_dtype;
+    P->device = device;
+    std::string err;
+    int rc = plan_blocks(m, lb, ip64.data(), low_memory != 0, P->blocks, err);
+    if (rc != VIPRS_OK) return fail(rc, err);
+    P->nnz = m > 0 ? ip64[(size_t)m] : 0;
+    if (P->nnz > 0 && !ld_data && !ex) return fail(VIPRS_EINVAL, "ld_data is null");
+
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    P->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
+    {   // team classes get the highest stream priority: their workgroups must become co-resident quickly
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        // The two team classes run on streams SHARED by all plans of a device: a team kernel needs all its
+        // workgroups resident at once (members spin on each other's hand-offs), so two team kernels of the
+        // same class from different plans must never be half-resident together.  The shared streams
+        // serialise them; the streams live as long as the process.
+        static std::mutex team_mu;
+        static std::map<int, std::array<hipStream_t, 2>> team_streams;
+        {
+            std::lock_guard<std::mutex> lock(team_mu);
+            auto it = team_streams.find(device);
+            if (it == team_streams.end()) {
+                std::array<hipStream_t, 2> st{};
+                for (int c = 0; c < 2; ++c) HIP_TRY(hipStreamCreateWithPriority(&st[c], hipStreamNonBlocking, prio_hi));
+                it = team_streams.emplace(device, st).first;
+            }
+            P->class_stream[0] = it->second[0];
+            P->class_stream[1] = it->second[1];
+        }
+        HIP_TRY(hipStreamCreateWithPriority(&P->class_stream[2], hipStreamNonBlocking, prio_lo));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+    for (auto& e : P->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    P->ev.assign(4 * viprs_plan::kRing, nullptr);
+    for (auto& e : P->ev) HIP_TRY(hipEventCreate(&e));
+
+    // ---- schedule: dense blocks -> panel kernels, everything else -> generic kernel ----------
+    // The panel kernels specialise T = float and U in {f32, i8, i16}; other LD dtypes run generic.
+    bool panel_ld = (ld_dtype == VIPRS_LD_F32 || ld_dtype == VIPRS_LD_I8 || ld_dtype == VIPRS_LD_I16);
+    if (const char* f = getenv("VIPRS_NO_DENSE")) panel_ld = panel_ld && !atoi(f);      // experiments: every block as a windowed component
+    int64_t dense_off = 0;
+    for (const Block& b : P->blocks) {
+        BlockDesc d;
+        d.start = (int32_t)b.start;
+        d.size = (int32_t)(b.end - b.start);
+        d.kind = b.kind;
+        d.stride = 0;
+        d.ld_off = 0;
+        d.gr_off = 0;
+        d.band_left = d.band_right = 0;
+        // the panel kernels keep q of a whole block in LDS: a dense block beyond that (~29 000 SNPs) is
+        // scheduled like a windowed component (band kernel if its ring fits, generic kernel otherwise)
+        constexpr int kMaxDenseBlock = (160 * 1024 / 4 - panel_lds_floats(kStrip) - kMixLdsFloats) / kPanel * kPanel;
+        const bool dense = panel_ld && (b.kind == VIPRS_BLOCK_DENSE_SYM || b.kind == VIPRS_BLOCK_DENSE_UPPER) &&
+                           d.size <= kMaxDenseBlock;
+        if (dense) {
+            d.stride = (d.size + kPanel - 1) / kPanel * kPanel;
+            d.ld_off = dense_off;
+            dense_off += (int64_t)d.size * d.stride;
+            dense_off = (dense_off + 63) / 64 * 64;
+            P->dense_h.push_back(d);
+            P->max_dense = std::max(P->max_dense, d.size);
+        } else {
+            // reach of the row windows around the diagonal, in panels (band kernel, estep_band.h)
+            int64_t wl = 0, wr = 0;
+            for (int64_t j = b.start; j < b.end; ++j) {
+                const int64_t len = ip64[(size_t)j + 1] - ip64[(size_t)j];
+                if (len <= 0) continue;
+                wl = std::max<int64_t>(wl, j - lb[j]);
+                wr = std::max<int64_t>(wr, lb[j] + len - 1 - j);
+            }
+            d.band_left = (int32_t)(wl / kPanel + 1);
+            d.band_right = (int32_t)(wr / kPanel + 1);
+            P->max_band_panels = std::max(P->max_band_panels, d.band_left + d.band_right + 2);
+            P->ragged_h.push_back(d);
+            P->max_ragged = std::max(P->max_ragged, d.size);
+        }
+    }
+    P->dense_elems = dense_off;
+    auto by_cost = [](const BlockDesc& a, const BlockDesc& b) {
+        return a.size != b.size ? a.size > b.size : a.start < b.start;
+    };
+    std::sort(P->dense_h.begin(), P->dense_h.end(), by_cost);
+    std::sort(P->ragged_h.begin(), P->ragged_h.end(), by_cost);
+    {   // descending order: [large | medium | small]
+        int i = 0, n = (int)P->dense_h.size();
+        P->class_begin[0] = 0;
+        while (i < n && P->dense_h[i].size >= sched_config().large_block) ++i;
+        P->class_begin[1] = i;
+        while (i < n && P->dense_h[i].size >= sched_config().medium_block) ++i;
+        P->class_begin[2] = i;
+        P->class_begin[3] = n;
+        // hand-off granules for the blocks served by teams (classes 0 and 1)
+        int64_t rows = 0;
+        for (int k = 0; k < P->class_begin[2]; ++k) {
+            P->dense_h[(size_t)k].gr_off = rows;
+            rows += (P->dense_h[(size_t)k].size + kPanel - 1) / kPanel;
+        }
+        P->n_granule_rows = rows;
+    }
+
+    // ---- upload -------------------------------------------------------------------------------
+    HIP_TRY(P->d_counters.alloc(16));
+    HIP_TRY(P->d_error.alloc(1));
+    HIP_TRY(hipMemset(P->d_error.p, 0, sizeof(int32_t)));
+    HIP_TRY(P->d_skipped.alloc(1));
+    HIP_TRY(hipMemset(P->d_skipped.p, 0, sizeof(unsigned long long)));
+    if (m > 0) {
+        HIP_TRY(P->d_lb.alloc((size_t)m));
+        HIP_TRY(P->d_ip.alloc((size_t)m + 1));
+        HIP_TRY(hipMemcpy(P->d_lb.p, lb, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(P->d_ip.p, ip64.data(), sizeof(int64_t) * ((size_t)m + 1), hipMemcpyHostToDevice));
+        std::vector<int32_t> rowlen((size_t)m);
+        for (int64_t j = 0; j < m; ++j) rowlen[(size_t)j] = (int32_t)(ip64[(size_t)j + 1] - ip64[(size_t)j]);
+        HIP_TRY(P->d_rowlen.alloc((size_t)m));
+        HIP_TRY(hipMemcpy(P->d_rowlen.p, rowlen.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice));
+        if (!P->dense_h.empty()) {
+            // element (row r, column c) of a repacked block sits at ld_off + r*stride + c; the row's
+            // window starts at column 0 (symmetric) or r + 1 (upper-triangular)
+            std::vector<int64_t> rs((size_t)m, 0);
+            for (const BlockDesc& d : P->dense_h)
+                for (int r = 0; r < d.size; ++r)
+                    rs[(size_t)d.start + r] = d.ld_off + (int64_t)r * d.stride + (P->low_memory ? r + 1 : 0);
+            HIP_TRY(P->d_rowstart_dense.alloc((size_t)m));
+            HIP_TRY(hipMemcpy(P->d_rowstart_dense.p, rs.data(), sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice));
+        }
+    }
+    if (P->nnz > 0) {
+        HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es + 64));      // + slack: the band kernel clamps empty rows to their start
+        if (!ex) {
+            HIP_TRY(hipMemcpy(P->d_ld_raw.p, ld_data, (size_t)P->nnz * es, hipMemcpyHostToDevice));
+        } else {
+            // upload the compact store, mirror it into the symmetric rows on the device, drop it
+            const size_t nnz_u = (size_t)ex->ip_upper[(size_t)m];
+            DevBuf<char> d_up;
+            DevBuf<int64_t> d_ipu;
+            HIP_TRY(d_up.alloc(std::max<size_t>(nnz_u, 1) * es));
+            HIP_TRY(d_ipu.alloc((size_t)m + 1));
+            if (nnz_u) HIP_TRY(hipMemcpy(d_up.p, ex->data, nnz_u * es, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_ipu.p, ex->ip_upper.data(), sizeof(int64_t) * ((size_t)m + 1), hipMemcpyHostToDevice));
+            hipError_t e = hipSuccess;
+            switch (ld_dtype) {
+                case VIPRS_LD_I8:  e = launch_expand<int8_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_I16: e = launch_expand<int16_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_I32: e = launch_expand<int32_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_I64: e = launch_expand<int64_t>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                case VIPRS_LD_F32: e = launch_expand<float>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+                default:           e = launch_expand<double>(d_up.p, d_ipu.p, P->d_lb.p, P->d_ip.p, P->d_ld_raw.p, m, ex->diag); break;
+            }
+            HIP_TRY(e);
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    if (P->n_granule_rows > 0) HIP_TRY(P->d_granules.alloc((size_t)P->n_granule_rows * kPanel));
+    if (!P->dense_h.empty()) {
+        HIP_TRY(P->d_dense.alloc(P->dense_h.size()));
+        HIP_TRY(hipMemcpy(P->d_dense.p, P->dense_h.data(), sizeof(BlockDesc) * P->dense_h.size(), hipMemcpyHostToDevice));
+        // + slack so that partial-panel tile loads stay inside the allocation: one strip for the panel
+        // kernels, one panel of rows of the widest block for the batched grid kernel (estep_grid_mfma.h)
+        int max_stride = 0;
+        for (const BlockDesc& d : P->dense_h) max_stride = std::max(max_stride, d.stride);
+        const size_t bytes = ((size_t)P->dense_elems + 4 * kStrip + (size_t)kPanel * max_stride) * es;
+        HIP_TRY(P->d_ld_dense.alloc(bytes));
+        HIP_TRY(hipMemset(P->d_ld_dense.p, 0, bytes));
+        dim3 grid(64, (unsigned)P->dense_h.size());
+        const int upper = P->low_memory;
+        switch (ld_dtype) {
+            case VIPRS_LD_F32:
+                repack_dense_kernel<float><<<grid, 256>>>((const float*)P->d_ld_raw.p, P->d_ip.p, (float*)P->d_ld_dense.p, P->d_dense.p, upper);
+                break;
+            case VIPRS_LD_I8:
+                repack_dense_kernel<int8_t><<<grid, 256>>>((const int8_t*)P->d_ld_raw.p, P->d_ip.p, (int8_t*)P->d_ld_dense.p, P->d_dense.p, upper);
+                break;
+            case VIPRS_LD_I16:
+                repack_dense_kernel<int16_t><<<grid, 256>>>((const int16_t*)P->d_ld_raw.p, P->d_ip.p, (int16_t*)P->d_ld_dense.p, P->d_dense.p, upper);
+                break;
+            default: break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        if (!P->low_memory) {
+            // batched grid E-step, symmetric form: the columns left of the chain are finished by
+            // estep_grid_lower_pass_kernel, one item per 128-column tile that has rows below it, longest first
+            std::vector<EpiItem> low;
+            for (size_t i = 0; i < P->dense_h.size(); ++i) {
+                const int np = (P->dense_h[i].size + kPanel - 1) / kPanel;
+                for (int T = 0; 2 * T + 1 < np; ++T) low.push_back({(int32_t)i, T});
+            }
+            std::stable_sort(low.begin(), low.end(), [&](const EpiItem& x, const EpiItem& y) {
+                const int npx = (P->dense_h[(size_t)x.blk].size + kPanel - 1) / kPanel, npy = (P->dense_h[(size_t)y.blk].size + kPanel - 1) / kPanel;
+                return npx - 2 * x.row0 > npy - 2 * y.row0;
+            });
+            P->n_low_items = (int64_t)low.size();
+            if (!low.empty()) {
+                HIP_TRY(P->d_low_items.alloc(low.size()));
+                HIP_TRY(hipMemcpy(P->d_low_items.p, low.data(), sizeof(EpiItem) * low.size(), hipMemcpyHostToDevice));
+            }
+        }
+        if (P->low_memory) {
+            std::vector<EpiItem> items;
+            for (int c = 0; c < 3; ++c) {
+                P->epi_begin[c] = (int)items.size();
+                std::vector<EpiItem> cls;
+                for (int i = P->class_begin[c]; i < P->class_begin[c + 1]; ++i)
+                    for (int r0 = 0; r0 < P->dense_h[(size_t)i].size; r0 += kPanel)
+                        cls.push_back({(int32_t)(i - P->class_begin[c]), r0});        // block index inside its class
+                // longest rows first (the item cost is the number of columns right of its rows)
+                const int cb = P->class_begin[c];
+                std::stable_sort(cls.begin(), cls.end(), [&](const EpiItem& x, const EpiItem& y) {
+                    return P->dense_h[(size_t)(cb + x.blk)].size - x.row0 > P->dense_h[(size_t)(cb + y.blk)].size - y.row0;
+                });
+                items.insert(items.end(), cls.begin(), cls.end());
+            }
+            P->epi_begin[3] = (int)items.size();
+            P->n_epi = (int64_t)items.size();
+            // the same items once more with plan-wide block indices, longest first across all classes
+            // (one launch of the batched grid second pass)
+            std::vector<EpiItem> all;
+            for (int c = 0; c < 3; ++c)
+                for (int k = P->epi_begin[c]; k < P->epi_begin[c + 1]; ++k)
+                    all.push_back({(int32_t)(items[(size_t)k].blk + P->class_begin[c]), items[(size_t)k].row0});
+            std::stable_sort(all.begin(), all.end(), [&](const EpiItem& x, const EpiItem& y) {
+                return P->dense_h[(size_t)x.blk].size - x.row0 > P->dense_h[(size_t)y.blk].size - y.row0;
+            });
+            HIP_TRY(P->d_epi_all.alloc(all.size()));
+            HIP_TRY(hipMemcpy(P->d_epi_all.p, all.data(), sizeof(EpiItem) * all.size(), hipMemcpyHostToDevice));
+            HIP_TRY(P->d_epi.alloc(items.size()));
+            HIP_TRY(hipMemcpy(P->d_epi.p, items.data(), sizeof(EpiItem) * items.size(), hipMemcpyHostToDevice));
+        }
+    }
+    if (!P->ragged_h.empty()) {
+        HIP_TRY(P->d_ragged.alloc(P->ragged_h.size()));
+        HIP_TRY(hipMemcpy(P->d_ragged.p, P->ragged_h.data(), sizeof(BlockDesc) * P->ragged_h.size(), hipMemcpyHostToDevice));
+    } else {
+        // raw copy no longer needed: every block was repacked
+        HIP_TRY(P->d_ld_raw.alloc(0));
+    }
+    // every copy / memset above went through the null stream; the plan's own streams are non-blocking
+    // (not ordered with it), so nothing may still be in flight when the first sweep is launched
+    HIP_TRY(hipDeviceSynchronize());
+    *out = P.release();
+    return VIPRS_OK;
+}
+
+extern "C" {
+
+const char* viprs_last_error(void) { return g_err.c_str(); }
+const char* viprs_version(void) { return "viprs_amd 0.1.0 (gfx950)"; }
+
+int viprs_device_count(int* count) {
+    if (!count) return fail(VIPRS_EINVAL, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(VIPRS_EDEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return VIPRS_OK;
+}
+
+int viprs_check_blas_support(void) { return 0; }
+int viprs_check_omp_support(void) { return 0; }
+
+int viprs_plan_blocks(int64_t m, const int32_t* lb, const void* indptr, int indptr_dtype, int low_memory,
+                      int64_t* n_blocks, int64_t* block_start, int32_t* block_kind) {
+    if (!n_blocks || !block_start) return fail(VIPRS_EINVAL, "null output");
+    if (m > 0 && (!lb || !indptr)) return fail(VIPRS_EINVAL, "null LD index array");
+    std::vector<int64_t> ip64;
+    const int64_t* ip = nullptr;
+    if (indptr_dtype == VIPRS_IP_I64) {
+        ip = static_cast<const int64_t*>(indptr);
+    } else if (indptr_dtype == VIPRS_IP_I32) {
+        const int32_t* p = static_cast<const int32_t*>(indptr);
+        ip64.assign(p, p + m + 1);
+        ip = ip64.data();
+    } else {
+        return fail(VIPRS_EINVAL, "bad indptr dtype code");
+    }
+    std::vector<Block> blocks;
+    std::string err;
+    int rc = plan_blocks(m, lb, ip, low_memory != 0, blocks, err);
+    if (rc != VIPRS_OK) return fail(rc, err);
+    *n_blocks = (int64_t)blocks.size();
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        block_start[i] = blocks[i].start;
+        if (block_kind) block_kind[i] = blocks[i].kind;
+    }
+    block_start[blocks.size()] = m;
+    return VIPRS_OK;
+}
+
+int viprs_plan_create(viprs_plan** out, int64_t m, const int32_t* lb, const void* indptr, int indptr_dtype,
+                      const void* ld_data, int ld_dtype, int low_memory, int device) {
+    if (!out) return fail(VIPRS_EINVAL, "plan output is null");
+    *out = nullptr;
+    if (ld_elem_size(ld_dtype) == 0) return fail(VIPRS_EINVAL, "bad LD dtype code");
+    if (m < 0 || m > INT32_MAX) return fail(VIPRS_EINVAL, "m out of range");
+    if (m > 0 && (!lb || !indptr)) return fail(VIPRS_EINVAL, "null LD index array");
+    std::vector<int64_t> ip64;
+    int rc = widen_indptr(m, indptr, indptr_dtype, ip64);
+    if (rc != VIPRS_OK) return rc;
+    return plan_create_impl(out, m, lb, ip64, ld_data, ld_dtype, low_memory, device, nullptr);
+}
+
+int viprs_plan_create_expanded(viprs_plan** out, int64_t m, const void* upper_indptr, int indptr_dtype,
+                               const void* upper_data, int ld_dtype, double diag_value, int device) {
+    if (!out) return fail(VIPRS_EINVAL, "plan output is null");
+    *out = nullptr;
+    if (ld_elem_size(ld_dtype) == 0) return fail(VIPRS_EINVAL, "bad LD dtype code");
+    if (m < 0 || m > INT32_MAX) return fail(VIPRS_EINVAL, "m out of range");
+    if (m > 0 && !upper_indptr) return fail(VIPRS_EINVAL, "null LD index array");
+    ExpandSource ex;
+    int rc = widen_indptr(m, upper_indptr, indptr_dtype, ex.ip_upper);
+    if (rc != VIPRS_OK) return rc;
+    ex.data = upper_data;
+    ex.diag = diag_value;
+    if (m > 0 && ex.ip_upper[(size_t)m] > 0 && !upper_data) return fail(VIPRS_EINVAL, "ld_data is null");
+    // symmetric windows: row j = [first row that reaches j .. j + len_j].  They are contiguous (the
+    // layout e_step.hpp:389-392 needs) iff the right ends j + len_j never decrease.
+    std::vector<int32_t> lb((size_t)m, 0);
+    std::vector<int64_t> ip((size_t)m + 1, 0);
+    int64_t first = 0, prev_reach = -1;
+    for (int64_t j = 0; j < m; ++j) {
+        const int64_t len = ex.ip_upper[(size_t)j + 1] - ex.ip_upper[(size_t)j];
+        if (len < 0) return fail(VIPRS_EINVAL, "ld_indptr is not non-decreasing");
+        const int64_t reach = j + len;
+        if (reach >= m) return fail(VIPRS_EINVAL, "an upper-triangular LD row runs past the last SNP");
+        if (reach < prev_reach) return fail(VIPRS_EINVAL, "the upper-triangular windows do not mirror into contiguous symmetric windows");
+        prev_reach = reach;
+        while (first < j && first + (ex.ip_upper[(size_t)first + 1] - ex.ip_upper[(size_t)first]) < j) ++first;
+        lb[(size_t)j] = (int32_t)first;
+        ip[(size_t)j + 1] = ip[(size_t)j] + (j - first) + 1 + len;
+    }
+    return plan_create_impl(out, m, lb.data(), ip, nullptr, ld_dtype, 0, device, &ex);
+}
+
+int viprs_plan_get_windows(const viprs_plan* P, int32_t* left_bound, int64_t* indptr) {
+    if (!P || !left_bound || !indptr) return fail(VIPRS_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(P->device));
+    indptr[0] = 0;
+    if (P->m > 0) {
+        HIP_TRY(hipMemcpy(left_bound, P->d_lb.p, sizeof(int32_t) * (size_t)P->m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(indptr, P->d_ip.p, sizeof(int64_t) * ((size_t)P->m + 1), hipMemcpyDeviceToHost));
+    }
+    return VIPRS_OK;
+}
+int viprs_plan_destroy(viprs_plan* plan) {
+    if (!plan) return VIPRS_OK;
+    (void)hipSetDevice(plan->device);
+    delete plan;
+    return VIPRS_OK;
+}
+
+int viprs_plan_info(const viprs_plan* P, int key, int64_t* value) {
+    if (!P || !value) return fail(VIPRS_EINVAL, "null argument");
+    switch (key) {
+        case VIPRS_INFO_M: *value = P->m; break;
+        case VIPRS_INFO_NNZ: *value = P->nnz; break;
+        case VIPRS_INFO_N_BLOCKS: *value = (int64_t)P->blocks.size(); break;
+        case VIPRS_INFO_N_DENSE: *value = (int64_t)P->dense_h.size(); break;
+        case VIPRS_INFO_N_RAGGED: *value = (int64_t)P->ragged_h.size(); break;
+        case VIPRS_INFO_MAX_BLOCK: *value = std::max(P->max_dense, P->max_ragged); break;
+        case VIPRS_INFO_LD_BYTES_DEVICE: *value = (int64_t)(P->d_ld_raw.n + P->d_ld_dense.n); break;
+        case VIPRS_INFO_LD_ELEM_SIZE: *value = (int64_t)ld_elem_size(P->ld_dtype); break;
+        case VIPRS_INFO_DEVICE: *value = P->device; break;
+        case VIPRS_INFO_LOW_MEMORY: *value = P->low_memory; break;
+        case VIPRS_INFO_N_CU: *value = P->n_cu; break;
+        default: return fail(VIPRS_EINVAL, "unknown info key");
+    }
+    return VIPRS_OK;
+}
+
+int viprs_plan_get_blocks(const viprs_plan* P, int64_t* block_start, int32_t* block_kind) {
+    if (!P || !block_start) return fail(VIPRS_EINVAL, "null argument");
+    for (size_t i = 0; i < P->blocks.size(); ++i) {
+        block_start[i] = P->blocks[i].start;
+        if (block_kind) block_kind[i] = P->blocks[i].kind;
+    }
+    block_start[P->blocks.size()] = P->m;
+    return VIPRS_OK;
+}
+
+int viprs_plan_set_math_mode(viprs_plan* P, int mode) {
+    if (!P) return fail(VIPRS_EINVAL, "null plan");
+    if (mode != VIPRS_MATH_EXACT && mode != VIPRS_MATH_FAST) return fail(VIPRS_EINVAL, "bad math mode");
+    P->math_mode = mode;
+    return VIPRS_OK;
+}
+
+}  // extern "C"

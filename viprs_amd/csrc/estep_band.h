@@ -25,7 +25,6 @@ constexpr int kBandIdleWave = 4;               // shares its SIMD with the chain
                                                // SIMDs): it only keeps the barriers, so the chain issues alone
 constexpr int kBandUpdaters = kBandWaves - 2 - kBandStagers;   // the rest: kBandTargets target panels each per round
 constexpr int kBandTargets = 2;                // target panels per strip wave and round
-constexpr int kBandMaxRingPanels = 256;        // 64 KB of q
 
 // LDS carve (floats): q ring[ring_panels][64] | a[2][64] | T[2][64*64] | D[2][64*64]
 __host__ __device__ constexpr int band_lds_floats(int ring_panels) {

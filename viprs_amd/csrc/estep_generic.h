@@ -108,7 +108,6 @@ __global__ __launch_bounds__(kGenericThreads) void estep_generic_kernel(EStepArg
 // (K+1)-way softmax (e_step.hpp:222-241) per SNP, no skip branch.  (m, K) arrays are C-ordered.
 // Every thread evaluates the K-loop redundantly (K is small); the axpy is spread over the lanes.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxMixtureK = 64;
 
 template <typename T> __device__ __forceinline__ T exp_nonpos(T x, const ExpTab& tab);
 template <> __device__ __forceinline__ float exp_nonpos<float>(float x, const ExpTab& tab) {

@@ -41,7 +41,6 @@ namespace viprs {
 #define GPROF(slot, cond) do { } while (0)
 #endif
 
-constexpr int kGridModels = 32;                    // models per launch (one 32-row MFMA tile)
 constexpr int kGridIoPitch = kPanel + 1;           // LDS pitch of the per-panel input/output staging
 // LDS carve (floats): io[2][4][32][65] | a[2][64][32] | diag[2][64][64] | carry[96][64] | qx[2][32][68]
 constexpr int kGridIoArr = kGridModels * kGridIoPitch;

@@ -155,8 +155,6 @@ template <typename U> __host__ __device__ constexpr int panel_cols() { return si
 constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
 constexpr int kStripRowsInFlight = 16;   // row loads in flight per updater lane (16 x 16 B for every LD type)
 
-// LDS carve (floats): q[qcap] | a[2][64] | T[2][64*64]
-__host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
 
 // Trailing update of one strip (64 * CPL columns) by one wave: q[c..c+CPL-1] = fma(R[row][c..], a_row, .)
 // for the 64 rows of a panel, in row order, with DEPTH row loads in flight per lane (DEPTH * CPL = 64
@@ -297,9 +295,6 @@ struct GridColumnModel {
 };
 
 // e_step_mixture (e_step.hpp:496-537) for K <= kPanelMaxK components ((m, K) arrays C-ordered).
-constexpr int kPanelMaxK = 8;
-// LDS of the lane-parallel mixture chain: mu_mult | sqrt_half_var_tau | u_logs | var_mu | var_gamma, [64 SNPs][K]
-constexpr int kMixLdsFloats = 5 * kPanel * kPanelMaxK;
 struct MixtureModel {
     // the chain evaluates the K + 1 components of ONE SNP on K + 1 lanes (see the chain in estep_panel_kernel)
     static constexpr bool kLaneParallel = true;
@@ -764,7 +759,7 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
 }
 
 // Copies the team kernels' eta / q outputs into place (runs behind the team kernel on its stream).
-__global__ void commit_team_kernel(EStepArgs<float> A0) {
+static __global__ void commit_team_kernel(EStepArgs<float> A0) {
     const EStepArgs<float> A = select_model(A0, blockIdx.y);
     const BlockDesc bd = A.blocks[blockIdx.x];
     for (int i = threadIdx.x; i < bd.size; i += blockDim.x) {
@@ -780,7 +775,6 @@ __global__ void commit_team_kernel(EStepArgs<float> A0) {
 // rows; 64x64 tiles are loaded row-wise (coalesced), transposed through LDS so that lane r walks
 // row r in column order.  Lower-left entries of the repacked block are zero (exactly neutral).
 // ---------------------------------------------------------------------------------------------
-struct EpiItem { int32_t blk; int32_t row0; };
 
 template <typename U, int NW>
 __global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs<float> A0, const EpiItem* items,

@@ -1,0 +1,188 @@
+// Internal host-side declarations shared by the translation units of libviprs_hip.so:
+// plan / state objects, error reporting, launcher entry points of the kernel families.
+// (The C ABI itself is include/viprs_hip.h.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/viprs_hip.h"
+#include "kernels_common.h"
+#include "planner.h"
+
+namespace viprs {
+
+int fail(int code, const std::string& msg);      // records the thread's error message, returns `code`
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return ::viprs::fail(VIPRS_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+inline size_t ld_elem_size(int ld_dtype) {
+    switch (ld_dtype) {
+        case VIPRS_LD_I8: return 1;
+        case VIPRS_LD_I16: return 2;
+        case VIPRS_LD_I32: return 4;
+        case VIPRS_LD_I64: return 8;
+        case VIPRS_LD_F32: return 4;
+        case VIPRS_LD_F64: return 8;
+        default: return 0;
+    }
+}
+inline size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 8 : 0); }
+
+// workgroup-size classes of the panel kernel (waves per workgroup; wave 0 is the chain)
+// Every class uses 4-wave workgroups (1 chain + 3 updaters) so that a team member needs exactly
+// the same CU resources as a small-block workgroup; larger blocks get more CUs, not bigger groups.
+struct SchedConfig {
+    int large_block = 2304, medium_block = 1280;   // VIPRS_LARGE_BLOCK / VIPRS_MEDIUM_BLOCK
+    int class_team[3] = {8, 2, 1};                 // workgroups (CUs) sharing one block of the class (0/1: teams)
+    // mixture: the chain step is ~4x the spike-and-slab one, every team member replicates it -- smaller teams
+    int class_team_mix[3] = {4, 1, 1};
+    bool team_env = false;                         // VIPRS_TEAM0/1 given: they apply to every model
+};
+SchedConfig& sched_config();                       // process-wide, read from the environment at plan creation
+constexpr int kClassWaves[3] = {4, 4, 4};
+constexpr int kEpiWaves = 4;
+
+template <typename V> struct DevBuf {
+    V* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(V));
+    }
+};
+
+}  // namespace viprs
+
+struct viprs_state;
+struct viprs_comm;                                  // comm.hip
+struct viprs_plan {
+    int64_t m = 0;
+    int64_t nnz = 0;
+    int low_memory = 0;
+    int ld_dtype = 0;
+    int device = 0;
+    int n_cu = 0;
+    int math_mode = VIPRS_MATH_EXACT;
+    hipStream_t stream = nullptr;
+    std::vector<viprs::Block> blocks;              // SNP order
+    std::vector<viprs::BlockDesc> dense_h, ragged_h;  // schedule order (descending cost)
+    // dense blocks are served by panel kernels of three workgroup sizes (more updater waves =
+    // more row loads in flight = a larger share of HBM bandwidth for the larger blocks); class c
+    // covers dense_h[class_begin[c] .. class_begin[c+1])
+    int class_begin[4] = {0, 0, 0, 0};
+    viprs::DevBuf<viprs::BlockDesc> d_dense, d_ragged;
+    hipStream_t class_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    viprs::DevBuf<viprs::EpiItem> d_epi;
+    viprs::DevBuf<unsigned long long> d_granules;  // team hand-off granules (one row of 64 per panel of a team block)
+    int64_t n_granule_rows = 0;
+    viprs::DevBuf<int32_t> d_error;
+    viprs::DevBuf<int32_t> d_admit;                // admission thresholds of the small-block class
+    int admit_grid = 0;
+    double admit_factor = 1.5;
+    int grid_mfma = -1;                     // batched grid E-step on the matrix cores: 1 always, 0 never (per-(block,
+                                            // model) items), -1 when the plan has enough blocks to fill the CUs (VIPRS_GRID_MFMA)
+    int64_t n_epi = 0;
+    int epi_begin[4] = {0, 0, 0, 0};        // per size class ranges of d_epi
+    viprs::DevBuf<viprs::EpiItem> d_epi_all;              // all items, plan-wide block indices, longest first
+    viprs::DevBuf<viprs::EpiItem> d_low_items;            // symmetric form: (block, 128-column tile) items of the batched grid lower pass
+    int64_t n_low_items = 0;
+    viprs::DevBuf<int32_t> d_lb;
+    viprs::DevBuf<int64_t> d_ip;
+    viprs::DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
+    viprs::DevBuf<int64_t> d_rowstart_dense;       // row starts inside the repacked dense buffer (generic kernels)
+    viprs::DevBuf<char> d_ld_raw;                  // kept only when ragged blocks exist
+    viprs::DevBuf<char> d_ld_dense;
+    int64_t dense_elems = 0;
+    int max_dense = 0, max_ragged = 0;
+    int max_band_panels = 0;                // ragged blocks: widest (band_left + band_right + 2), sizes the band kernel's q ring
+    viprs::DevBuf<int32_t> d_counters;             // [0] dense queue head, [1] ragged queue head
+    viprs::DevBuf<unsigned long long> d_skipped;
+    // HIP-event ring: per sweep {sweep start, sweep end, panel start, panel end}, recorded on
+    // the stream the kernels are launched on
+    static constexpr int kRing = 256;
+    std::vector<hipEvent_t> ev;             // 4 * kRing
+    int64_t sweeps = 0;                     // sweeps recorded since the last timing reset
+    viprs_state* scratch = nullptr;         // state used by the one-shot host-buffer calls
+
+    ~viprs_plan();
+};
+
+struct viprs_state {
+    viprs_plan* plan = nullptr;
+    int float_dtype = VIPRS_F32;
+    int model_kind = VIPRS_MODEL_SPIKE_SLAB;
+    int width = 1;
+    viprs::DevBuf<char> f[VIPRS_FIELD_COUNT];
+    viprs::DevBuf<int32_t> d_active;               // grid: active model indices of the current call
+    viprs::DevBuf<char> eta_out, q_out;            // team kernels' in-out staging (see kernels_common.h)
+    viprs::DevBuf<double> d_n, d_var_tau, d_partials, d_sums;   // device-resident EM iteration
+    viprs::DevBuf<double> d_weight;                // optional per-SNP weight of sum [0] (several chromosomes in one plan)
+    viprs::DevBuf<double> d_log_var_tau0;          // mixture: the log var_tau of the initial state (the reference's ELBO never refreshes it)
+    viprs::DevBuf<double> d_colparams, d_sumcols;  // grid: per-column parameters of the batched prep / of the batched sums
+    int sums_cols = 0;                      // columns of the reduction in flight (grid: sums_columns_begin)
+    size_t h_sums_cap = 0;
+    double* h_sums = nullptr;               // pinned landing buffer of the device sums
+    bool sums_pending = false, sums_empty = false;
+    viprs_comm* comm = nullptr;             // viprs_state_set_comm: the sums are all-rank sums (one all-gather per reduction)
+    hipEvent_t ev_prep = nullptr;           // the last batched prep launch (it reads d_colparams)
+    double* h_params = nullptr;             // pinned staging of the batched prep (6 x width) / sums (2 x width) parameters
+    ~viprs_state() {
+        if (h_sums) (void)hipHostFree(h_sums);
+        if (h_params) (void)hipHostFree(h_params);
+        if (ev_prep) (void)hipEventDestroy(ev_prep);
+    }
+    size_t field_elems(int field) const {
+        const size_t m = (size_t)plan->m;
+        switch (field) {
+            case VIPRS_FIELD_STD_BETA: return m;
+            case VIPRS_FIELD_LOG_NULL_PI: return model_kind == VIPRS_MODEL_MIXTURE ? m : 0;
+            case VIPRS_FIELD_ETA: case VIPRS_FIELD_Q: case VIPRS_FIELD_ETA_DIFF:
+                return model_kind == VIPRS_MODEL_GRID ? m * width : m;
+            default: return m * width;
+        }
+    }
+};
+
+namespace viprs {
+
+// after a synchronisation point: did a team hand-off give up (bounded spin)?
+int check_device_error(viprs_plan* P);
+
+// comm.hip: all-gather + rank-ordered reduction of the device vector (n doubles, in place) on `stream`; the last
+// element of every `group` is a maximum, the others are sums
+int comm_reduce_on_stream(viprs_comm* C, double* d_vec, int n, int group, hipStream_t stream);
+
+// ---- kernel families (one translation unit per family and LD element type) ------------------------
+enum { kGenSpikeSlab = 0, kGenMixture = 1, kGenGrid = 2 };
+enum { kPanelSpikeSlab = 0, kPanelGridColumn = 1, kPanelMixture = 2 };
+enum { kBandSpikeSlab = 0, kBandGridColumn = 1, kBandMixture = 2 };
+
+// generic kernels over one block list: `dense` = the repacked dense blocks, otherwise the ragged blocks
+template <typename T, typename U> int launch_generic(viprs_plan* P, EStepArgs<T> A, int model, bool dense);
+// panel kernels of the three size classes on their own streams, joined into the plan's stream
+template <typename U> int launch_panel(viprs_plan* P, EStepArgs<float> A, int model);
+// band kernel for the windowed components
+template <typename U> int launch_band(viprs_plan* P, EStepArgs<float> A, int model);
+int band_ring_panels(const viprs_plan* P);
+// batched grid E-step on the matrix cores
+template <typename U> int launch_grid_mfma(viprs_plan* P, EStepArgs<float> A);
+
+}  // namespace viprs

@@ -8,6 +8,19 @@ namespace viprs {
 constexpr int kPanel = 64;          // SNPs per panel = lanes per wavefront on gfx950
 constexpr int kStrip = 256;         // padding unit of the per-block q arrays (one fp32 updater strip: 64 lanes x 4 columns)
 
+// ---- sizes the host-side schedule shares with the kernel headers ------------------------------------
+// panel kernels (estep_panel.h): LDS carve (floats) q[qcap] | a[2][64] | T[2][64*64]
+__host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
+constexpr int kPanelMaxK = 8;       // mixture components the lane-parallel panel chain handles
+// LDS of the lane-parallel mixture chain: mu_mult | sqrt_half_var_tau | u_logs | var_mu | var_gamma, [64 SNPs][K]
+constexpr int kMixLdsFloats = 5 * kPanel * kPanelMaxK;
+constexpr int kMaxMixtureK = 64;    // generic mixture kernel (estep_generic.h): one lane per component
+constexpr int kGridModels = 32;     // batched grid kernel (estep_grid_mfma.h): models per launch (one 32-row MFMA tile)
+constexpr int kBandMaxRingPanels = 256;   // band kernel (estep_band.h): 64 KB of q in the LDS ring
+
+// work item of the second-pass / lower-pass kernels: (block, first row of a 64-row group or tile index)
+struct EpiItem { int32_t blk; int32_t row0; };
+
 // One LD block as the device sees it.
 struct BlockDesc {
     int32_t start;      // first SNP (index into the per-SNP vectors)

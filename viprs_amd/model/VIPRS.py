@@ -20,7 +20,7 @@ import logging
 
 import numpy as np
 
-from ..parallel import LocalComm, assign_chromosomes
+from ..parallel import BlockShard, LocalComm, broadcast_from_root, shard_blocks
 from ..utils.optim import ConditionStreak, OptimizeResult
 
 logger = logging.getLogger(__name__)
@@ -74,24 +74,23 @@ class VIPRS:
         self.math_mode = math_mode
         self._e_step_fn = e_step_fn
 
-        # ---- which chromosomes live on this rank -----------------------------------------------
+        # ---- inputs + LD: load, shard at LD-block granularity, then make device-resident ---------
+        # (BayesPRSModel.py:118-142, VIPRS.py:151-191).  With several ranks every LD block -- the
+        # independent unit of the E-step -- is assigned to one rank (chain-aware LPT over the blocks of
+        # ALL chromosomes, `parallel.shard_blocks`), so a single-chromosome fit shards as well; each rank
+        # keeps only the rows / per-SNP entries of its blocks, re-indexed to a local SNP numbering.
         self._all_shapes = dict(gdl.shapes)
-        ld_mats = gdl.get_ld_matrices()
-        costs = {c: float(self._all_shapes[c]) ** 2 for c in self._all_shapes}
-        self._owner = assign_chromosomes(costs, self.comm.world_size)
-        self.shapes = {c: s for c, s in self._all_shapes.items() if self._owner[c] == self.comm.rank}
         self._n_chroms_total = len(self._all_shapes)
-
-        # ---- inputs (BayesPRSModel.py:118-142) --------------------------------------------------
-        self.n_per_snp = {c: gdl.sumstats_table[c].n_per_snp for c in self.shapes}
-        self.std_beta = {c: gdl.sumstats_table[c].get_snp_pseudo_corr().astype(self._T) for c in self.shapes}
         self._sample_size = max(float(np.max(s.n_per_snp)) for s in gdl.sumstats_table.values())
+        ld_mats = gdl.get_ld_matrices()
+        world = self.comm.world_size
+        all_chroms = sorted(self._all_shapes)
 
-        # ---- LD: load, then make it device-resident (VIPRS.py:151-191) -------------------------
         self.ld_data, self.ld_indptr, self.ld_left_bound = {}, {}, {}
         self.lambda_min = 0.0
         self._expanded = False
-        for c in self.chromosomes:
+        loaded = {}
+        for c in all_chroms:
             ld_mat = ld_mats[c]
             if dequantize_on_the_fly and np.issubdtype(ld_mat.stored_dtype, np.integer):
                 dtype = ld_mat.stored_dtype
@@ -109,16 +108,49 @@ class VIPRS:
             if expand:
                 lop = ld_mat.load(return_symmetric=False, dtype=dtype)
                 self._expanded = True
-            self.ld_data[c], self.ld_indptr[c], self.ld_left_bound[c] = lop.ld_data, lop.ld_indptr, lop.leftmost_idx
+            loaded[c] = (lop.ld_data, lop.ld_indptr, lop.leftmost_idx)
             if lambda_min is None:
                 self.lambda_min = 0.0
             elif _is_numeric(lambda_min):
                 self.lambda_min = lambda_min
-            else:                                                    # 'infer'
+            else:                                # 'infer': the reference keeps the LAST chromosome's value (:186-191)
                 self.lambda_min = ld_mat.get_lambda_min(min_max_ratio=1e-3)
+
+        self._shard = {}
+        if world > 1:
+            from ..plan import plan_blocks
+            upper_form = bool(low_memory) or self._expanded
+            starts = {c: plan_blocks(np.ascontiguousarray(loaded[c][2], dtype=np.int32), loaded[c][1], upper_form)[0]
+                      for c in all_chroms}
+            sizes = np.concatenate([np.diff(starts[c]) for c in all_chroms])
+            es = np.dtype(loaded[all_chroms[0]][0].dtype).itemsize
+            owner = shard_blocks(sizes, world, es)
+            k = 0
+            for c in all_chroms:
+                nb = len(starts[c]) - 1
+                mine = [b for b in range(nb) if owner[k + b] == self.comm.rank]
+                k += nb
+                self._shard[c] = BlockShard(starts[c], mine)
+        self.shapes = {}
+        self.n_per_snp, self.std_beta = {}, {}
+        for c in all_chroms:
+            data, ip, lb = loaded.pop(c)
+            sh = self._shard.get(c)
+            if sh is None:
+                self.shapes[c] = int(self._all_shapes[c])
+                self.ld_data[c], self.ld_indptr[c], self.ld_left_bound[c] = data, ip, lb
+                self.n_per_snp[c] = gdl.sumstats_table[c].n_per_snp
+                self.std_beta[c] = gdl.sumstats_table[c].get_snp_pseudo_corr().astype(self._T)
+            elif sh.m > 0:
+                self.shapes[c] = sh.m
+                self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c] = sh.slice_ld(
+                    np.asarray(lb), np.asarray(ip), data)
+                self.n_per_snp[c] = sh.take(gdl.sumstats_table[c].n_per_snp)
+                self.std_beta[c] = sh.take(gdl.sumstats_table[c].get_snp_pseudo_corr()).astype(self._T)
+            del data
         self.dequantize_on_the_fly = dequantize_on_the_fly
-        if dequantize_on_the_fly and self.chromosomes:
-            self.dequantize_scale = 1.0 / np.iinfo(self.ld_data[self.chromosomes[0]].dtype).max   # :203-207
+        if dequantize_on_the_fly:
+            self.dequantize_scale = 1.0 / np.iinfo(ld_mats[all_chroms[0]].stored_dtype).max              # :203-207
         else:
             self.dequantize_scale = 1.0
 
@@ -131,23 +163,34 @@ class VIPRS:
                 raise RuntimeError("VIPRS needs a HIP device: the E-step has no CPU fallback")
             self.device = int(device) if device is not None else self.comm.rank % ndev
             self._resident = bool(device_resident) and self._supports_resident()
+            # several ranks: ONE plan per rank whatever the number of local chromosomes (one collective per EM
+            # iteration, per-SNP weights 1 / m_c of the FULL chromosome for the update_pi mean)
             self._merged = (self._resident and bool(merge_chromosomes) and self._supports_merged()
-                            and len(self.chromosomes) > 1)
+                            and (len(self.chromosomes) > 1 or world > 1))
             if self._merged:
                 # one plan over the concatenated chromosomes: windows and row offsets shifted into place
                 from ..data import merge_ld_arrays
                 chroms = self.chromosomes
-                lb, ip, data, self._seg = merge_ld_arrays(chroms, self.shapes, self.ld_left_bound, self.ld_indptr,
-                                                          self.ld_data)
+                if chroms:
+                    lb, ip, data, self._seg = merge_ld_arrays(chroms, self.shapes, self.ld_left_bound, self.ld_indptr,
+                                                              self.ld_data)
+                else:                            # a rank without any LD block still takes part in the reductions
+                    ref = ld_mats[all_chroms[0]]
+                    lb, ip, self._seg = np.zeros(0, np.int32), np.zeros(1, np.int64), {}
+                    data = np.zeros(0, ref.stored_dtype if self.dequantize_on_the_fly else self._T)
                 if self._expanded:
                     self._plans["*"] = LDPlan.from_upper(ip, data, device=self.device, math_mode=math_mode)
                 else:
                     self._plans["*"] = LDPlan(lb, ip, data, low_memory, device=self.device, math_mode=math_mode)
                 del data
                 ds = self._dstate["*"] = self._make_device_state(self._plans["*"])
-                ds.upload("std_beta", np.concatenate([self.std_beta[c] for c in chroms]))
-                ds.set_n_per_snp(np.concatenate([np.asarray(self.n_per_snp[c], dtype=np.float64).ravel() for c in chroms]))
-                ds.set_snp_weights(np.concatenate([np.full(self.shapes[c], 1.0 / self.shapes[c]) for c in chroms]))
+                cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+                ds.upload("std_beta", cat([self.std_beta[c] for c in chroms], self._T))
+                ds.set_n_per_snp(cat([np.asarray(self.n_per_snp[c], dtype=np.float64).ravel() for c in chroms], np.float64))
+                ds.set_snp_weights(cat([np.full(self.shapes[c], 1.0 / self._all_shapes[c]) for c in chroms], np.float64))
+                if getattr(self.comm, "device_side", False) and world > 1:
+                    ds.set_comm(self.comm)       # sums_begin / sums_end return the all-rank sums (RCCL, C ABI)
+                    self._device_reduce = True
             else:
                 for c in self.chromosomes:
                     if self._expanded:
@@ -171,6 +214,7 @@ class VIPRS:
                 self._expanded = False
         self._host_stale = False
         self._last_prep = None
+        self._device_reduce = getattr(self, "_device_reduce", False)
 
         # ---- model state -------------------------------------------------------------------------
         self.var_gamma, self.var_mu, self.var_tau, self._log_var_tau = {}, {}, {}, {}
@@ -232,7 +276,20 @@ class VIPRS:
             theta_0 = {}
         return theta_0
 
+    def _sync_theta(self):
+        """Several ranks: everyone takes rank 0's hyper-parameters (the random draws of initialize_theta
+        would otherwise differ per rank).  One small collective, called symmetrically on every rank."""
+        if self.comm.world_size == 1:
+            return
+        pi, tau = np.atleast_1d(np.asarray(self.pi, dtype=np.float64)), np.atleast_1d(np.asarray(self.tau_beta, dtype=np.float64))
+        v = broadcast_from_root(self.comm, np.concatenate([pi, tau, [float(self.sigma_epsilon)]]))
+        pi_b, tau_b = v[:pi.size], v[pi.size:pi.size + tau.size]
+        self.pi = pi_b.reshape(np.shape(self.pi)) if np.ndim(self.pi) else float(pi_b[0])
+        self.tau_beta = tau_b.reshape(np.shape(self.tau_beta)) if np.ndim(self.tau_beta) else float(tau_b[0])
+        self.sigma_epsilon = float(v[-1])
+
     def _cast_theta(self):
+        self._sync_theta()
         t = self._T.type
         self.sigma_epsilon, self.pi, self.lambda_min = t(self.sigma_epsilon), t(self.pi), t(self.lambda_min)
         self._sigma_g = t(0.0)
@@ -393,6 +450,38 @@ class VIPRS:
         self.post_mean_beta = {c: e.copy() for c, e in self.eta.items()}
         self.post_var_beta = {c: z - self.eta[c] ** 2 for c, z in self.zeta.items()}
 
+    def _gather_posterior(self):
+        """Several ranks: every rank ends up with the posterior of ALL SNPs (pip / post_mean_beta /
+        post_var_beta and q keyed by every chromosome, full length) -- one exchange at the end of fit(),
+        the only time per-SNP vectors travel.  The variational state itself stays sharded."""
+        if self.comm.world_size == 1:
+            return
+        chroms = sorted(self._all_shapes)
+
+        def gather(local):
+            tail = next((np.shape(a)[1:] for a in local.values()), None)
+            tail_v = self.comm.allreduce_max(np.array([float(tail[0]) if tail else 0.0]))    # grid models: (m, G)
+            tail = (int(tail_v[0]),) if tail_v[0] > 0 else ()
+            width = int(np.prod(tail)) if tail else 1
+            full = np.zeros((sum(self._all_shapes[c] for c in chroms), width), dtype=np.float64)
+            off = 0
+            for c in chroms:
+                sh = self._shard[c]
+                if sh.m > 0:
+                    full[off + sh.index] = np.asarray(local[c], dtype=np.float64).reshape(sh.m, width)
+                off += self._all_shapes[c]
+            full = self.comm.allreduce_sum(full.ravel()).reshape(full.shape)
+            out, off = {}, 0
+            for c in chroms:
+                a = full[off:off + self._all_shapes[c]].astype(self._T)
+                out[c] = a.reshape((self._all_shapes[c],) + tail)
+                off += self._all_shapes[c]
+            return out
+
+        self.pip, self.post_mean_beta, self.post_var_beta = gather(self.pip), gather(self.post_mean_beta), \
+            gather(self.post_var_beta)
+        self.q_full = gather(self.q)
+
     # ---- posterior tables and pseudo-validation (BayesPRSModel.py:333-410) --------------------------
     def to_table(self, col_subset=("CHR", "SNP", "POS", "A1", "A2"), per_chromosome=False):
         """Posterior estimates as a pandas table: the data loader's SNP columns (``gdl.to_snp_table``
@@ -404,7 +493,8 @@ class VIPRS:
         if hasattr(self.gdl, "to_snp_table"):
             tables = self.gdl.to_snp_table(col_subset=col_subset, per_chromosome=True)
         else:
-            tables = {c: pd.DataFrame({"CHR": c, "IDX": np.arange(self.shapes[c])}) for c in self.chromosomes}
+            tables = {c: pd.DataFrame({"CHR": c, "IDX": np.arange(len(self.post_mean_beta[c]))})
+                      for c in sorted(self.post_mean_beta)}
 
         def cols(name, a):
             a = np.asarray(a)
@@ -412,14 +502,15 @@ class VIPRS:
                 return {name: a}
             return {f"{name}_{i}": a[:, i] for i in range(a.shape[1])}
 
-        for c in self.chromosomes:
+        chroms = sorted(self.post_mean_beta)
+        for c in chroms:
             add = dict(cols("BETA", self.post_mean_beta[c]))
             if self.pip is not None:
                 add.update(cols("PIP", self.pip[c]))
             if self.post_var_beta is not None:
                 add.update(cols("VAR_BETA", self.post_var_beta[c]))
             tables[c] = pd.concat([tables[c], pd.DataFrame(add, index=tables[c].index)], axis=1)
-        return tables if per_chromosome else pd.concat([tables[c] for c in self.chromosomes])
+        return tables if per_chromosome else pd.concat([tables[c] for c in chroms])
 
     def pseudo_validate(self, validation_std_beta=None):
         """Pseudo-R^2 of the fitted effects against standardized marginal betas of an independent
@@ -429,9 +520,11 @@ class VIPRS:
         vb = validation_std_beta if validation_std_beta is not None else getattr(self, "validation_std_beta", None)
         assert self.post_mean_beta is not None, "The posterior means for BETA are not set. Call `.fit()` first."
         assert vb is not None, "standardized betas of a validation set are required"
-        cat = lambda d: np.concatenate([np.asarray(d[c]) for c in self.chromosomes], axis=0)
+        chroms = sorted(self.post_mean_beta)
+        q = self.q_full if self.comm.world_size > 1 else self.q       # several ranks: gathered at the end of fit()
+        cat = lambda d: np.concatenate([np.asarray(d[c]) for c in chroms], axis=0)
         r, b = cat(vb), cat(self.post_mean_beta)
-        rb_w = cat({c: self.q[c] + self.post_mean_beta[c] for c in self.chromosomes})
+        rb_w = cat({c: q[c] + self.post_mean_beta[c] for c in chroms})
         rb = np.sum((b.T * r).T, axis=0)
         bsb = np.sum(b * rb_w, axis=0)
         return rb ** 2 / bsb
@@ -451,7 +544,7 @@ class VIPRS:
                 ds.sums_begin(1.0 + lam)
             for c, ds in self._dstate.items():       # ... then collected in order
                 v = ds.sums_end()
-                s[0] += v[0] if self._merged else v[0] / self.shapes[c]     # merged: weights 1 / m_c on the device
+                s[0] += v[0] if self._merged else v[0] / self._all_shapes[c]     # merged: weights 1 / m_c on the device
                 s[1:5] += v[1:5]
                 s[5:9] += v[5:9]
                 s[9] += v[9]
@@ -460,7 +553,7 @@ class VIPRS:
         s = np.zeros(9, dtype=np.float64)
         for c in self.chromosomes:
             g, z = self.var_gamma[c], self.zeta[c]
-            s[0] += np.mean(g, axis=0)                                   # update_pi: mean of per-chromosome means
+            s[0] += np.sum(g, axis=0) / self._all_shapes[c]              # update_pi: mean of per-chromosome means (:446-453)
             s[1] += z.sum()
             s[2] += np.sum((1.0 + lam) * z + np.multiply(self.q[c], self.eta[c]), axis=0)
             s[3] += self.std_beta[c].dot(self.eta[c])
@@ -481,11 +574,22 @@ class VIPRS:
         if self._sums is not None and self._sums_valid and not force:
             return self._sums
         self._sums_valid = True
-        self._sums = self.comm.allreduce_sum(self._partial_sums())
-        if self._resident and self._host_stale:
-            local_max = self._dev_max_eta_diff
-        else:
-            local_max = max([float(np.max(np.abs(d))) for d in self.eta_diff.values()] or [0.0])
+        on_device = self._resident and self._host_stale
+        part = self._partial_sums()
+        if on_device and self._device_reduce:
+            # the device sums were all-gathered and reduced in rank order on the plan's stream (RCCL through
+            # the C ABI, `DeviceState.set_comm`): ONE collective per EM iteration, max |eta_diff| included
+            self._sums = part
+            self._max_eta_diff = float(self._dev_max_eta_diff)
+            return self._sums
+        local_max = self._dev_max_eta_diff if on_device else \
+            max([float(np.max(np.abs(d))) if d.size else 0.0 for d in self.eta_diff.values()] or [0.0])
+        if self.comm.world_size == 1:
+            self._sums, self._max_eta_diff = np.asarray(part, dtype=np.float64), float(local_max)
+            return self._sums
+        # host transport (CPU tests over gloo): the max travels as one more slot of the same exchange
+        both = self.comm.allreduce_sum(np.concatenate([part, [0.0]]))
+        self._sums = both[:-1]
         self._max_eta_diff = float(self.comm.allreduce_max(np.array([local_max]))[0])
         return self._sums
 
@@ -508,7 +612,7 @@ class VIPRS:
 
     # ---- objective (VIPRS.py:497-581) ----------------------------------------------------------------
     def elbo(self, sum_axis=None):
-        s = self._sums if self._sums is not None else self._reduce()
+        s = self._current_sums()
         pi, null_pi, tau_beta = self.pi, self.get_null_pi(), self.tau_beta
         e = -np.log(2.0 * np.pi * self.sigma_epsilon)
         if "sigma_epsilon" not in self.fix_params:
@@ -525,7 +629,7 @@ class VIPRS:
     objective = elbo
 
     def mse(self, sum_axis=None):                                                      # :689-704
-        s = self._sums
+        s = self._current_sums()
         return 1.0 - 2.0 * s[3] + (self._sigma_g - s[1] + s[4])
 
     # ---- the ELBO's parts (VIPRS.py:583-687), from the same partial sums as `elbo` -----------------------
@@ -666,6 +770,7 @@ class VIPRS:
 
         self.sync_host()
         self.update_posterior_moments()
+        self._gather_posterior()
         if not res.stop_iteration:
             res.update(self.elbo(), stop_iteration=True, success=False, increment=False,
                        message="Maximum iterations reached without convergence.\n"

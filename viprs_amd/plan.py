@@ -117,6 +117,10 @@ class LDPlan:
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            if getattr(self, "_live_states", 0) > 0:
+                # a DeviceState dereferences its plan when it is destroyed: closing the plan first would be a
+                # use-after-free on the C side
+                raise ValueError(f"LDPlan.close(): {self._live_states} DeviceState(s) of this plan are still open")
             L.lib.viprs_plan_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -229,11 +233,13 @@ class DeviceState:
         self._h = ctypes.c_void_p()
         L.check(L.lib.viprs_state_create(ctypes.byref(self._h), plan.handle, _FLOAT_CODE[self.dtype], kind,
                                          self.width))
+        plan._live_states = getattr(plan, "_live_states", 0) + 1
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             L.lib.viprs_state_destroy(self._h)
             self._h = ctypes.c_void_p()
+            self.plan._live_states -= 1
 
     def __del__(self):
         try:
@@ -266,11 +272,28 @@ class DeviceState:
         order = "F" if self.model == "grid" and len(shape) == 2 else "C"
         if out is None:
             out = np.empty(shape, dtype=self.dtype, order=order)
+        else:                                   # the C side copies field_elems * itemsize bytes whatever it is handed
+            if not isinstance(out, np.ndarray) or out.dtype != self.dtype:
+                raise ValueError(f"Buffer dtype mismatch for {name}: expected {self.dtype}, got "
+                                 f"{getattr(out, 'dtype', type(out))}")
+            if tuple(out.shape) != shape:
+                raise ValueError(f"{name}: expected shape {shape}, got {out.shape}")
+            if (order == "F" and not out.flags.f_contiguous) or (order == "C" and not out.flags.c_contiguous):
+                raise ValueError(f"ndarray is not {'Fortran' if order == 'F' else 'C'} contiguous ({name})")
+            if not out.flags.writeable:
+                raise ValueError(f"{name}: output array is read-only")
         L.check(L.lib.viprs_state_download(self._h, self.FIELDS[name], _ptr(out)))
         return out
 
     def reset(self, pi):
         L.check(L.lib.viprs_state_reset(self._h, float(pi)))
+
+    def set_comm(self, comm):
+        """Attach an ``RcclComm`` (None detaches): `sums_begin / sums_end` (and the mixture / grid-column
+        variants) then return the sums over ALL ranks -- one all-gather + rank-ordered reduction on the
+        plan's stream per call (`viprs_state_set_comm`)."""
+        self._comm = comm                       # keeps the communicator alive as long as the state uses it
+        L.check(L.lib.viprs_state_set_comm(self._h, comm.handle if comm is not None else None))
 
     # -- device-resident EM iteration (spike-and-slab) ------------------------------------------
     def set_n_per_snp(self, n_per_snp):
