@@ -2,8 +2,8 @@
 """bench.py -- SNP-updates/sec of one E-step sweep over synthetic LD blocks on N MI355X GPUs.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU.
-Rank 0 prints ONE JSON line.
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU
+(RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Rank 0 prints ONE JSON line.
 
 A "step" = one pass of the hot path over one batch: the variational state is re-initialised on
 the device to the standard start (var_gamma = pi, var_mu = eta = q = eta_diff = 0; the reference's
@@ -12,10 +12,14 @@ because a converged state takes the skip branch e_step.hpp:410-413 and reads no 
 E-step sweep runs over every LD block of the workload.  LD and the per-SNP inputs are resident in
 HBM before the timed region starts.
 
-Workload (N = 1): BASELINE.json configs[2] -- ~1.1 M SNPs in ~1 700 LD blocks (lognormal block
-sizes, AR(1) LD), spike-and-slab prior, fp32 state, fp32 LD, symmetric form.
-N > 1: "weak" (default) gives every rank its own genome-scale workload (blocks are independent,
-no data-path collective); "strong" shards the blocks of ONE workload over the ranks.
+Workload: BASELINE.json configs[2] -- ~1.1 M SNPs in ~1 700 LD blocks (lognormal block sizes, AR(1)
+LD), spike-and-slab prior, fp32 state, fp32 LD, symmetric form.
+N > 1 (default, "strong"): the blocks of that ONE workload are sharded over the ranks (chain-aware
+LPT, viprs_amd.parallel.shard_blocks; no data-path collective) and `value` = its 1.1 M SNPs per max-
+over-ranks sweep time.  The weak-scaling figure (every rank its own genome-scale workload) is measured
+in the same run and reported under `weak_scaling` -- never as `value`.
+
+No PyTorch: the ranks synchronise and reduce through RCCL via the C ABI (viprs_comm_*).
 """
 import argparse
 import json
@@ -37,12 +41,16 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg3max"],
+                    help="cfg3max = cfg3 with its largest block replaced by a 6 000-SNP one (BASELINE's clip limit)")
     ap.add_argument("--low-memory", action="store_true", help="upper-triangular LD (reference default)")
     ap.add_argument("--ld-dtype", default="float32", choices=["float32", "int8", "int16"])
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = ONE workload sharded by LD block (BASELINE's config); weak = one workload per rank")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (N = 1: upper-triangular sweep; N > 1: weak scaling)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--model", default="spike_slab", choices=["spike_slab", "mixture", "grid"],
                     help="spike_slab = the headline (configs[1..2]); mixture = configs[3] (VIPRSMix); grid = configs[4]")
     ap.add_argument("--width", type=int, default=0, help="mixture components K (default 4) / grid models G (default 32)")
@@ -50,29 +58,40 @@ def parse_args():
     return ap.parse_args()
 
 
+def config_sizes(config, seed):
+    from viprs_amd.utils import synthetic as syn
+    if config == "cfg3max":
+        s = syn.block_sizes("cfg3", seed).copy()
+        s[int(np.argmax(s))] = 6000
+        return s
+    return syn.block_sizes(config, seed)
+
+
 def shard_blocks_lpt(sizes, n_parts):
-    """Longest-processing-time bin packing of blocks (cost ~ b^2) over ranks (strong scaling)."""
-    order = np.argsort(-sizes, kind="stable")
-    load = np.zeros(n_parts)
-    parts = [[] for _ in range(n_parts)]
-    for i in order:
-        r = int(np.argmin(load))
-        parts[r].append(int(i))
-        load[r] += float(sizes[i]) ** 2
-    return [sorted(p) for p in parts]
+    """Blocks of one workload -> ranks (chain-aware LPT, viprs_amd.parallel.shard_blocks); sorted block lists."""
+    from viprs_amd.parallel import shard_blocks
+    owner = shard_blocks(np.asarray(sizes), n_parts)
+    return [sorted(int(i) for i in np.nonzero(owner == r)[0]) for r in range(n_parts)]
 
 
+# ---- CPU baseline ---------------------------------------------------------------------------------------
 def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0=None):
-    """The reference's own e_step.hpp (oracle/_ref, built from /root/reference by oracle/Makefile)
-    timed on this host, state re-initialised before every call: first with threads=1 (the parity
-    reference), then with its OpenMP path on all cores (racy Hogwild, e_step.hpp:384-387 -- the
-    "reference multithreaded-CPU" figure).  Sample: leading blocks of the same workload sized to
-    the time budget (a mixture / grid SNP-update costs `width` times a spike-and-slab one)."""
+    """The reference's own e_step.hpp (oracle/_ref, built from /root/reference by oracle/Makefile) timed on
+    this host, state re-initialised before every call:
+      1. threads=1 (the parity reference);
+      2. its OpenMP path on all hardware threads -- racy Hogwild, e_step.hpp:384-387: the "reference
+         multithreaded-CPU" figure, `value`;
+      3. exact block-parallel: one threads=1 call per LD block, blocks spread over all hardware threads
+         (what joblib over chromosomes does at a finer grain, bin/viprs_fit:1080-1086) -- spike-and-slab only;
+      4. variant 2 from a build with -march=x86-64-v3 (AVX2 + FMA: the portable stand-in for the
+         "-march=native" optimistic-CPU line -- the library is built where /root/reference lives, not here).
+    Sample of 1, 2, 4: leading blocks of the same workload sized to the time budget (a mixture / grid SNP-update
+    costs `width` times a spike-and-slab one); 3 runs the WHOLE workload (its sweep takes tens of ms)."""
     from oracle import oracle as O
     kind = "reference" if O.have_reference() else "restated"
     cores = os.cpu_count() or 1
-    # ~0.2-0.5 M SNP-updates/s single-threaded: size the sample for ~budget/3 per single-thread pass
-    target_snps = int(min(ld.m, max(2000, 0.1e6 * budget_s / max(1, width))))
+    # ~0.2-0.5 M SNP-updates/s single-threaded: size the sample for ~budget/4 per single-thread pass
+    target_snps = int(min(ld.m, max(2000, 0.08e6 * budget_s / max(1, width))))
     nb = int(np.searchsorted(ld.block_start, target_snps, side="left"))
     nb = max(1, min(nb, len(ld.block_start) - 1))
     m_s = int(ld.block_start[nb])
@@ -88,46 +107,176 @@ def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0
         order = "F" if model == "grid" else "C"
         vec = {k: np.asarray(v[:m_s], order=order).copy(order=order) for k, v in extra.items()}
 
-    def one(threads):
+    def one(threads, kind_):
         if model == "spike_slab":
             st = {k: np.ascontiguousarray(v[:m_s]).copy() for k, v in inp.state_copy().items()}
             t0 = time.perf_counter()
             O.cpp_e_step(lb, ip, data, std_beta, st["var_gamma"], st["var_mu"], st["eta"], st["q"],
                          st["eta_diff"], vec["u_logs"], vec["sqrt_half_var_tau"], vec["mu_mult"], ld.dq_scale,
-                         threads, ld.low_memory, kind=kind)
+                         threads, ld.low_memory, kind=kind_)
         elif model == "mixture":
             vg = np.full((m_s, width), pi0, dtype=T)
             vm = np.zeros((m_s, width), dtype=T)
             eta, q, ed = (np.zeros(m_s, dtype=T) for _ in range(3))
             t0 = time.perf_counter()
             O.cpp_e_step_mixture(lb, ip, data, std_beta, vg, vm, eta, q, ed, vec["log_null_pi"], vec["u_logs"],
-                                 vec["sqrt_half_var_tau"], vec["mu_mult"], ld.dq_scale, threads, ld.low_memory, kind=kind)
+                                 vec["sqrt_half_var_tau"], vec["mu_mult"], ld.dq_scale, threads, ld.low_memory, kind=kind_)
         else:
             vg = np.full((m_s, width), pi0, dtype=T, order="F")
             vm, eta, q, ed = (np.zeros((m_s, width), dtype=T, order="F") for _ in range(4))
             t0 = time.perf_counter()
             O.cpp_e_step_grid(lb, ip, data, std_beta, vg, vm, eta, q, ed, vec["u_logs"], vec["half_var_tau"],
                               vec["mu_mult"], ld.dq_scale, np.arange(width, dtype=np.int32), threads, ld.low_memory,
-                              kind=kind)
+                              kind=kind_)
         return time.perf_counter() - t0
 
-    res = {}
-    for name, threads in (("threads1", 1), ("all_cores", cores if kind == "reference" else 1)):
-        one(threads)                                   # warm-up
+    def timed(fn, share):
+        fn()                                           # warm-up
         ts, t_used = [], 0.0
-        while t_used < budget_s / 3 and len(ts) < 15:
-            dt = one(threads)
+        while t_used < budget_s * share and len(ts) < 15:
+            dt = fn()
             ts.append(dt)
             t_used += dt
-        res[name] = m_s / float(np.median(ts))
+        return float(np.median(ts))
+
+    res = {"threads1": m_s / timed(lambda: one(1, kind), 0.25)}
+    mt = cores if kind == "reference" else 1
+    res["all_cores"] = m_s / timed(lambda: one(mt, kind), 0.2)
+    variants = {
+        "1_single_thread": res["threads1"],
+        "2_openmp_all_threads_racy": res["all_cores"],
+    }
+    if kind == "reference" and O.have_reference("reference_v3"):
+        variants["4_openmp_all_threads_racy_march_x86_64_v3"] = m_s / timed(lambda: one(mt, "reference_v3"), 0.15)
+        variants["4_single_thread_march_x86_64_v3"] = m_s / timed(lambda: one(1, "reference_v3"), 0.15)
+    if model == "spike_slab":
+        variants["3_block_parallel_exact"] = _block_parallel_exact(ld, inp, kind, cores, budget_s * 0.2)
     return {
-        "value": res["all_cores"], "unit": "SNP-updates/s", "cores": cores if kind == "reference" else 1,
+        "value": res["all_cores"], "unit": "SNP-updates/s", "cores": mt,
         "kind": "reference" if kind == "reference" else "port",
         "sample": f"first {nb} LD blocks ({m_s} SNPs, {nnz_s} LD entries) of the same workload, model={model}"
                   + (f" width={width}" if model != "spike_slab" else "")
-                  + f", state re-initialised per call, median; OpenMP threads={cores} (racy, as the reference)",
+                  + f", state re-initialised per call, median; OpenMP threads={mt} (racy, as the reference)"
+                  + "; variant 3 = every block of the workload, one threads=1 call per block on a thread pool",
         "single_thread_value": res["threads1"],
+        "variants": variants,
     }
+
+
+def _block_parallel_exact(ld, inp, kind, workers, budget_s):
+    """SNP-updates/s of the whole workload with one exact (threads=1) reference call per LD block, blocks
+    dealt to `workers` host threads longest first (ctypes releases the GIL; each call is plain C++)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    bs = ld.block_start
+    order = np.argsort(-np.diff(bs), kind="stable")
+    blocks = []
+    for b in order:
+        s, e = int(bs[b]), int(bs[b + 1])
+        o = int(ld.ld_indptr[s])
+        blocks.append((s, e, np.ascontiguousarray(ld.ld_left_bound[s:e] - s, dtype=np.int32),
+                       np.ascontiguousarray(ld.ld_indptr[s:e + 1] - o), ld.ld_data[o:int(ld.ld_indptr[e])]))
+    workers = max(1, min(workers, len(blocks)))
+
+    def sweep():
+        st = inp.state_copy()
+        t0 = time.perf_counter()
+
+        def run(k):
+            for s, e, lb, ip, data in blocks[k::workers]:
+                O.cpp_e_step(lb, ip, data, inp.std_beta[s:e], st["var_gamma"][s:e], st["var_mu"][s:e], st["eta"][s:e],
+                             st["q"][s:e], st["eta_diff"][s:e], inp.u_logs[s:e], inp.sqrt_half_var_tau[s:e],
+                             inp.mu_mult[s:e], ld.dq_scale, 1, ld.low_memory, kind=kind)
+
+        list(pool.map(run, range(workers)))
+        return time.perf_counter() - t0
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        sweep()
+        ts, used = [], 0.0
+        while used < budget_s and len(ts) < 10:
+            ts.append(sweep())
+            used += ts[-1]
+    return ld.m / float(np.median(ts))
+
+
+# ---- workload ---------------------------------------------------------------------------------------------
+def build_workload(args, sizes_all, mine, seed, low_memory, ld_dtype):
+    """LD + inputs of the blocks `mine` of the workload (`sizes_all`, seed): every random draw is made for the
+    WHOLE workload (block AR(1) coefficients, effects, noise, hyper-parameters M pi / h2), so a block holds
+    the same numbers whichever rank it lands on and however many ranks share the workload."""
+    from viprs_amd.utils import synthetic as syn
+    rng = np.random.default_rng(seed + 1)
+    rho_all = rng.uniform(0.3, 0.8, len(sizes_all))
+    if mine is None:
+        ld = syn.make_ld(sizes_all, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, rho=rho_all)
+        ss = syn.make_sumstats(ld, seed=seed)
+        return ld, ss, syn.make_inputs(ss), ld.m
+    starts = np.concatenate([[0], np.cumsum(sizes_all)]).astype(np.int64)
+    m_all = int(starts[-1])
+    skeleton = syn.SyntheticLD(np.empty(m_all, np.int32), None, None, starts, rho_all, low_memory)
+    ss_all = syn.make_sumstats(skeleton, seed=seed)
+    inp_all = syn.make_inputs(ss_all)
+    idx = np.concatenate([np.arange(starts[b], starts[b + 1]) for b in mine]) if len(mine) else np.zeros(0, np.int64)
+    ld = syn.make_ld(sizes_all[mine], low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, rho=rho_all[mine])
+    ss = syn.SyntheticSumstats(ss_all.std_beta[idx], ss_all.n_per_snp[idx], ss_all.beta_true[idx], ss_all.n)
+    take = lambda a: np.ascontiguousarray(a[idx])
+    inp = syn.EStepInputs(**{k: take(getattr(inp_all, k)) for k in
+                             ("std_beta", "var_gamma", "var_mu", "eta", "q", "eta_diff", "u_logs", "sqrt_half_var_tau",
+                              "mu_mult")},
+                          pi=inp_all.pi, sigma_epsilon=inp_all.sigma_epsilon, tau_beta=inp_all.tau_beta)
+    return ld, ss, inp, m_all
+
+
+class Sweep:
+    """Device-resident plan + state of one workload (share) and the timed step."""
+
+    def __init__(self, args, ld, ss, inp, device, model, width, low_memory):
+        from viprs_amd.plan import DeviceState, LDPlan
+        from viprs_amd.utils import synthetic as syn
+        self.ld = ld
+        self.plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory, device=device, math_mode=args.math)
+        self.state = DeviceState(self.plan, "float32", model, width)
+        self.active = None
+        self.host_extra = None
+        self.pi0 = inp.pi
+        if model == "spike_slab":
+            for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+                self.state.upload(name, getattr(inp, name))
+        else:
+            extra = syn.make_mixture_inputs(ss, width) if model == "mixture" else syn.make_grid_inputs(ss, width)
+            self.pi0 = extra.pop("pi")
+            self.host_extra = extra
+            self.state.upload("std_beta", inp.std_beta)
+            for name, arr in extra.items():
+                self.state.upload(name, arr)
+            if model == "grid":
+                self.active = np.arange(width, dtype=np.int32)
+
+    def step(self):
+        self.state.reset(self.pi0)
+        self.state.e_step(self.ld.dq_scale, self.active, sync=False)
+
+    def run(self, steps, warmup, barrier):
+        """W untimed steps, barrier, exactly K timed steps, device idle; returns this rank's seconds."""
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        self.plan.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.state.synchronize()
+        barrier()
+        return time.perf_counter() - t0
+
+    def close(self):
+        self.state.close()
+        self.plan.close()
+
+
+def pct(v, q):
+    return float(np.percentile(v, q)) if len(v) else None
 
 
 def main():
@@ -139,109 +288,90 @@ def main():
     if world != n_gpus and world > 1:
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
 
-    dist = None
-    backend = os.environ.get("VIPRS_BENCH_BACKEND", "nccl")       # nccl = RCCL over xGMI; gloo for dry runs
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-
     from viprs_amd import _lib
-    from viprs_amd.plan import DeviceState, LDPlan
-    from viprs_amd.utils import synthetic as syn
+    from viprs_amd.parallel import LocalComm, RcclComm, rank_time_model
 
-    if _lib.device_count() < 1:
+    ndev = _lib.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (the E-step has no CPU fallback)")
-
-    # ---- workload -------------------------------------------------------------------------------
-    ld_dtype = np.dtype(args.ld_dtype)
-    sizes_all = syn.block_sizes(args.config, args.seed)
-    if world > 1 and args.scaling == "strong":
-        mine = shard_blocks_lpt(sizes_all, world)[rank]
-        sizes = sizes_all[mine]
-        seed = args.seed
-    else:
-        sizes = sizes_all
-        seed = args.seed + 1000 * rank          # weak: every rank its own genome-scale workload
-    ld = syn.make_ld(sizes, low_memory=args.low_memory, ld_dtype=ld_dtype, seed=seed)
-    ss = syn.make_sumstats(ld, seed=seed)
-    inp = syn.make_inputs(ss)
-
-    device = local_rank % _lib.device_count()
-    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, ld.low_memory, device=device, math_mode=args.math)
-    width = args.width or {"spike_slab": 1, "mixture": 4, "grid": 32}[args.model]
-    state = DeviceState(plan, "float32", args.model, width)
-    active = None
-    host_extra = None
-    pi0 = inp.pi
-    if args.model == "spike_slab":
-        for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
-            state.upload(name, getattr(inp, name))
-    else:
-        extra = syn.make_mixture_inputs(ss, width) if args.model == "mixture" else syn.make_grid_inputs(ss, width)
-        pi0 = extra.pop("pi")
-        host_extra = extra
-        state.upload("std_beta", inp.std_beta)
-        for name, arr in extra.items():
-            state.upload(name, arr)
-        if args.model == "grid":
-            active = np.arange(width, dtype=np.int32)
-
-    def step():
-        state.reset(pi0)
-        state.e_step(ld.dq_scale, active, sync=False)
+    device = local_rank % ndev
+    comm = RcclComm(rank, world, device) if world > 1 else LocalComm()     # RCCL over xGMI, C ABI; no PyTorch
 
     def barrier():
-        state.synchronize()
-        if dist is not None:
-            if backend == "nccl":
-                import torch
-                torch.cuda.synchronize()
-            dist.barrier()
+        # every rank: device idle (hipDeviceSynchronize), then all ranks arrived (RCCL collective + stream sync)
+        _lib.check(_lib.lib.viprs_device_synchronize(device))
+        comm.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    plan.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    state.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        dev = "cuda" if backend == "nccl" else "cpu"
-        if backend == "nccl":
-            torch.cuda.synchronize()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(ld.m)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_snps = float(tot.item())
+    ld_dtype = np.dtype(args.ld_dtype)
+    sizes_all = config_sizes(args.config, args.seed)
+    width = args.width or {"spike_slab": 1, "mixture": 4, "grid": 32}[args.model]
+
+    # ---- primary measurement -----------------------------------------------------------------------------
+    strong = world > 1 and args.scaling == "strong"
+    if strong:
+        parts = shard_blocks_lpt(sizes_all, world)
+        mine = parts[rank]
+        ld, ss, inp, m_total = build_workload(args, sizes_all, mine, args.seed, args.low_memory, ld_dtype)
+        total_snps = float(m_total)
     else:
-        total_snps = float(ld.m)
+        seed = args.seed + 1000 * rank                 # weak: every rank its own genome-scale workload
+        ld, ss, inp, _ = build_workload(args, sizes_all, None, seed, args.low_memory, ld_dtype)
+        total_snps = float(comm.allreduce_sum(np.array([float(ld.m)]))[0])
+    sw = Sweep(args, ld, ss, inp, device, args.model, width, args.low_memory)
+    elapsed = float(comm.allreduce_max(np.array([sw.run(args.steps, args.warmup, barrier)]))[0])
+    skipped = sw.plan.last_skipped()
+    k_ms = sw.plan.timing_history(which=1)
+    sweep_ms = sw.plan.timing_history(which=0)
+    es = ld_dtype.itemsize
+    nnz_streamed = int(ld.ld_indptr[-1]) * (2 if ld.low_memory else 1)   # upper form is read twice
+    # state bytes per SNP: index (12) + per model column 4 inputs + 5 state reads/writes + std_beta
+    state_bytes = STATE_BYTES_PER_SNP if args.model == "spike_slab" else (
+        12 + 4 + 4 * (3 * width + 1) + 8 * (2 * width + 3) if args.model == "mixture" else 12 + 4 + 36 * width)
+    algo_bytes = es * nnz_streamed + state_bytes * ld.m                   # this rank's share
+    k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
+    # per-rank kernel time and bytes -> node-level achieved bandwidth = all ranks' bytes / slowest rank's kernel time
+    per_rank = comm.allreduce_sum(np.array([float(algo_bytes)]))         # bytes of all ranks
+    k_max_ms = float(comm.allreduce_max(np.array([k_avg_ms]))[0])
+    achieved = float(per_rank[0]) / (k_max_ms * 1e-3) / 1e9
+    model_ms = float(comm.allreduce_max(np.array([rank_time_model(np.diff(ld.block_start), es) * 1e3]))[0])
 
-    skipped = plan.last_skipped()
-    k_ms = plan.timing_history(which=1)
-    sweep_ms = plan.timing_history(which=0)
+    # ---- secondary measurements -----------------------------------------------------------------------------
+    secondary = None
+    weak = None
+    if not args.no_secondary and args.model == "spike_slab":
+        half = max(5, args.steps // 2)
+        if world == 1 and not args.low_memory and args.config != "cfg1":
+            # the reference's DEFAULT LD form (low_memory=True, VIPRS.py:75): upper-triangular store + second pass
+            ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, ld_dtype)
+            sw_u = Sweep(args, ld_u, ss_u, inp_u, device, args.model, width, True)
+            el_u = sw_u.run(half, 3, barrier)
+            ku = sw_u.plan.timing_history(which=1)
+            bytes_u = es * int(ld_u.ld_indptr[-1]) * 2 + STATE_BYTES_PER_SNP * ld_u.m
+            secondary = {
+                "ld_form": "upper-triangular (low_memory=True, the reference's default)",
+                "value": ld_u.m * half / el_u, "unit": "SNP-updates/s", "ms_per_step": el_u / half * 1e3,
+                "kernel_ms_avg": float(np.mean(ku)), "kernel_ms_p50": pct(ku, 50),
+                "roofline_frac": bytes_u / (float(np.mean(ku)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": int(bytes_u), "steps": half,
+            }
+            sw_u.close()
+            del ld_u
+        if strong:
+            # weak scaling beside it: every rank sweeps a whole genome-scale workload of its own
+            sw.close()
+            ld_w, ss_w, inp_w, _ = build_workload(args, sizes_all, None, args.seed + 1000 * rank, args.low_memory, ld_dtype)
+            sw_w = Sweep(args, ld_w, ss_w, inp_w, device, args.model, width, args.low_memory)
+            el_w = float(comm.allreduce_max(np.array([sw_w.run(half, 3, barrier)]))[0])
+            tot_w = float(comm.allreduce_sum(np.array([float(ld_w.m)]))[0])
+            weak = {"value": tot_w * half / el_w, "unit": "SNP-updates/s", "ms_per_step": el_w / half * 1e3,
+                    "snps_per_gpu": int(ld_w.m), "steps": half,
+                    "note": "every rank its own 1.1 M-SNP workload (N x the work of `value`'s config)"}
+            sw_w.close()
 
     if rank == 0:
-        es = ld_dtype.itemsize
-        nnz_streamed = int(ld.ld_indptr[-1]) * (2 if ld.low_memory else 1)   # upper form is read twice
-        # state bytes per SNP: index (12) + per model column 4 inputs + 5 state reads/writes + std_beta
-        state_bytes = STATE_BYTES_PER_SNP if args.model == "spike_slab" else (
-            12 + 4 + 4 * (3 * width + 1) + 8 * (2 * width + 3) if args.model == "mixture" else 12 + 4 + 36 * width)
-        algo_bytes = es * nnz_streamed + state_bytes * ld.m
-        k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
-        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and world == 1:
             try:
                 key = f"{args.config}_{args.ld_dtype}_{'upper' if args.low_memory else 'sym'}"
                 if args.model != "spike_slab":
@@ -256,25 +386,32 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if n_gpus > 1 else "weak",
+            "scaling": ("strong" if strong else "weak") if n_gpus > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": {"cfg1": "configs[0]: single LD block, 500 SNPs",
                              "cfg2": "configs[1]: chr22-like, ~19k SNPs / 40 LD blocks",
-                             "cfg3": "configs[2]: genome-wide, ~1.1M SNPs / 1700 LD blocks"}[args.config]
+                             "cfg3": "configs[2]: genome-wide, ~1.1M SNPs / 1700 LD blocks",
+                             "cfg3max": "configs[2] with one 6 000-SNP block (BASELINE's clip limit)"}[args.config]
                             + {"spike_slab": ", spike-and-slab", "mixture": f", sparse mixture prior K={width} (configs[3])",
-                               "grid": f", grid of {width} (pi, sigma_eps) models batched per SNP (configs[4])"}[args.model]
-                            + ", AR(1) block LD",
+                               "grid": f", grid of {width} (sigma_eps x pi) models batched per SNP (configs[4])"}[args.model]
+                            + ", AR(1) block LD"
+                            + (f", ONE workload block-sharded over {n_gpus} GPUs" if strong else
+                               (f", one workload per GPU x {n_gpus}" if n_gpus > 1 else "")),
                 "prior": args.model, "prior_width": width,
                 "snp_x_grid_point_updates_per_s": total_snps * width * args.steps / elapsed if args.model == "grid" else None,
-                "snps_per_gpu": int(ld.m), "ld_blocks_per_gpu": int(len(sizes)),
-                "ld_entries_per_gpu": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype,
+                "snps_total": int(total_snps), "snps_rank0": int(ld.m), "ld_blocks_rank0": int(len(ld.block_start) - 1),
+                "ld_entries_rank0": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype,
+                "largest_block": int(np.max(sizes_all)),
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
-                "math_mode": args.math, "skipped_snps_last_sweep": int(skipped),
-                "parallelism": f"ld-blocks x{n_gpus} ({args.scaling})" if n_gpus > 1 else "single GPU",
+                "math_mode": args.math, "skipped_snps_last_sweep_rank0": int(skipped),
+                "parallelism": (f"ld-blocks x{n_gpus} (strong: chain-aware LPT, no data-path collective; RCCL barrier / max only)"
+                                if strong else f"one workload per GPU x{n_gpus}") if n_gpus > 1 else "single GPU",
                 "step": "device state re-init + one E-step sweep over all blocks",
+                "time_model_ms": model_ms,
+                "secondary": secondary,
             },
             "roofline": {
                 "bound": "hbm",
@@ -282,18 +419,24 @@ def main():
                            + (" + estep_grid_upper_epilogue_kernel" if ld.low_memory else "")) if args.model == "grid" else
                           ("estep_panel_kernel (3 size classes on 3 streams; the largest two share blocks between CUs)"
                            + (" + estep_upper_epilogue_kernel" if ld.low_memory else "")),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes),
-                "kernel_ms_avg": k_avg_ms, "sweep_ms_avg": float(np.mean(sweep_ms)) if sweep_ms else None,
+                "achieved": achieved, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n_gpus),
+                "traffic": traffic, "algorithmic_bytes_per_launch": int(per_rank[0]),
+                "kernel_ms_avg": k_max_ms, "kernel_ms_p10": pct(k_ms, 10), "kernel_ms_p50": pct(k_ms, 50),
+                "kernel_ms_p90": pct(k_ms, 90), "kernel_ms_max": float(np.max(k_ms)) if k_ms else None,
+                "sweep_ms_avg": float(np.mean(sweep_ms)) if sweep_ms else None,
+                "note": "achieved = algorithmic bytes of all ranks / slowest rank's mean kernel time (HIP events on the "
+                        "kernels' own streams); percentiles are rank 0's per-sweep kernel times",
             },
         }
+        if weak is not None:
+            out["weak_scaling"] = weak
         if n_gpus == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds, args.model, width, host_extra, pi0)
+            out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds, args.model, width, sw.host_extra, sw.pi0)
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.barrier()
+    if world > 1:
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -19,6 +19,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_RESTATED = os.path.join(_HERE, "liboracle.so")
 _LIB_REF = os.path.join(_HERE, "_ref", "libviprs_ref.so")
+# the same sources with -march=x86-64-v3 (AVX2 + FMA): bench.py's "optimistic CPU" line only, never the parity reference
+_LIB_REF_V3 = os.path.join(_HERE, "_ref", "libviprs_ref_v3.so")
 
 _TCODE = {np.dtype(np.float32): 0, np.dtype(np.float64): 1}
 _UCODE = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2,
@@ -32,8 +34,8 @@ def build(force=False):
         subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
 
 
-def have_reference():
-    return os.path.exists(_LIB_REF)
+def have_reference(kind="reference"):
+    return os.path.exists(_LIB_REF_V3 if kind == "reference_v3" else _LIB_REF)
 
 
 _libs = {}
@@ -41,7 +43,7 @@ _libs = {}
 
 def _lib(kind):
     if kind not in _libs:
-        path = _LIB_RESTATED if kind == "restated" else _LIB_REF
+        path = {"restated": _LIB_RESTATED, "reference": _LIB_REF, "reference_v3": _LIB_REF_V3}[kind]
         if not os.path.exists(path):
             build()
         _libs[kind] = ctypes.CDLL(path)
@@ -85,7 +87,7 @@ def cpp_e_step(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, e
         _check_vec(n, a, T)
     m = var_mu.shape[0]
     lib = _lib(kind)
-    if kind == "reference":
+    if kind != "restated":
         rc = lib.ref_e_step(t, u, i, ctypes.c_int(m), _p(ld_left_bound), _p(ld_indptr), _p(ld_data),
                             _p(std_beta), _p(var_gamma), _p(var_mu), _p(eta), _p(q), _p(eta_diff),
                             _p(u_logs), _p(sqrt_half_var_tau), _p(mu_mult), ctypes.c_double(dq_scale),
@@ -113,7 +115,7 @@ def cpp_e_step_mixture(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, v
         _check_vec(n, a, T, ndim=2, order="C")
     m, K = var_mu.shape
     lib = _lib(kind)
-    if kind == "reference":
+    if kind != "restated":
         rc = lib.ref_e_step_mixture(t, u, i, ctypes.c_int(m), ctypes.c_int(K), _p(ld_left_bound),
                                     _p(ld_indptr), _p(ld_data), _p(std_beta), _p(var_gamma),
                                     _p(var_mu), _p(eta), _p(q), _p(eta_diff), _p(log_null_pi),
@@ -146,7 +148,7 @@ def cpp_e_step_grid(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_
     active = np.ascontiguousarray(active_model_idx)  # int[:] may be strided in the reference
     m = var_mu.shape[0]
     lib = _lib(kind)
-    if kind == "reference":
+    if kind != "restated":
         rc = lib.ref_e_step_grid(t, u, i, ctypes.c_int(m), ctypes.c_int(active.shape[0]), _p(active),
                                  _p(ld_left_bound), _p(ld_indptr), _p(ld_data), _p(std_beta),
                                  _p(var_gamma), _p(var_mu), _p(eta), _p(q), _p(eta_diff), _p(u_logs),

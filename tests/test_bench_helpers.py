@@ -46,3 +46,59 @@ def test_cpu_baseline_leg(problem, model, width):
     assert r["value"] > 0 and r["single_thread_value"] > 0 and r["unit"] == "SNP-updates/s"
     assert r["kind"] == ("reference" if O.have_reference() else "port")
     assert f"model={model}" in r["sample"]
+
+
+def test_strong_scaling_shards_hold_the_same_numbers_as_the_whole_workload():
+    """bench.py --gpus N: the blocks of ONE workload are dealt to the ranks; a block's LD, summary statistics and
+    inputs are the same numbers whichever rank builds it (every random draw is made for the whole workload)."""
+    class A:
+        math = "exact"
+    sizes = np.array([40, 90, 33, 64, 120, 51, 77], dtype=np.int64)
+    ld, ss, inp, m = bench.build_workload(A, sizes, None, 11, False, np.dtype("float32"))
+    assert m == sizes.sum()
+    parts = bench.shard_blocks_lpt(sizes, 3)
+    assert sorted(b for p in parts for b in p) == list(range(len(sizes)))
+    for mine in parts:
+        ld_r, ss_r, inp_r, m_all = bench.build_workload(A, sizes, mine, 11, False, np.dtype("float32"))
+        assert m_all == m
+        idx = np.concatenate([np.arange(ld.block_start[b], ld.block_start[b + 1]) for b in mine])
+        for k in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+            np.testing.assert_array_equal(getattr(inp_r, k), getattr(inp, k)[idx])
+        # LD rows of the shard == the rows of the whole workload (symmetric form: a block's rows are its b x b entries)
+        off = 0
+        for b in mine:
+            s, e = int(ld.block_start[b]), int(ld.block_start[b + 1])
+            n = (e - s) ** 2
+            np.testing.assert_array_equal(ld_r.ld_data[off:off + n], ld.ld_data[int(ld.ld_indptr[s]):int(ld.ld_indptr[e])])
+            off += n
+
+
+def test_chain_aware_block_sharding():
+    from viprs_amd import parallel as P
+    sizes = syn.block_sizes("cfg3")
+    for world in (2, 4, 8):
+        owner = P.shard_blocks(sizes, world)
+        assert owner.shape == sizes.shape and set(owner) == set(range(world))
+        loads = np.array([P.block_cost(sizes[owner == r]).sum() for r in range(world)])
+        assert loads.max() / loads.mean() < 1.02                     # LPT over 1 700 blocks balances to ~1 %
+        # the largest blocks go to different ranks (their serial chains are each rank's floor)
+        top = np.argsort(-sizes)[:world]
+        assert len(set(owner[top])) == world
+    # small blocks cost their chain share, large blocks their bytes
+    assert P.block_cost(100) == pytest.approx(100 * P.CHAIN_STEP_S / P.CHAIN_SLOTS)
+    assert P.block_cost(4000) == pytest.approx(4000 * 4000 * 4 / P.HBM_STREAM_BYTES_PER_S)
+
+
+def test_block_shard_slices_ld_rows_into_a_local_numbering():
+    from viprs_amd.parallel import BlockShard
+    for low_memory in (False, True):
+        ld = syn.make_ld(np.array([5, 9, 4, 7]), low_memory=low_memory, seed=3)
+        sh = BlockShard(ld.block_start, [3, 1])
+        assert sh.m == 16 and list(sh.blocks) == [1, 3]
+        lb, ip, data = sh.slice_ld(ld.ld_left_bound, ld.ld_indptr, ld.ld_data)
+        ref = syn.make_ld(np.array([9, 7]), low_memory=low_memory, seed=3, rho=ld.rho[[1, 3]])
+        np.testing.assert_array_equal(lb, ref.ld_left_bound)
+        np.testing.assert_array_equal(ip, ref.ld_indptr)
+        np.testing.assert_array_equal(data, ref.ld_data)
+        full = np.arange(ld.m, dtype=np.float32)
+        np.testing.assert_array_equal(sh.scatter(sh.take(full), np.zeros(ld.m, np.float32))[sh.index], full[sh.index])

@@ -188,7 +188,7 @@ class VIPRS:
                 ds.upload("std_beta", cat([self.std_beta[c] for c in chroms], self._T))
                 ds.set_n_per_snp(cat([np.asarray(self.n_per_snp[c], dtype=np.float64).ravel() for c in chroms], np.float64))
                 ds.set_snp_weights(cat([np.full(self.shapes[c], 1.0 / self._all_shapes[c]) for c in chroms], np.float64))
-                if getattr(self.comm, "device_side", False) and world > 1:
+                if getattr(self.comm, "device_side", False):
                     ds.set_comm(self.comm)       # sums_begin / sums_end return the all-rank sums (RCCL, C ABI)
                     self._device_reduce = True
             else:

@@ -214,15 +214,17 @@ def make_problem(config="cfg1", low_memory=False, ld_dtype=np.float32, seed=SEED
     return ld, ss, inp
 
 
-def make_mixture_inputs(ss, K=4, float_precision=np.float32):
-    """Per-SNP inputs of `e_step_mixture` for a K-component sparse mixture prior (VIPRSMix.py:52,
-    :206-223): component variances d_k = 2^-(K-1) .. 1 around the spike-and-slab scale, C-order (m, K)."""
+def make_mixture_inputs(ss, K=4, float_precision=np.float32, pi=0.01, sigma_eps=0.8, h2=0.2):
+    """Per-SNP inputs of `e_step_mixture` for a K-component sparse mixture prior, C-order (m, K):
+    prior multipliers d = 2^linspace(-min(K-1, 7), 0, K) (VIPRSMix.py:52; K = 4: 2^-3 .. 1), mixing proportions
+    pi_k = pi * [.4, .3, .2, .1] for K = 4 (in general decreasing weights 2 (K - k) / (K (K + 1))), component
+    precisions tau_k = d_k M sum_k(pi_k / d_k) / h2 (VIPRSMix.py:126-128), inputs as VIPRSMix.py:181-223."""
     T = np.dtype(float_precision)
     m = ss.n_per_snp.shape[0]
     d = 2.0 ** np.linspace(-min(K - 1, 7), 0, K)
-    pis = np.full(K, 0.01 / K)
-    sigma_eps, h2 = 0.8, 0.2
-    tau = d * (m * pis.sum() / h2)
+    w = 2.0 * (K - np.arange(K)) / (K * (K + 1.0))           # K = 4: [.4, .3, .2, .1]
+    pis = pi * w
+    tau = d * (m * np.dot(1.0 / d, pis) / h2)
     n = np.asarray(ss.n_per_snp, dtype=np.float64)[:, None]
     var_tau = n / sigma_eps + tau[None, :]
     return dict(
@@ -233,13 +235,27 @@ def make_mixture_inputs(ss, K=4, float_precision=np.float32):
         pi=float(pis[0]))
 
 
+def grid_points(G=32, n_snps=1_100_000):
+    """The (sigma_epsilon, pi) grid of BASELINE configs[4]: the reference's own `HyperparameterGrid`
+    with h2 = 0.1 +- 0.1 -- G / 8 sigma_epsilon values (the slow axis of `itertools.product`,
+    HyperparameterGrid.py:110-166, :238-245) x 8 pi values (log-spaced, the fast axis, :184-208); G = 32: 4 x 8.
+    Returns (sigma_epsilon (G,), pi (G,))."""
+    from ..model.gridsearch.HyperparameterGrid import HyperparameterGrid
+    n_pi = 8 if G % 8 == 0 and G >= 8 else G
+    grid = HyperparameterGrid(sigma_epsilon_steps=G // n_pi, pi_steps=n_pi, h2_est=0.1, h2_se=0.1, n_snps=n_snps)
+    pts = grid.combine_grids()
+    assert len(pts) == G
+    return (np.array([p["sigma_epsilon"] for p in pts], dtype=np.float64),
+            np.array([p["pi"] for p in pts], dtype=np.float64))
+
+
 def make_grid_inputs(ss, G=32, float_precision=np.float32):
-    """Per-SNP inputs of `e_step_grid` for G (pi, sigma_epsilon) grid points, column-major (m, G)
-    (VIPRSGrid.py: one column per model)."""
+    """Per-SNP inputs of `e_step_grid` for the G grid points of `grid_points`, column-major (m, G) (VIPRSGrid.py:
+    one column per model); per model tau_beta = pi M / (1 - sigma_epsilon) (VIPRS.py:310), inputs as VIPRS.py:400-418
+    with half_var_tau in place of its square root (e_step.hpp:616)."""
     T = np.dtype(float_precision)
     m = ss.n_per_snp.shape[0]
-    pis = np.logspace(-3, -1, G)
-    sig = np.linspace(0.7, 0.95, G)
+    sig, pis = grid_points(G, m)
     tau = pis * m / (1 - sig)
     n = np.asarray(ss.n_per_snp, dtype=np.float64)[:, None]
     var_tau = n / sig[None, :] + tau[None, :]
