@@ -1,0 +1,194 @@
+"""CPU: the zarr-v2 / blosc-1 LD store reader (viprs_amd.io.zarr_ld) -- SURVEY 8(f-3), "LD ingestion without magenpy".
+
+PARITY UNPINNED: neither zarr / numcodecs / magenpy nor a sample store exist in the authoring image, so the reader is
+pinned by (i) round trips against the self-written encoder over every codec / shuffle / split / type-size combination,
+(ii) hand-assembled frames that follow the blosc-1 header layout byte by byte, and (iii) an end-to-end fit from a store
+against the same fit from arrays.
+"""
+import json
+import os
+import struct
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
+from viprs_amd.io import zarr_ld as Z
+from viprs_amd.utils import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.mark.parametrize("cname", ["lz4", "zstd", "zlib"])
+@pytest.mark.parametrize("shuffle", [0, 1, 2])
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("dtype", [np.int8, np.int16, np.float32, np.int64])
+def test_blosc_round_trip(cname, shuffle, split, dtype):
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 17, 127, 128, 1000, 40_001):
+        a = (rng.normal(0, 30, n)).astype(dtype)
+        for blocksize in (None, 512, 4096):
+            frame = Z.blosc_compress(a.tobytes(), a.dtype.itemsize, cname, 3, shuffle, blocksize, split)
+            back = np.frombuffer(Z.blosc_decompress(frame), dtype=dtype)
+            np.testing.assert_array_equal(back, a)
+            # header fields as c-blosc lays them out
+            ver, _, flags, ts, nbytes, _, cbytes = struct.unpack_from("<BBBBIII", frame, 0)
+            assert (ver, ts, nbytes, cbytes) == (2, a.dtype.itemsize, a.nbytes, len(frame))
+
+
+def test_hand_assembled_frames():
+    """Frames written out byte by byte from the format description (not through the encoder)."""
+    payload = bytes(range(200)) * 3
+    # (a) memcpy'ed frame: header + raw bytes
+    f = struct.pack("<BBBBIII", 2, 1, 0x2, 1, len(payload), len(payload), 16 + len(payload)) + payload
+    assert Z.blosc_decompress(f) == payload
+    # (b) one zlib block, don't-split, no shuffle: header | bstarts[1] | int32 cbytes | stream
+    comp = zlib.compress(payload)
+    f = (struct.pack("<BBBBIII", 2, 1, (3 << 5) | 0x10, 4, len(payload), len(payload), 16 + 4 + 4 + len(comp))
+         + struct.pack("<i", 20) + struct.pack("<i", len(comp)) + comp)
+    assert Z.blosc_decompress(f) == payload
+    # (c) byte-shuffled 4-byte elements, two blocks (second one a leftover block), streams stored raw
+    a = np.arange(300, dtype="<u4")
+    raw = a.tobytes()
+    bs = 1024
+    blk0 = np.frombuffer(raw[:bs], np.uint8).reshape(bs // 4, 4).T.tobytes()         # shuffled: byte planes
+    blk1 = np.frombuffer(raw[bs:], np.uint8).reshape((len(raw) - bs) // 4, 4).T.tobytes()
+    body0 = struct.pack("<i", len(blk0)) + blk0                                     # cbytes == neblock: stored raw
+    body1 = struct.pack("<i", len(blk1)) + blk1
+    off0 = 16 + 8
+    f = (struct.pack("<BBBBIII", 2, 1, (1 << 5) | 0x10 | 0x1, 4, len(raw), bs, off0 + len(body0) + len(body1))
+         + struct.pack("<ii", off0, off0 + len(body0)) + body0 + body1)
+    np.testing.assert_array_equal(np.frombuffer(Z.blosc_decompress(f), "<u4"), a)
+    with pytest.raises(NotImplementedError, match="blosclz"):
+        Z.blosc_decompress(struct.pack("<BBBBIII", 2, 1, 0x10, 1, 200, 200, 16 + 4 + 4 + 8) + struct.pack("<ii", 20, 8) + b"x" * 8)
+    with pytest.raises(ValueError):
+        Z.blosc_decompress(b"\x02\x01")
+
+
+def test_zarr_array_partial_reads_and_missing_chunks(tmp_path):
+    a = np.arange(10_000, dtype=np.int16) - 5000
+    p = str(tmp_path / "arr")
+    Z.write_zarr_array(p, a, chunks=777, cname="lz4")
+    z = Z.ZarrArray(p)
+    assert z.shape == (10_000,) and z.dtype == np.int16 and len(os.listdir(p)) == 1 + 13
+    np.testing.assert_array_equal(z.read(), a)
+    for lo, hi in ((0, 1), (776, 778), (1554, 9999), (9999, 10_000), (5, 5)):
+        np.testing.assert_array_equal(z.read(lo, hi), a[lo:hi])
+    os.remove(os.path.join(p, "3"))                                  # a missing chunk reads as fill_value
+    b = a.copy(); b[3 * 777:4 * 777] = 0
+    np.testing.assert_array_equal(z.read(), b)
+    # uncompressed chunks and the '/' separator
+    q = str(tmp_path / "raw")
+    os.makedirs(q)
+    json.dump({"zarr_format": 2, "shape": [5], "chunks": [4], "dtype": "<f4", "fill_value": 0, "order": "C",
+               "filters": None, "compressor": None, "dimension_separator": "/"}, open(os.path.join(q, ".zarray"), "w"))
+    np.array([1, 2, 3, 4], "<f4").tofile(os.path.join(q, "0"))
+    np.array([5, 0, 0, 0], "<f4").tofile(os.path.join(q, "1"))
+    np.testing.assert_array_equal(Z.ZarrArray(q).read(), np.array([1, 2, 3, 4, 5], np.float32))
+
+
+def _store(tmp_path, sizes, seed, name, dtype=np.int8, **kw):
+    up = syn.make_ld(sizes, low_memory=True, ld_dtype=dtype, seed=seed)
+    path = str(tmp_path / name)
+    Z.write_ld_store(path, up.ld_indptr, up.ld_data, attrs={"Chromosome": int(name.split("_")[-1]), "Sample size": 1000,
+                                                            "LD estimator": "block"},
+                     chunks=5000, metadata={"bp": np.arange(up.m, dtype=np.int32)}, **kw)
+    return up, path
+
+
+def test_ld_store_round_trip_and_loader_surface(tmp_path):
+    up, path = _store(tmp_path, [40, 90, 33], 11, "chr_22")
+    m = Z.ZarrLDMatrix(path)
+    assert m.n_snps == up.m and m.stored_dtype == np.int8 and m.chromosome == 22 and m.ld_estimator == "block"
+    lo = m.load(return_symmetric=False, dtype=np.int8)               # dequantize_on_the_fly: as stored
+    np.testing.assert_array_equal(lo.ld_data, up.ld_data)
+    np.testing.assert_array_equal(lo.ld_indptr, up.ld_indptr)
+    np.testing.assert_array_equal(lo.leftmost_idx, up.ld_left_bound)
+    f = m.load(return_symmetric=False, dtype=np.float32)             # dequantised at load time
+    np.testing.assert_allclose(f.ld_data, up.ld_data.astype(np.float32) / 127.0, rtol=1e-7)
+    with pytest.raises(ValueError, match="upper-triangular"):
+        m.load(return_symmetric=True)
+    lb, ip, data = m.load_rows(40, 130)                              # the second block only
+    np.testing.assert_array_equal(data, up.ld_data[int(up.ld_indptr[40]):int(up.ld_indptr[130])])
+    np.testing.assert_array_equal(ip, up.ld_indptr[40:131] - up.ld_indptr[40])
+    np.testing.assert_array_equal(m.metadata("bp"), np.arange(up.m))
+    assert m.get_lambda_min() == 0.0
+    found = Z.find_ld_stores(str(tmp_path))
+    assert list(found) == [22] and found[22].n_snps == up.m
+
+
+def _loaders(tmp_path, chrom_sizes, seed=31):
+    stores, arrays, ss = {}, {}, {}
+    for ci, (c, sizes) in enumerate(chrom_sizes.items()):
+        up, path = _store(tmp_path, sizes, seed + ci, f"chr_{c}", cname="zstd" if ci % 2 else "lz4")
+        sym = syn.make_ld(sizes, low_memory=False, ld_dtype=np.int8, seed=seed + ci)
+        s = syn.make_sumstats(sym, seed=seed + ci)
+        stores[c] = Z.ZarrLDMatrix(path)
+        arrays[c] = LDArrays(symmetric=(sym.ld_left_bound, sym.ld_indptr, sym.ld_data),
+                             upper=(up.ld_left_bound, up.ld_indptr, up.ld_data), stored_dtype=np.int8, dq_scale=1 / 127.0)
+        ss[c] = SumstatsArrays(s.std_beta, s.n_per_snp)
+    return ArrayDataLoader(stores, ss), ArrayDataLoader(arrays, ss)
+
+
+@pytest.mark.parametrize("low_memory", [True, False])
+def test_fit_from_a_store_equals_fit_from_arrays(tmp_path, low_memory):
+    """VIPRS on ZarrLDMatrix stores (int8, dequantised on the fly) against the same model on in-memory arrays; with
+    low_memory=False the store only has the upper-triangular form and the symmetric rows are mirrored from it."""
+    from viprs_amd.model import VIPRS
+    g_store, g_arr = _loaders(tmp_path, {1: [60, 130, 45], 2: [80, 70]})
+    theta = {"pi": 0.02, "sigma_epsilon": 0.85}
+    kw = dict(low_memory=low_memory, dequantize_on_the_fly=True, e_step_fn=O.cpp_e_step)
+    a = VIPRS(g_arr, **kw).fit(max_iter=12, theta_0=dict(theta))
+    b = VIPRS(g_store, **kw).fit(max_iter=12, theta_0=dict(theta))
+    np.testing.assert_array_equal(a.history["ELBO"], b.history["ELBO"])
+    for c in a.chromosomes:
+        np.testing.assert_array_equal(a.pip[c], b.pip[c])
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch.distributed as dist
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+from oracle import oracle as O
+from tests.test_zarr_ld import _loaders
+from viprs_amd.model import VIPRS
+from viprs_amd.parallel import TorchDistComm
+import pathlib
+g_store, g_arr = _loaders(pathlib.Path({tmp!r}) / ("r" + sys.argv[1]), {{1: [60, 130, 45], 2: [80, 70]}})
+reads = []
+for m in g_store.get_ld_matrices().values():
+    orig = m._data.read
+    m._data.read = (lambda o: (lambda lo=0, hi=None: (reads.append((lo, hi)), o(lo, hi))[1]))(orig)
+theta = {{"pi": 0.02, "sigma_epsilon": 0.85}}
+kw = dict(low_memory=True, dequantize_on_the_fly=True, e_step_fn=O.cpp_e_step)
+single = VIPRS(g_arr, **kw).fit(max_iter=12, theta_0=dict(theta))
+sharded = VIPRS(g_store, comm=TorchDistComm(), **kw).fit(max_iter=12, theta_0=dict(theta))
+np.testing.assert_allclose(sharded.history["ELBO"], single.history["ELBO"], rtol=2e-7)   # the sums change their order
+for c in single.chromosomes:
+    np.testing.assert_allclose(sharded.pip[c], single.pip[c], rtol=2e-3, atol=2e-6)
+# only the rows of this rank's blocks were read from the stores (never a whole `data` array)
+assert reads and all(hi is not None for lo, hi in reads)
+assert sum(hi - lo for lo, hi in reads) < sum(int(m.indptr()[-1]) for m in g_store.get_ld_matrices().values())
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", sys.argv[1])
+"""
+
+
+def test_two_rank_fit_reads_only_its_blocks_from_the_store(tmp_path):
+    script = tmp_path / "worker.py"
+    port = 31500 + (os.getpid() % 1000)
+    script.write_text(_WORKER.format(root=ROOT, port=port, tmp=str(tmp_path)))
+    for r in range(2):
+        os.makedirs(tmp_path / f"r{r}")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]

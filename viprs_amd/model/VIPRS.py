@@ -98,17 +98,26 @@ class VIPRS:
                 dtype = float_precision
                 dequantize_on_the_fly = False
             expand = bool(expand_ld_on_device) and not low_memory
-            if not expand:
-                try:
-                    lop = ld_mat.load(return_symmetric=not low_memory, dtype=dtype)
-                except ValueError:
-                    if low_memory or expand_ld_on_device is False:
-                        raise
-                    expand = True
-            if expand:
-                lop = ld_mat.load(return_symmetric=False, dtype=dtype)
-                self._expanded = True
-            loaded[c] = (lop.ld_data, lop.ld_indptr, lop.leftmost_idx)
+            # a store that can hand out row ranges (viprs_amd.io.zarr_ld.ZarrLDMatrix): with several ranks only the
+            # index is read here, the LD entries of this rank's blocks after the blocks have been dealt out
+            lazy = world > 1 and hasattr(ld_mat, "load_rows") and (low_memory or expand_ld_on_device is not False)
+            if lazy:
+                expand = not low_memory
+                self._expanded = self._expanded or expand
+                loaded[c] = (None, np.asarray(ld_mat.indptr()), np.arange(1, self._all_shapes[c] + 1, dtype=np.int32),
+                             ld_mat, dtype)
+            else:
+                if not expand:
+                    try:
+                        lop = ld_mat.load(return_symmetric=not low_memory, dtype=dtype)
+                    except ValueError:
+                        if low_memory or expand_ld_on_device is False:
+                            raise
+                        expand = True
+                if expand:
+                    lop = ld_mat.load(return_symmetric=False, dtype=dtype)
+                    self._expanded = True
+                loaded[c] = (lop.ld_data, lop.ld_indptr, lop.leftmost_idx, None, dtype)
             if lambda_min is None:
                 self.lambda_min = 0.0
             elif _is_numeric(lambda_min):
@@ -123,7 +132,7 @@ class VIPRS:
             starts = {c: plan_blocks(np.ascontiguousarray(loaded[c][2], dtype=np.int32), loaded[c][1], upper_form)[0]
                       for c in all_chroms}
             sizes = np.concatenate([np.diff(starts[c]) for c in all_chroms])
-            es = np.dtype(loaded[all_chroms[0]][0].dtype).itemsize
+            es = np.dtype(loaded[all_chroms[0]][4]).itemsize
             owner = shard_blocks(sizes, world, es)
             k = 0
             for c in all_chroms:
@@ -134,7 +143,7 @@ class VIPRS:
         self.shapes = {}
         self.n_per_snp, self.std_beta = {}, {}
         for c in all_chroms:
-            data, ip, lb = loaded.pop(c)
+            data, ip, lb, lazy_mat, dtype = loaded.pop(c)
             sh = self._shard.get(c)
             if sh is None:
                 self.shapes[c] = int(self._all_shapes[c])
@@ -143,8 +152,11 @@ class VIPRS:
                 self.std_beta[c] = gdl.sumstats_table[c].get_snp_pseudo_corr().astype(self._T)
             elif sh.m > 0:
                 self.shapes[c] = sh.m
-                self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c] = sh.slice_ld(
-                    np.asarray(lb), np.asarray(ip), data)
+                if lazy_mat is not None:
+                    self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c] = sh.read_ld(lazy_mat, dtype)
+                else:
+                    self.ld_left_bound[c], self.ld_indptr[c], self.ld_data[c] = sh.slice_ld(
+                        np.asarray(lb), np.asarray(ip), data)
                 self.n_per_snp[c] = sh.take(gdl.sumstats_table[c].n_per_snp)
                 self.std_beta[c] = sh.take(gdl.sumstats_table[c].get_snp_pseudo_corr()).astype(self._T)
             del data

@@ -100,6 +100,22 @@ class BlockShard:
         ip = np.concatenate([[0], np.cumsum(np.concatenate(len_parts))]).astype(ld_indptr.dtype)
         return lb, ip, np.ascontiguousarray(np.concatenate(data_parts))
 
+    def read_ld(self, ld_mat, dtype=None):
+        """The same from a store that reads row ranges (`load_rows(start, stop, dtype)` ->
+        (leftmost_idx, indptr re-based to 0, data)): only this rank's LD entries leave the disk."""
+        lb_parts, len_parts, data_parts = [], [], []
+        off = 0
+        for b in self.blocks:
+            s, e = int(self.block_start[b]), int(self.block_start[b + 1])
+            lb, ip, data = ld_mat.load_rows(s, e, dtype)
+            lb_parts.append(np.asarray(lb, dtype=np.int64) - s + off)
+            len_parts.append(np.diff(ip).astype(np.int64))
+            data_parts.append(data)
+            off += e - s
+        lb = np.concatenate(lb_parts).astype(np.int32)
+        ip = np.concatenate([[0], np.cumsum(np.concatenate(len_parts))]).astype(np.int64)
+        return lb, ip, np.ascontiguousarray(np.concatenate(data_parts))
+
 
 # ---- communicators ------------------------------------------------------------------------------------
 class LocalComm:
