@@ -1,0 +1,39 @@
+"""Schedule-parameter sweep on the headline workload (cfg3, fp32, symmetric): team sizes, class limits, resident
+workgroups per CU, admission factor.  One process, one host copy of the workload; every configuration builds its own
+plan (the environment switches are read at plan creation / launch).  Prints median / p10 / p90 kernel ms of 30 sweeps.
+    python tools/sched_sweep.py [upper] [int8]"""
+import itertools, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from viprs_amd.plan import DeviceState, LDPlan
+from viprs_amd.utils import synthetic as syn
+
+upper = "upper" in sys.argv
+dt = np.int8 if "int8" in sys.argv else np.float32
+ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
+CONFIGS = [dict()]
+for t0, t1 in (("8", "1"), ("6", "1"), ("6", "2"), ("4", "1"), ("12", "2"), ("16", "2")):
+    CONFIGS.append(dict(VIPRS_TEAM0=t0, VIPRS_TEAM1=t1))
+for lg, md in (("2304", "1600"), ("1920", "1280"), ("3000", "1600"), ("2304", "1024")):
+    CONFIGS.append(dict(VIPRS_LARGE_BLOCK=lg, VIPRS_MEDIUM_BLOCK=md))
+for bm in ("0", "2", "4"):
+    CONFIGS.append(dict(VIPRS_BOTTOM_MOD=bm))
+KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_HELPERS", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK", "VIPRS_ADMIT_FACTOR")
+for cfg in CONFIGS:
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(cfg)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper)
+    ds = DeviceState(plan)
+    ds.upload("std_beta", inp.std_beta)
+    for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"):
+        ds.upload(k, getattr(inp, k))
+    for _ in range(5):
+        ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
+    ds.synchronize(); plan.timing_reset()
+    for _ in range(30):
+        ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
+    ds.synchronize()
+    t = np.array(plan.timing_history(which=1))
+    print(f"{str(cfg):110s} kernel ms p50 {np.median(t):.3f}  p10 {np.percentile(t, 10):.3f}  p90 {np.percentile(t, 90):.3f}", flush=True)
+    ds.close(); plan.close()

@@ -32,7 +32,8 @@ __device__ __forceinline__ float expf_lane(float x, const ExpTab& tab, int sel_l
     const double z = InvLn2N * xd;
     const double kd = rint(z);
     const double r = fma(InvLn2N, xd, -kd);
-    const int ki = (int)kd;
+    int ki = (int)kd;
+    asm volatile("" : "+v"(ki));                              // (per-lane convert, then ONE readlane: hipcc would read kd's two words)
     const int sidx = __builtin_amdgcn_readlane(ki, sel_lane);
     int tlo = __builtin_amdgcn_readlane(tab.lo, sidx);
     int thi = __builtin_amdgcn_readlane(tab.hi, sidx);
@@ -40,8 +41,26 @@ __device__ __forceinline__ float expf_lane(float x, const ExpTab& tab, int sel_l
     const uint64_t t = ((uint64_t)(uint32_t)thi << 32) | (uint32_t)tlo;
     return expf_glibc_finish(r, t);
 }
+__device__ __forceinline__ float expf_lane_shift(float x, const ExpTab& tab, int sel_lane) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+    const double Shift = 0x1.8p52;
+    const double xd = (double)fmaxf(x, -104.0f);
+    const double z = InvLn2N * xd;
+    double kd = z + Shift;
+    int ki = (int)(uint32_t)(uint64_t)__double_as_longlong(kd);
+    kd = kd - Shift;
+    const double r = fma(InvLn2N, xd, -kd);
+    asm volatile("" : "+v"(ki));
+    const int sidx = __builtin_amdgcn_readlane(ki, sel_lane);
+    int tlo = __builtin_amdgcn_readlane(tab.lo, sidx);
+    int thi = __builtin_amdgcn_readlane(tab.hi, sidx);
+    thi += (int)((unsigned)sidx << 15);
+    const uint64_t t = ((uint64_t)(uint32_t)thi << 32) | (uint32_t)tlo;
+    return expf_glibc_finish(r, t);
+}
+template <bool SHIFT = false>
 __device__ __forceinline__ float sigmoid_new(float x, const ExpTab& tab, int sel_lane) {
-    const float e = expf_lane(-fabsf(x), tab, sel_lane);
+    const float e = SHIFT ? expf_lane_shift(-fabsf(x), tab, sel_lane) : expf_lane(-fabsf(x), tab, sel_lane);
     const double ed = (double)e;
     const double den = 1.0 + ed;
     const double num = (x < 0.0f) ? ed : 1.0;
@@ -59,6 +78,7 @@ struct In { float mm, beta, sv, ulog, eta_old; };
 // V = 1 new: sigmoid_new, scalar skip test, next step fed from the un-selected fma result, SGPR lane mask, rows from LDS
 // V = 2 as 1 with the shipped global prefetch
 // V = 3 as 1 with the VALU skip test
+// V = 5 as 3 with glibc's shift trick for the table index and no multiply by dq (valid for dq == 1 only)
 // V = 4 as 1 without the own-lane bookkeeping (q capture, diagonal subtraction): lower bound, NOT the same result
 template <int V>
 __global__ __launch_bounds__(64) void chain(const float* __restrict__ tile_g, const In* __restrict__ ins, float* __restrict__ out,
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(64) void chain(const float* __restrict__ tile_g, co
                     avec = sel(avec, sa, mask);
                     qf = __builtin_fmaf(drow[jj], sa, qc);
                     qc = sel(qf, qf - sdz, mask);
-                    asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(mask));
+                    asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(mask) : : "scc");
                 }
             }
         } else {
@@ -134,14 +154,14 @@ __global__ __launch_bounds__(64) void chain(const float* __restrict__ tile_g, co
                 const float mu = __builtin_fmaf(in.mm, in.beta, -p_);
                 const float u = in.sv * mu;
                 const float x = __builtin_fmaf(u, u, in.ulog);
-                const float gamma = sigmoid_new(x, tab, jj);
+                const float gamma = (V == 5) ? sigmoid_new<true>(x, tab, jj) : sigmoid_new<false>(x, tab, jj);
                 const float d = __builtin_fmaf(gamma, mu, -in.eta_old);
                 float sa, sdz;
-                if (V == 3) {
+                if (V == 3 || V == 5) {
                     const bool upd = !(fabsf(d) < kEps);
                     const float dz = upd ? d : 0.0f;
                     sdz = rlf(dz, jj);
-                    sa = dq * sdz;
+                    sa = (V == 5) ? sdz : dq * sdz;          // V = 5: dq == 1 (fp32 LD), the multiply by 1 is dropped
                 } else {
                     const int sd = __builtin_amdgcn_readlane(__float_as_int(d), jj);
                     const bool upd = (unsigned)(sd & 0x7fffffff) >= 0x34000000u;
@@ -155,7 +175,7 @@ __global__ __launch_bounds__(64) void chain(const float* __restrict__ tile_g, co
                 qf = __builtin_fmaf(drow, sa, qc);
                 if (V != 4) {
                     qc = sel(qf, qf - sdz, mask);
-                    asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(mask));
+                    asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(mask) : : "scc");
                 } else {
                     qc = qf;
                 }
@@ -206,7 +226,7 @@ int main(int argc, char** argv) {
             printf("dq=%.4f variant %d: %.1f ns per chain step   (bitwise differences from variant 0: %d of 192)\n", dq, V, \
                    w * 10.0 / panels / kP, bad);                                                                    \
         }
-        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4)
+        RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
     }
     return 0;
 }

@@ -91,7 +91,7 @@ int run_spike_slab(viprs_state* S, double dq) {
     {
         const int64_t ng = P->n_granule_rows * kPanel;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
-        sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, ng);
+        sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, kPlanCounters, P->d_skipped.p, P->d_granules.p, ng);
         HIP_TRY(hipGetLastError());
     }
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
@@ -131,7 +131,7 @@ static int sweep_prologue(viprs_plan* P, int n_models = 1) {
         HIP_TRY(P->d_granules.alloc((size_t)ng));
     }
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
-    sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, 16, P->d_skipped.p, P->d_granules.p, ng);
+    sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, kPlanCounters, P->d_skipped.p, P->d_granules.p, ng);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
 }

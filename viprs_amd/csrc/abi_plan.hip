@@ -107,12 +107,18 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     const size_t es = ld_elem_size(ld_dtype);
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
+    // environment switches, re-read at every plan creation
     if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
-    if (const char* f = getenv("VIPRS_LARGE_BLOCK")) sched_config().large_block = atoi(f);
-    if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) sched_config().medium_block = atoi(f);
     if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
-    if (const char* f = getenv("VIPRS_TEAM0")) { sched_config().class_team[0] = std::max(1, atoi(f)); sched_config().team_env = true; }
-    if (const char* f = getenv("VIPRS_TEAM1")) { sched_config().class_team[1] = std::max(1, atoi(f)); sched_config().team_env = true; }
+    {
+        SchedConfig c;                          // defaults
+        if (const char* f = getenv("VIPRS_LARGE_BLOCK")) c.large_block = atoi(f);
+        if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) c.medium_block = atoi(f);
+        if (const char* f = getenv("VIPRS_TEAM0")) { c.class_team[0] = std::max(1, atoi(f)); c.team_env = true; }
+        if (const char* f = getenv("VIPRS_TEAM1")) { c.class_team[1] = std::max(1, atoi(f)); c.team_env = true; }
+        if (const char* f = getenv("VIPRS_BOTTOM_MOD")) c.bottom_mod = std::max(0, atoi(f));
+        sched_config() = c;
+    }
     P->low_memory = low_memory != 0;
     P->ld_dtype = ld_dtype;
     P->device = device;
@@ -220,7 +226,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     }
 
     // ---- upload -------------------------------------------------------------------------------
-    HIP_TRY(P->d_counters.alloc(16));
+    HIP_TRY(P->d_counters.alloc(kPlanCounters));
     HIP_TRY(P->d_error.alloc(1));
     HIP_TRY(hipMemset(P->d_error.p, 0, sizeof(int32_t)));
     HIP_TRY(P->d_skipped.alloc(1));

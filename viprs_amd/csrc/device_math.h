@@ -61,49 +61,49 @@ __device__ __forceinline__ float expf_glibc_finish(double r, uint64_t t) {
 enum { kLookupPerLane = 0, kLookupLane = 1 };
 
 // x <= 0 is all the E-step needs (sigmoid / softmax arguments are -|x| or u - max(u)).
+// glibc returns 0 (__math_uflowf) below -0x1.9fe368p6 = -103.97; here the argument is clamped to -104, where the
+// double result 2^-150.04 rounds to 0.0f by itself (it is below half the smallest denormal) -- no select, and no
+// out-of-range table index either.  tools/ubench/sigmoid_variants.hip holds the exhaustive bit-check of this and of
+// the divide below over all 2^32 inputs of the sigmoid.
 template <int LOOKUP>
 __device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab, int sel = 0) {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32;
-    // glibc returns 0 (__math_uflowf) below -0x1.9fe368p6; branch-free here because the per-lane
-    // flavour's ds_bpermute needs every lane of the wave active (inactive source lanes read as 0)
-    const bool uflow = x < -104.0f;
-    const double xd = (double)(uflow ? -104.0f : x);
+    const double xd = (double)fmaxf(x, -104.0f);
     const double z = InvLn2N * xd;
     const double kd = rint(z);                 // == (z + 0x1.8p52) - 0x1.8p52 in round-to-nearest
     const double r = fma(InvLn2N, xd, -kd);
-    const int ki = (int)kd;                    // |kd| < 2^13
-    const int idx = ki & 31;
+    int ki = (int)kd;                          // |kd| < 2^13
     int tlo, thi;
     if (LOOKUP == kLookupLane) {
-        const int sidx = __builtin_amdgcn_readlane(idx, sel);
-        tlo = __builtin_amdgcn_readlane(tab.lo, sidx);
-        thi = __builtin_amdgcn_readlane(tab.hi, sidx);
+        // only lane `sel` matters: its k is read once (v_readlane uses the low 6 bits of the lane select, and lanes
+        // l and l + 32 hold the same table entry: no mask), the table words and the exponent shift are scalar
+        asm volatile("" : "+v"(ki));           // (a per-lane convert and ONE v_readlane: hipcc would read kd's two words)
+        const int sk = __builtin_amdgcn_readlane(ki, sel);
+        tlo = __builtin_amdgcn_readlane(tab.lo, sk);
+        thi = __builtin_amdgcn_readlane(tab.hi, sk) + (int)((unsigned)sk << 15);
     } else {
-        tlo = __builtin_amdgcn_ds_bpermute(idx << 2, tab.lo);
-        thi = __builtin_amdgcn_ds_bpermute(idx << 2, tab.hi);
+        tlo = __builtin_amdgcn_ds_bpermute(ki << 2, tab.lo);      // (ds_bpermute takes address bits 7:2)
+        thi = __builtin_amdgcn_ds_bpermute(ki << 2, tab.hi) + (int)((unsigned)ki << 15);
     }
     // t = tab + (ki << 47): only the high word changes (ki << 15), two's complement wraps as
     // the 64-bit add in glibc does (tab low word is untouched: 47 >= 32).
-    thi += (int)((unsigned)ki << 15);
     const uint64_t t = ((uint64_t)(uint32_t)thi << 32) | (uint32_t)tlo;
-    const float y = expf_glibc_finish(r, t);
-    return uflow ? 0.0f : y;
+    return expf_glibc_finish(r, t);
 }
 
 // ---------------------------------------------------------------------------------------------
 // sigmoid<T> (e_step.hpp:245-261).  With T = float the literal `1.` there is a double, so the add
 // and the divide happen in double and the quotient is rounded to float once.
 // ---------------------------------------------------------------------------------------------
-// num / den for den in [1, 2], 0 <= num <= 1: the Newton-Raphson sequence hipcc itself emits for
-// an IEEE double divide (v_rcp_f64, two refinement steps, one residual correction) without the
-// v_div_scale / v_div_fmas / v_div_fixup instructions, which only rescale operands near the
-// exponent limits and patch inf/nan/0 -- none of which can occur for these ranges, so the quotient
-// is the same correctly rounded double.  (viprs_selftest checks it against `/` on the device.)
+// num / den for den in [1, 2], 0 <= num <= 1, rounded to float by the caller: v_rcp_f64 (2^-23 relative), ONE
+// Newton step (2^-46), the quotient and one residual correction -- the double quotient is the IEEE one except in
+// ties that never decide the float rounding: over all 2^32 arguments of the sigmoid the float result equals
+// (float)(num / den) bit for bit (0 mismatches; with the raw reciprocal and one correction: 1 025).  No
+// v_div_scale / v_div_fmas / v_div_fixup: they only rescale operands near the exponent limits and patch
+// inf / nan / 0, none of which can occur for these ranges.
 __device__ __forceinline__ double div_unit_range(double num, double den) {
     double r = __builtin_amdgcn_rcp(den);
-    double e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-den, r, 1.0);
+    const double e = __builtin_fma(-den, r, 1.0);
     r = __builtin_fma(r, e, r);
     const double q0 = num * r;
     const double rem = __builtin_fma(-den, q0, num);
@@ -113,8 +113,9 @@ __device__ __forceinline__ double div_unit_range(double num, double den) {
 template <int LOOKUP>
 __device__ __forceinline__ float sigmoid_exact(float x, const ExpTab& tab, int sel = 0) {
     const float e = expf_glibc_nonpos<LOOKUP>(-fabsf(x), tab, sel);
-    const float numf = (x < 0.0f) ? e : 1.0f;
-    return (float)div_unit_range((double)numf, 1.0 + (double)e);
+    const double ed = (double)e;
+    const double num = (x < 0.0f) ? ed : 1.0;
+    return (float)div_unit_range(num, 1.0 + ed);
 }
 
 // Hardware-transcendental variant (VIPRS_MATH_FAST): v_exp_f32 with a compensated x*log2(e)

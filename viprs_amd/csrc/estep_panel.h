@@ -30,7 +30,7 @@
 #include "kernels_common.h"
 
 #ifndef PANEL_MIN_WAVES
-#define PANEL_MIN_WAVES 1      // waves per SIMD the panel kernel is compiled for (register budget 512 / n)
+#define PANEL_MIN_WAVES 2      // waves per SIMD the panel kernel is compiled for (register budget 512 / n): two workgroups per CU
 #endif
 
 namespace viprs {
@@ -118,6 +118,13 @@ template <int N> __device__ __forceinline__ float dpp_max_shr(float x) {
     return r;
 }
 
+// r = mask[lane] ? b : a with the lane mask in an SGPR pair (one v_cndmask, no per-step v_cmp)
+__device__ __forceinline__ float sel_mask(float a, float b, unsigned long long m) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+
 __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -153,7 +160,10 @@ template <typename U, int CPL> __device__ __forceinline__ RawRow<U, CPL> load_ra
 template <typename U> __host__ __device__ constexpr int panel_cols() { return sizeof(U) == 4 ? 4 : 8; }
 
 constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
-constexpr int kStripRowsInFlight = 16;   // row loads in flight per updater lane (16 x 16 B for every LD type)
+#ifndef PANEL_STRIP_DEPTH
+#define PANEL_STRIP_DEPTH 16
+#endif
+constexpr int kStripRowsInFlight = PANEL_STRIP_DEPTH;   // row loads in flight per updater lane (x 16 B for every LD type)
 
 
 // Trailing update of one strip (64 * CPL columns) by one wave: q[c..c+CPL-1] = fma(R[row][c..], a_row, .)
@@ -220,10 +230,17 @@ struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
         in.eta_old = live ? A.eta[j] : 0.0f;
         return in;
     }
+    static constexpr bool kHasSkip = true;     // e_step.hpp:410-413
+    // d = new eta - old eta of the lane's SNP from the current q (no skip handling)
+    template <int LOOKUP>
+    static __device__ __forceinline__ float delta(const In& in, float q, const ExpTab& tab, int sel) {
+        float mu, gamma, d;
+        snp_update<EXACT, LOOKUP>(in.mm, in.beta, in.sv, in.ulog, in.eta_old, q, tab, mu, gamma, d, sel);
+        return d;
+    }
     template <int LOOKUP>
     static __device__ __forceinline__ bool update(const In& in, float q, const ExpTab& tab, float& d, int sel) {
-        float mu, gamma;
-        snp_update<EXACT, LOOKUP>(in.mm, in.beta, in.sv, in.ulog, in.eta_old, q, tab, mu, gamma, d, sel);
+        d = delta<LOOKUP>(in, q, tab, sel);
         return !(fabsf(d) < Eps<float>::value);                       // :410
     }
     template <bool TEAM>
@@ -272,10 +289,16 @@ struct GridColumnModel {
         gamma = sigmoid_exact<LOOKUP>(u, tab, sel);                       // :617
         d = gamma * mu - in.eta_old;                                      // :620
     }
+    static constexpr bool kHasSkip = false;
+    template <int LOOKUP>
+    static __device__ __forceinline__ float delta(const In& in, float q, const ExpTab& tab, int sel) {
+        float mu, gamma, d;
+        core<LOOKUP>(in, q, tab, mu, gamma, d, sel);
+        return d;
+    }
     template <int LOOKUP>
     static __device__ __forceinline__ bool update(const In& in, float q, const ExpTab& tab, float& d, int sel) {
-        float mu, gamma;
-        core<LOOKUP>(in, q, tab, mu, gamma, d, sel);
+        d = delta<LOOKUP>(in, q, tab, sel);
         return true;
     }
     template <bool TEAM>
@@ -373,13 +396,21 @@ struct MixtureModel {
     }
 };
 
+// One role of the sweep kernel below: a workgroup either works as member `wg % team_size` of team `wg / team_size`
+// on the statically assigned blocks of a team class (TEAM), or pulls blocks from the small-block queue.
 template <typename U, typename MODEL, bool SYM, int NW, bool TEAM, int CPL>
-__global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(EStepArgs<float> A0, int qcap) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int qcap, float* __restrict__ smem, const int wg) {
+    // q[qcap] | a[2][64] | tiles[2][64 x 64] | mixture chain scratch.  The two tile buffers hold
+    //   lane-per-SNP models: the DIAGONAL tiles R[p, p] / R[p+1, p+1] (staged by the updaters one phase ahead; the
+    //     chain reads its row with one ds_read per step and touches no LD memory on its critical path -- the
+    //     off-diagonal tile R[p, p+1] of its next phase it prefetches into registers, one row per step, a whole
+    //     phase ahead of its use);
+    //   mixture (rolled chain loop): the off-diagonal tiles R[p-1, p] / R[p, p+1], diagonal rows from global memory.
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
     float* lmx = lT + 2 * kPanel * kPanel;              // mixture chain only (kMixLdsFloats)
+    constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     __shared__ int s_blk;
 
     const int tid = threadIdx.x;
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
     // descending size; workgroup r starts pulling work only once the queue head has reached
     // admit[r].  The head only moves forward and workgroup 0 is never gated: no deadlock.
     if (A0.admit != nullptr) {
-        const int th = A0.admit[blockIdx.x];
+        const int th = A0.admit[wg];
         if (th > 0) {
             if (tid == 0) {
                 while (__hip_atomic_load(A0.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < th)
@@ -415,8 +446,8 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
     // Blocks are assigned to teams statically (team t: blocks t, t + n_teams, ...).
     constexpr int kSW = kPanel * CPL;                   // strip width (columns per updater wave)
     const int TS = TEAM ? A0.team_size : 1;
-    const int team = TEAM ? (int)blockIdx.x / TS : 0;
-    const int member = TEAM ? (int)blockIdx.x % TS : 0;
+    const int team = TEAM ? wg / TS : 0;
+    const int member = TEAM ? wg % TS : 0;
     int team_iter = 0;
 
     for (;;) {
@@ -425,7 +456,16 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
             item = team + team_iter * A0.n_teams;
             ++team_iter;
         } else {
-            if (tid == 0) s_blk = atomicAdd(A0.counter, 1);
+            if (tid == 0) {
+                int it = atomicAdd(A0.counter, 1);
+                if (A0.bottom_mod > 0 && it < A0.n_blocks * n_models) {
+                    // claim `it` is valid: take the next block from this workgroup's end of the sorted list (the two ends
+                    // cannot cross: at most n claims are valid)
+                    const bool bottom = (wg % A0.bottom_mod) == A0.bottom_mod - 1;
+                    it = bottom ? A0.n_blocks * n_models - 1 - atomicAdd(A0.counter + 2, 1) : atomicAdd(A0.counter + 1, 1);
+                }
+                s_blk = it;
+            }
             __syncthreads();
             item = s_blk;
             __syncthreads();
@@ -447,6 +487,14 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
         const int bpad = np * kPanel;
 
         for (int i = tid; i < bpad + kStrip; i += NW * 64) lq[i] = (i < b) ? A.q[s0 + i] : 0.0f;
+        if (kDiagInLds) {
+            // diagonal tile of panel 0 (rows past the end of a short block are clamped: finite values that
+            // only ever meet a = 0)
+            for (int i = tid; i < kPanel * kPanel / 4; i += NW * 64) {
+                const int row = i >> 4, tcol = (i & 15) * 4;
+                *reinterpret_cast<float4*>(lT + row * kPanel + tcol) = load4<U>(base + (int64_t)min(row, b - 1) * stride + tcol);
+            }
+        }
         __syncthreads();
 
         float a_prev = 0.0f;   // chain wave: lane j = dq * eta_diff of SNP j of the previous panel
@@ -454,22 +502,29 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
         // ---- chain wave: inputs and first diagonal-tile rows of the NEXT panel, fetched under the
         //      current panel's serial updates so that no HBM latency sits between two panels
         typename MODEL::In nxt_in{};
-        float dnext[kChainPrefetch];
+        float dnext[kChainPrefetch];                    // mixture chain: first diagonal rows of the next panel
+        float tnext[kDiagInLds ? kPanel : 1];           // lane-per-SNP chain: column `lane` of tile R[p, p+1], row by row
         if (wave == 0) {
             const bool live0 = lane < b;
             nxt_in = MODEL::load(A, s0 + (live0 ? lane : 0), live0);
+            if (!kDiagInLds) {
 #pragma unroll
-            for (int k = 0; k < kChainPrefetch; ++k)
-                dnext[k] = static_cast<float>(base[(int64_t)min(k, b - 1) * stride + lane]);
+                for (int k = 0; k < kChainPrefetch; ++k)
+                    dnext[k] = static_cast<float>(base[(int64_t)min(k, b - 1) * stride + lane]);
+            }
         }
 
         // symmetric form: one extra phase applies the last panel's a-vector to the columns left of it
 #ifdef VIPRS_PANEL_PROFILE
         __shared__ unsigned s_pprof[64][8];
 #endif
+        // The chain wave and the updater waves run their OWN loops over the phases (one workgroup barrier per phase
+        // in each): what a role keeps in registers across phases -- the chain's 64 prefetched tile rows -- is then
+        // live in its own branch only and does not add to the other role's register budget.
+        if (wave == 0) {
         for (int p = 0; p < np + (SYM ? 1 : 0); ++p) {
-            PPROF(0, wave == 0);
-            if (wave == 0) {
+            PPROF(0, true);
+            {
                 // ================================ chain ======================================
                 if (p < np) {
                     const int r0 = p * kPanel;
@@ -489,9 +544,11 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
                     // path (a = 0 leaves every q untouched).
                     const int last = nrows - 1;
                     const U* __restrict__ dptr = base + (int64_t)r0 * stride + r0 + lane;
-                    float drow[kPanel];
+                    float drow[kDiagInLds ? 1 : kPanel];
+                    if (!kDiagInLds) {
 #pragma unroll
-                    for (int k = 0; k < kChainPrefetch; ++k) drow[k] = dnext[k];
+                        for (int k = 0; k < kChainPrefetch; ++k) drow[k] = dnext[k];
+                    }
                     // first rows of the next panel's diagonal tile (clamped to the block when there
                     // is no next panel: loaded, never used)
                     const int rn0 = min(r0 + kPanel, bpad - kPanel);
@@ -516,10 +573,16 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
                     }
                     PPROF(1, true);
                     if (p > 0) {
-                        // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
-                        const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
+                        if (kDiagInLds) {
+                            // a_{p-1} through tile R[p-1, p], prefetched into registers during the previous phase
 #pragma unroll
-                        for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
+                            for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(tnext[k], rl(a_prev, k), qc);
+                        } else {
+                            // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
+                            const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
+#pragma unroll
+                            for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
+                        }
                     }
 
                     PPROF(2, true);
@@ -637,34 +700,43 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
                         }
                         a_prev = avec;
                     } else {
-                    // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own
-                        // q[j]); every lane executes the update arithmetic on its own values, but at
-                        // step j only lane j's result is meaningful: its scaled eta_diff is broadcast
-                        // (one v_readlane) and applied to the whole panel through row j of the
-                        // diagonal tile.  The wave is issue-bound here (one wave per chain), so the
-                        // step is written for instruction count: no input broadcasts, no branches.
+                        // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own q[j]);
+                        // every lane evaluates the update on its own values, but at step j only lane j's
+                        // result is meaningful: it is broadcast with one v_readlane and applied to the whole
+                        // panel through row j of the diagonal tile (LDS).  One wave per chain: every
+                        // instruction of the step is on the critical path or competes for its issue slots,
+                        // so the step is written for both --
+                        //   * the next step's update reads q from the fma result `qf` directly; the own-lane
+                        //     bookkeeping (q capture for the replay, the symmetric form's diagonal
+                        //     subtraction e_step.hpp:427) hangs off the side through selects on an SGPR lane
+                        //     mask that is shifted once per step (no per-step lane compare);
+                        //   * skipped steps (|d| < eps, e_step.hpp:410) become a = 0: fma(R, 0, q) == q.
+                        //     Lanes past a partial last panel carry all-zero inputs (MODEL::load), which makes
+                        //     their d exactly 0: they skip by themselves, no `live` test inside the loop;
+                        //   * the tile row R[p, p+1][jj, lane] the NEXT phase starts with is fetched here,
+                        //     one row per step: by the time it is used the load is a whole phase old.
                         float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
+                        const float* __restrict__ Dt = lT + (p & 1) * kPanel * kPanel + lane;
+                        // rows of panel p x columns of panel p+1 (clamped into the block when there is no next panel)
+                        // (rows past a partial last panel run into the slack behind the dense LD buffer: loaded, never used)
+                        const U* __restrict__ tptr = base + (int64_t)r0 * stride + min(r0 + kPanel, bpad - kPanel) + lane;
+                        unsigned long long lane_bit = 1ull;
+                        float qf = qc;
     #pragma unroll
                         for (int jj = 0; jj < kPanel; ++jj) {
-                            if (jj + kChainPrefetch < kPanel)
-                                drow[jj + kChainPrefetch] =
-                                    static_cast<float>(dptr[(int64_t)min(jj + kChainPrefetch, last) * stride]);
-                            else
-                                dnext[jj + kChainPrefetch - kPanel] = static_cast<float>(
-                                    nptr[(int64_t)min(jj + kChainPrefetch - kPanel, b - 1 - rn0) * stride]);
-                            float d;
-                            // dead lanes (past a partial last panel) are forced onto the skip path
-                            const bool upd = MODEL::template update<kLookupLane>(in, qc, tab, d, jj) && live;
-                            const float a_lane = upd ? dq * d : 0.0f;
-                            // (keeps hipcc from hoisting 64 loop-invariant lane masks and spilling them)
-                            int l = lane;
-                            asm volatile("" : "+v"(l));
-                            const bool me = (l == jj);
-                            qcap_v = me ? qc : qcap_v;
-                            qc = __builtin_fmaf(drow[jj], rl(a_lane, jj), qc);
-                            if (SYM) qc = (me && upd) ? qc - d : qc;   // e_step.hpp:427 (diagonal entry of the symmetric form)
+                            tnext[jj] = static_cast<float>(*tptr);
+                            tptr += stride;
+                            const float dr = Dt[jj * kPanel];
+                            const float d = MODEL::template delta<kLookupLane>(in, qf, tab, jj);
+                            const float dz = (MODEL::kHasSkip && fabsf(d) < Eps<float>::value) ? 0.0f : d;   // :410
+                            const float sdz = rl(dz, jj);
+                            const float sa = dq * sdz;
+                            qcap_v = sel_mask(qcap_v, qc, lane_bit);
+                            qf = __builtin_fmaf(dr, sa, qc);
+                            qc = SYM ? sel_mask(qf, qf - sdz, lane_bit) : qf;   // e_step.hpp:427 (own lane only)
+                            asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(lane_bit) : : "scc");
                         }
-    
+
                         PPROF(3, true);
                         // lane-parallel replay of the 64 updates (same operations, same inputs ->
                         // same bits) to produce the per-SNP outputs without serialising the stores
@@ -676,17 +748,32 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
                     lq[r0 + lane] = qc;
                     PPROF(4, true);
                 }
-            } else {
+            }
+            __syncthreads();
+        }
+        } else {
+        for (int p = 0; p < np + (SYM ? 1 : 0); ++p) {
+            {
                 // ================================ updaters ===================================
                 const int uw = wave - 1;
-                // stage tile R[p, p+1] for the chain's next phase
+                // stage the tile of the chain's next phase: the diagonal tile R[p+1, p+1] (lane-per-SNP models) or the
+                // off-diagonal tile R[p, p+1] (mixture).  16 row groups of 4 rows dealt to the updater waves, all of a
+                // wave's loads issued before its first LDS store (one memory round trip per phase)
                 if (p + 1 < np) {
                     float* __restrict__ T = lT + ((p + 1) & 1) * kPanel * kPanel;
                     const int trow = lane >> 4, tcol = (lane & 15) * 4;
-                    for (int i = uw; i < kPanel / 4; i += NW - 1) {
-                        const int row = 4 * i + trow;
-                        const float4 v = load4<U>(base + (int64_t)(p * kPanel + row) * stride + (p + 1) * kPanel + tcol);
-                        *reinterpret_cast<float4*>(T + row * kPanel + tcol) = v;
+                    const int row_base = (kDiagInLds ? p + 1 : p) * kPanel;
+                    constexpr int kGroups = (kPanel / 4 + NW - 2) / (NW - 1);
+                    float4 v[kGroups];
+#pragma unroll
+                    for (int g = 0; g < kGroups; ++g) {
+                        const int row = 4 * min(uw + g * (NW - 1), kPanel / 4 - 1) + trow;
+                        v[g] = load4<U>(base + (int64_t)min(row_base + row, b - 1) * stride + (p + 1) * kPanel + tcol);
+                    }
+#pragma unroll
+                    for (int g = 0; g < kGroups; ++g) {
+                        const int i = uw + g * (NW - 1);
+                        if (i < kPanel / 4) *reinterpret_cast<float4*>(T + (4 * i + trow) * kPanel + tcol) = v[g];
                     }
                 }
                 PPROF(5, wave == 1);
@@ -737,6 +824,7 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
             PPROF(7, wave == 1);
             __syncthreads();
         }
+        }
 #ifdef VIPRS_PANEL_PROFILE
         if (TEAM && item == 0 && member < 2 && tid == 0) {
             for (int p = 0; p < np && p < 64; p += (p < 4 || p > np - 4) ? 1 : 8) {
@@ -756,6 +844,33 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_panel_kernel(E
         __syncthreads();
     }
     if (lane == 0 && my_skipped && member == 0) atomicAdd(A0.skipped, my_skipped);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The sweep over all dense blocks of a plan as ONE launch.  Workgroups 0 .. n_wg[0]-1 are the teams of
+// the largest blocks, the next n_wg[1] the teams of the medium class, the rest small-block workers;
+// a team workgroup that has finished its team's blocks carries on as a small-block worker.  One
+// dispatch means: (i) the whole grid is resident by construction (the host sizes it to the
+// occupancy of this kernel), so team members -- which wait on each other's hand-offs -- never depend
+// on the launch order or timing of other kernels; (ii) workgroups are placed in index order, the
+// critical path (the teams) first; (iii) no stream fork / join around the sweep.
+// ---------------------------------------------------------------------------------------------
+struct SweepArgs {
+    EStepArgs<float> cls[3];     // per size class: block list, team geometry, queue counters
+    int32_t qcap[3];             // LDS floats reserved for q per class (largest block of the class, padded)
+    int32_t n_wg[2];             // team workgroups of class 0 / class 1 (0 = class empty)
+};
+
+template <typename U, typename MODEL, bool SYM, int NW, int CPL>
+__global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(SweepArgs S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wg = blockIdx.x;
+    const int team_cls = wg < S.n_wg[0] ? 0 : (wg < S.n_wg[0] + S.n_wg[1] ? 1 : 2);
+    if (team_cls < 2) {
+        panel_role<U, MODEL, SYM, NW, true, CPL>(S.cls[team_cls], S.qcap[team_cls], smem, wg - (team_cls ? S.n_wg[0] : 0));
+        __syncthreads();
+    }
+    if (S.cls[2].n_blocks > 0) panel_role<U, MODEL, SYM, NW, false, CPL>(S.cls[2], S.qcap[2], smem, wg);
 }
 
 // Copies the team kernels' eta / q outputs into place (runs behind the team kernel on its stream).

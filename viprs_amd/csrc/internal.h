@@ -51,9 +51,12 @@ struct SchedConfig {
     // mixture: the chain step is ~4x the spike-and-slab one, every team member replicates it -- smaller teams
     int class_team_mix[3] = {4, 1, 1};
     bool team_env = false;                         // VIPRS_TEAM0/1 given: they apply to every model
+    // small-block queue: every `bottom_mod`-th workgroup pulls from the SMALL end of the size-sorted queue (0 = off)
+    int bottom_mod = 3;                            // VIPRS_BOTTOM_MOD
 };
 SchedConfig& sched_config();                       // process-wide, read from the environment at plan creation
 constexpr int kClassWaves[3] = {4, 4, 4};
+constexpr int kPlanCounters = 32;                  // work-queue heads of a plan (d_counters), zeroed by every sweep's prologue
 constexpr int kEpiWaves = 4;
 
 template <typename V> struct DevBuf {

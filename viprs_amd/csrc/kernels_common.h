@@ -39,6 +39,11 @@ struct EStepArgs {
     const BlockDesc* blocks;     // schedule order (descending cost)
     int32_t n_blocks;
     int32_t* counter;            // work-queue head (zeroed before every launch)
+    // Two-ended queue of the small-block class (bottom_mod > 0): counter[0] counts claims, counter[1] / counter[2] the
+    // blocks taken from the large / the small end of the size-sorted list.  Workgroups with blockIdx % bottom_mod ==
+    // bottom_mod - 1 take from the small end: at any time the chip then works on a MIX of bandwidth-bound (large)
+    // and chain-bound (small) blocks instead of all workgroups moving from large to small blocks in lockstep.
+    int32_t bottom_mod;
     const int32_t* admit;        // per-workgroup admission threshold on the queue head (may be null)
     unsigned long long* granules; // team kernels: {tag, value} hand-off granules (zeroed before every launch)
     int32_t* error;              // set to non-zero when a bounded spin gives up

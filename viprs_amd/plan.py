@@ -7,6 +7,7 @@ independent LD blocks, uploaded and re-laid-out for the panel kernels once; ever
 only moves per-SNP vectors.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -117,10 +118,10 @@ class LDPlan:
     # -- lifetime -----------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            if getattr(self, "_live_states", 0) > 0:
-                # a DeviceState dereferences its plan when it is destroyed: closing the plan first would be a
-                # use-after-free on the C side
-                raise ValueError(f"LDPlan.close(): {self._live_states} DeviceState(s) of this plan are still open")
+            # a DeviceState dereferences its plan when it is destroyed (closing the plan first would be a
+            # use-after-free on the C side): the plan closes the states that are still open before it goes
+            for st in list(getattr(self, "_states", ())):
+                st.close()
             L.lib.viprs_plan_destroy(self._h)
             self._h = ctypes.c_void_p()
 
@@ -233,13 +234,15 @@ class DeviceState:
         self._h = ctypes.c_void_p()
         L.check(L.lib.viprs_state_create(ctypes.byref(self._h), plan.handle, _FLOAT_CODE[self.dtype], kind,
                                          self.width))
-        plan._live_states = getattr(plan, "_live_states", 0) + 1
+        if not hasattr(plan, "_states"):
+            plan._states = weakref.WeakSet()
+        plan._states.add(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             L.lib.viprs_state_destroy(self._h)
             self._h = ctypes.c_void_p()
-            self.plan._live_states -= 1
+            self.plan._states.discard(self)
 
     def __del__(self):
         try:
