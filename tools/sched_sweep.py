@@ -12,12 +12,11 @@ upper = "upper" in sys.argv
 dt = np.int8 if "int8" in sys.argv else np.float32
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
 CONFIGS = [dict()]
-for t0, t1 in (("8", "1"), ("6", "1"), ("6", "2"), ("4", "1"), ("12", "2"), ("16", "2")):
-    CONFIGS.append(dict(VIPRS_TEAM0=t0, VIPRS_TEAM1=t1))
-for lg, md in (("2304", "1600"), ("1920", "1280"), ("3000", "1600"), ("2304", "1024")):
-    CONFIGS.append(dict(VIPRS_LARGE_BLOCK=lg, VIPRS_MEDIUM_BLOCK=md))
-for bm in ("0", "2", "4"):
-    CONFIGS.append(dict(VIPRS_BOTTOM_MOD=bm))
+for md, t1 in (("1280", "2"), ("1280", "4"), ("1024", "2"), ("1024", "4"), ("1152", "3"), ("1408", "3"), ("896", "2")):
+    CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK=md, VIPRS_TEAM1=t1, VIPRS_TEAM0="8"))
+CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK="1024", VIPRS_TEAM1="3", VIPRS_LARGE_BLOCK="1920"))
+CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK="1152", VIPRS_TEAM1="2", VIPRS_LARGE_BLOCK="2048", VIPRS_TEAM0="6"))
+CONFIGS.append(dict())
 KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_HELPERS", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK", "VIPRS_ADMIT_FACTOR")
 for cfg in CONFIGS:
     for k in KEYS:

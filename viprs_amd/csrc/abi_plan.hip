@@ -176,7 +176,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         d.band_left = d.band_right = 0;
         // the panel kernels keep q of a whole block in LDS: a dense block beyond that (~29 000 SNPs) is
         // scheduled like a windowed component (band kernel if its ring fits, generic kernel otherwise)
-        constexpr int kMaxDenseBlock = (160 * 1024 / 4 - panel_lds_floats(kStrip) - kMixLdsFloats) / kPanel * kPanel;
+        constexpr int kMaxDenseBlock = (160 * 1024 / 4 - panel_lds_floats(kStrip) - panel_upper_lds_floats(kStrip) - kMixLdsFloats) / 2 / kPanel * kPanel;
         const bool dense = panel_ld && (b.kind == VIPRS_BLOCK_DENSE_SYM || b.kind == VIPRS_BLOCK_DENSE_UPPER) &&
                            d.size <= kMaxDenseBlock;
         if (dense) {

@@ -209,6 +209,39 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
     for (int i = 0; i < CPL; ++i) lq_c[i] = qv[i];
 }
 
+// Upper-triangular form, the reference's second pass (update_q_factor, e_step.hpp:331-337:
+//     q[j] += dq * dot(eta_diff[j+1 .. end), R[j, j+1 .. end)),  the dot a serial fma chain from 0 in column order)
+// done PROGRESSIVELY inside the sweep: when the chain has finished column panel `pp`, the tiles R[r, pp] of all
+// row panels r <= pp extend the running sums s[j] of their rows by the panel's 64 columns -- columns still arrive in
+// ascending order for every row, so the sums are the reference's, bit for bit.  One wave per tile, lane = row: each
+// lane walks its own row (16-byte loads along the row; the four loads of a 64-byte line hit L1), eta_diff of the
+// panel comes in by v_readlane.  DIAG: the tile on the diagonal counts columns right of the row only.
+// (half a tile = 32 columns of 64 rows per unit, so that the next unit's loads can be in flight while the current one
+// is accumulated without a second tile's worth of registers)
+template <typename U> struct HalfTileRows {
+    static constexpr int C = 16 / (int)sizeof(U);      // columns per 16-byte load
+    static constexpr int N = (kPanel / 2) / C;         // loads per lane and half tile
+    RawRow<U, C> v[N];
+    __device__ __forceinline__ void load(const U* __restrict__ rowp) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = load_raw<U, C>(rowp + C * i);
+    }
+    // s += sum_c R[row, c0 + c] * ed[c0 + c] in column order (diag: columns right of the row's own column only)
+    template <int C0>
+    __device__ __forceinline__ float accumulate(float s, float edv, bool diag, int lane) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int e = 0; e < C; ++e) {
+                const int c = C0 + C * i + e;
+                const float t = __builtin_fmaf(v[i].get(e), rl(edv, c), s);
+                s = (!diag || c > lane) ? t : s;
+            }
+        }
+        return s;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Model policies: what one SNP update computes (the serial chain evaluates `update` with the
 // lane-select table lookup; after the 64 steps every lane replays its own SNP with the per-lane
@@ -245,7 +278,8 @@ struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
     }
     template <bool TEAM>
     static __device__ __forceinline__ float finish(const EStepArgs<float>& A, int64_t j, const In& in, float q,
-                                                   const ExpTab& tab, bool live, bool writer, bool& skipped) {
+                                                   const ExpTab& tab, bool live, bool writer, bool& skipped,
+                                                   float* d_out = nullptr) {
         float mu, gamma, d;
         snp_update<EXACT, kLookupPerLane>(in.mm, in.beta, in.sv, in.ulog, in.eta_old, q, tab, mu, gamma, d);
         const bool skip = fabsf(d) < Eps<float>::value;
@@ -261,6 +295,7 @@ struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
             if (TEAM) A.eta_out[j] = skip ? in.eta_old : in.eta_old + d;
         }
         skipped = live && skip;
+        if (d_out) *d_out = (live && !skip) ? d : 0.0f;
         return (live && !skip) ? A.dq * d : 0.0f;
     }
 };
@@ -303,9 +338,11 @@ struct GridColumnModel {
     }
     template <bool TEAM>
     static __device__ __forceinline__ float finish(const EStepArgs<float>& A, int64_t j, const In& in, float q,
-                                                   const ExpTab& tab, bool live, bool writer, bool& skipped) {
+                                                   const ExpTab& tab, bool live, bool writer, bool& skipped,
+                                                   float* d_out = nullptr) {
         float mu, gamma, d;
         core<kLookupPerLane>(in, q, tab, mu, gamma, d, 0);
+        if (d_out) *d_out = live ? d : 0.0f;
         if (live && writer) {
             A.var_mu[j] = mu;
             A.var_gamma[j] = gamma;
@@ -410,6 +447,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
     float* lmx = lT + 2 * kPanel * kPanel;              // mixture chain only (kMixLdsFloats)
+    // upper-triangular form: eta_diff of the last two panels and the running second-pass sums s[j] of the block
+    // (panel_upper_lds_floats; behind the mixture scratch)
+    float* led = lmx + (MODEL::kLaneParallel ? kMixLdsFloats : 0);
+    float* ls = led + 2 * kPanel;
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     __shared__ int s_blk;
 
@@ -487,6 +528,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         const int bpad = np * kPanel;
 
         for (int i = tid; i < bpad + kStrip; i += NW * 64) lq[i] = (i < b) ? A.q[s0 + i] : 0.0f;
+        if (!SYM) for (int i = tid; i < bpad; i += NW * 64) ls[i] = 0.0f;
         if (kDiagInLds) {
             // diagonal tile of panel 0 (rows past the end of a short block are clamped: finite values that
             // only ever meet a = 0)
@@ -522,7 +564,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         // in each): what a role keeps in registers across phases -- the chain's 64 prefetched tile rows -- is then
         // live in its own branch only and does not add to the other role's register budget.
         if (wave == 0) {
-        for (int p = 0; p < np + (SYM ? 1 : 0); ++p) {
+        for (int p = 0; p < np + 1; ++p) {
             PPROF(0, true);
             {
                 // ================================ chain ======================================
@@ -699,6 +741,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             }
                         }
                         a_prev = avec;
+                        if (!SYM) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
                     } else {
                         // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own q[j]);
                         // every lane evaluates the update on its own values, but at step j only lane j's
@@ -741,8 +784,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         // lane-parallel replay of the 64 updates (same operations, same inputs ->
                         // same bits) to produce the per-SNP outputs without serialising the stores
                         bool skipped_lane;
-                        a_prev = MODEL::template finish<TEAM>(A, j, in, qcap_v, tab, live, member == 0, skipped_lane);
+                        float d_lane = 0.0f;
+                        a_prev = MODEL::template finish<TEAM>(A, j, in, qcap_v, tab, live, member == 0, skipped_lane, &d_lane);
                         my_skipped += __popcll(__ballot(skipped_lane));
+                        if (!SYM) led[(p & 1) * kPanel + lane] = d_lane;
                     }
                     la[(p & 1) * kPanel + lane] = a_prev;
                     lq[r0 + lane] = qc;
@@ -752,7 +797,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             __syncthreads();
         }
         } else {
-        for (int p = 0; p < np + (SYM ? 1 : 0); ++p) {
+        for (int p = 0; p < np + 1; ++p) {
             {
                 // ================================ updaters ===================================
                 const int uw = wave - 1;
@@ -819,6 +864,34 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                                __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
+                    if (!SYM) {
+                        // second pass, column panel pp: tiles R[r, pp], r = 0 .. pp, of the row panels this member owns
+                        // (the owner of a strip owns the q -- and the sums -- of its rows), dealt to its updater waves
+                        const float edv = led[(pp & 1) * kPanel + lane];
+                        if (__ballot(edv != 0.0f) != 0) {
+                            // this wave's tiles: row panels r = uw, uw + NU, ... <= pp (teams: of the member's own strips);
+                            // the next tile's 16 row loads are in flight while the current tile is accumulated
+                            auto mine = [&](int r) { return !TEAM || (((r * kPanel) / kSW) % TS) == member; };
+                            auto rowptr = [&](int r) {
+                                // rows past the block are clamped (their sums are never used)
+                                return base + (int64_t)min(r * kPanel + lane, b - 1) * stride + pp * kPanel;
+                            };
+                            int r = uw;
+                            while (r <= pp && !mine(r)) r += NW - 1;
+                            HalfTileRows<U> h0, h1;                 // columns 0..31 / 32..63 of the current tile
+                            if (r <= pp) h0.load(rowptr(r));
+                            while (r <= pp) {
+                                int rn = r + NW - 1;
+                                while (rn <= pp && !mine(rn)) rn += NW - 1;
+                                h1.load(rowptr(r) + kPanel / 2);
+                                float* __restrict__ sl = ls + r * kPanel + lane;
+                                float sv = h0.template accumulate<0>(*sl, edv, r == pp, lane);
+                                if (rn <= pp) h0.load(rowptr(rn));
+                                *sl = h1.template accumulate<kPanel / 2>(sv, edv, r == pp, lane);
+                                r = rn;
+                            }
+                        }
+                    }
                 }
             }
             PPROF(7, wave == 1);
@@ -839,7 +912,8 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         {   // teams: every member owns the final q of its own strips
             float* __restrict__ qdst = TEAM ? A.q_out : A.q;
             for (int i = tid; i < b; i += NW * 64)
-                if (!TEAM || ((i / kSW) % TS) == member) qdst[s0 + i] = lq[i];
+                if (!TEAM || ((i / kSW) % TS) == member)
+                    qdst[s0 + i] = SYM ? lq[i] : lq[i] + A.dq * ls[i];      // upper form: q[j] += dq * dot (e_step.hpp:335)
         }
         __syncthreads();
     }

@@ -46,8 +46,8 @@ inline size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 
 // Every class uses 4-wave workgroups (1 chain + 3 updaters) so that a team member needs exactly
 // the same CU resources as a small-block workgroup; larger blocks get more CUs, not bigger groups.
 struct SchedConfig {
-    int large_block = 2304, medium_block = 1280;   // VIPRS_LARGE_BLOCK / VIPRS_MEDIUM_BLOCK
-    int class_team[3] = {8, 2, 1};                 // workgroups (CUs) sharing one block of the class (0/1: teams)
+    int large_block = 2304, medium_block = 1600;   // VIPRS_LARGE_BLOCK / VIPRS_MEDIUM_BLOCK
+    int class_team[3] = {8, 4, 1};                 // workgroups (CUs) sharing one block of the class (0/1: teams)
     // mixture: the chain step is ~4x the spike-and-slab one, every team member replicates it -- smaller teams
     int class_team_mix[3] = {4, 1, 1};
     bool team_env = false;                         // VIPRS_TEAM0/1 given: they apply to every model
