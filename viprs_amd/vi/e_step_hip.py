@@ -15,7 +15,10 @@ from .. import _lib as L
 from ..plan import LDPlan
 
 _PLAN_CACHE = OrderedDict()
-_PLAN_CACHE_SIZE = 32
+# Device-resident LD kept by the drop-in entry points: bounded by BYTES of device memory (a genome-scale plan is
+# ~4 GB), least recently used plans are closed first.  VIPRS_PLAN_CACHE_GB overrides the default budget.
+import os as _os
+_PLAN_CACHE_BYTES = int(float(_os.environ.get("VIPRS_PLAN_CACHE_GB", "64")) * (1 << 30))
 _DEFAULT_DEVICE = 0
 _DEFAULT_MATH = "exact"
 
@@ -31,14 +34,45 @@ def set_default_math_mode(mode):
     if mode not in ("exact", "fast"):
         raise ValueError("math mode must be 'exact' or 'fast'")
     _DEFAULT_MATH = mode
-    for plan, _ in _PLAN_CACHE.values():
+    for plan, _, _ in _PLAN_CACHE.values():
         plan.set_math_mode(mode)
 
 
 def clear_plan_cache():
-    for plan, _ in _PLAN_CACHE.values():
+    for plan, _, _ in _PLAN_CACHE.values():
         plan.close()
     _PLAN_CACHE.clear()
+
+
+def set_plan_cache_budget(n_bytes):
+    """Device-memory budget (bytes) of the plan cache; evicts down to it at once."""
+    global _PLAN_CACHE_BYTES
+    _PLAN_CACHE_BYTES = int(n_bytes)
+    _evict(keep=None)
+
+
+def _evict(keep):
+    total = sum(b for _, _, b in _PLAN_CACHE.values())
+    for key in list(_PLAN_CACHE):
+        if total <= _PLAN_CACHE_BYTES:
+            break
+        if key == keep:
+            continue
+        plan, _, nbytes = _PLAN_CACHE.pop(key)
+        plan.close()
+        total -= nbytes
+
+
+def invalidate(ld_data=None):
+    """Forget the device copy of `ld_data` (all cached plans when None).  The cache is keyed on the IDENTITY of the
+    host buffers, so an in-place edit of an LD array is not noticed: call this after one."""
+    if ld_data is None:
+        clear_plan_cache()
+        return
+    addr = ld_data.__array_interface__["data"][0]
+    for key in [k for k in _PLAN_CACHE if k[3] == addr]:
+        plan, _, _ = _PLAN_CACHE.pop(key)
+        plan.close()
 
 
 def plan_for(ld_left_bound, ld_indptr, ld_data, low_memory):
@@ -52,10 +86,8 @@ def plan_for(ld_left_bound, ld_indptr, ld_data, low_memory):
         _PLAN_CACHE.move_to_end(key)
         return hit[0]
     plan = LDPlan(ld_left_bound, ld_indptr, ld_data, low_memory, device=_DEFAULT_DEVICE, math_mode=_DEFAULT_MATH)
-    _PLAN_CACHE[key] = (plan, (ld_left_bound, ld_indptr, ld_data))
-    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
-        _, (old, _) = _PLAN_CACHE.popitem(last=False)
-        old.close()
+    _PLAN_CACHE[key] = (plan, (ld_left_bound, ld_indptr, ld_data), int(plan.info(L.INFO_LD_BYTES_DEVICE)))
+    _evict(keep=key)
     return plan
 
 
@@ -117,6 +149,14 @@ def cpp_e_step_mixture(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, v
     for name, a in (("var_gamma", var_gamma), ("var_mu", var_mu), ("u_logs", u_logs),
                     ("sqrt_half_var_tau", sqrt_half_var_tau), ("mu_mult", mu_mult)):
         _floating(name, a, T, ndim=2, order="C")
+    m, K = var_mu.shape
+    for name, a in (("std_beta", std_beta), ("eta", eta), ("q", q), ("eta_diff", eta_diff), ("log_null_pi", log_null_pi)):
+        if a.shape != (m,):
+            raise ValueError(f"{name}: expected shape ({m},), got {a.shape}")
+    for name, a in (("var_gamma", var_gamma), ("u_logs", u_logs), ("sqrt_half_var_tau", sqrt_half_var_tau),
+                    ("mu_mult", mu_mult)):
+        if a.shape != (m, K):
+            raise ValueError(f"{name}: expected shape ({m}, {K}), got {a.shape}")
     plan = plan_for(ld_left_bound, ld_indptr, ld_data, low_memory)
     if plan.m != var_mu.shape[0]:
         raise ValueError(f"LD arrays describe {plan.m} SNPs but the state has {var_mu.shape[0]}")
@@ -134,6 +174,15 @@ def cpp_e_step_grid(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_
         _floating(name, a, T, ndim=2, order="F")
     if not isinstance(active_model_idx, np.ndarray) or active_model_idx.dtype != np.int32:
         raise ValueError("Buffer dtype mismatch, expected 'int' (active_model_idx)")
+    m, G = var_mu.shape
+    if std_beta.shape != (m,):
+        raise ValueError(f"std_beta: expected shape ({m},), got {std_beta.shape}")
+    for name, a in (("var_gamma", var_gamma), ("eta", eta), ("q", q), ("eta_diff", eta_diff), ("u_logs", u_logs),
+                    ("half_var_tau", half_var_tau), ("mu_mult", mu_mult)):
+        if a.shape != (m, G):
+            raise ValueError(f"{name}: expected shape ({m}, {G}), got {a.shape}")
+    if active_model_idx.ndim != 1 or (active_model_idx.size and (active_model_idx.min() < 0 or active_model_idx.max() >= G)):
+        raise ValueError("active_model_idx: model index out of range")
     plan = plan_for(ld_left_bound, ld_indptr, ld_data, low_memory)
     if plan.m != var_mu.shape[0]:
         raise ValueError(f"LD arrays describe {plan.m} SNPs but the state has {var_mu.shape[0]}")
