@@ -21,10 +21,12 @@ def _run_mix(mod, ld, inp, mix, st0, sweeps, **kw):
 
 
 @pytest.mark.parametrize("low_memory", [False, True])
-@pytest.mark.parametrize("K", [1, 4, 8, 10])          # K <= 8: panel kernels; K = 10: generic kernel
+# K <= 8: panel kernels, DPP scans; 9..31: panel kernels, scalar chains over the lanes (10 = the reference's own test,
+# 20 = its benchmark; 15 / 16 / 31: the edges of the two instantiations); 33: generic kernel
+@pytest.mark.parametrize("K", [1, 4, 8, 9, 10, 15, 16, 20, 31, 33])
 def test_mixture_matches_oracle(gpu, K, low_memory):
     from viprs_amd.vi import e_step_hip as S
-    ld, ss, inp = syn.make_problem(sizes=[70, 1400, 333], low_memory=low_memory, seed=31)
+    ld, ss, inp = syn.make_problem(sizes=[70, 1400, 333, 2400], low_memory=low_memory, seed=31)   # single workgroups + a team block
     mix, st0 = _mixture_inputs(ld, ss, K)
     ref = _run_mix(O, ld, inp, mix, st0, 2)
     got = _run_mix(S, ld, inp, mix, st0, 2)

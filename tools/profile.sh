@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 rm -rf $R/gpurun_out/${TAG}_stats $R/gpurun_out/${TAG}_fetch $R/gpurun_out/${TAG}_write
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 "$@" > $R/gpurun_out/${TAG}_stats_bench.json 2>/dev/null
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 "$@" > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 "$@" > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-secondary "$@" > $R/gpurun_out/${TAG}_stats_bench.json 2>/dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-secondary "$@" > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-secondary "$@" > /dev/null 2>&1
 cat $R/gpurun_out/${TAG}_stats/*/*kernel_stats.csv | head -8 | cut -c1-170
 cut -c1-300 $R/gpurun_out/${TAG}_stats_bench.json

@@ -155,7 +155,7 @@ static int launch_grid_mfma_u(viprs_plan* P, const EStepArgs<float>& A) {
 
 // mixture / grid.  fp32 state on dense blocks: the panel kernels with the model's policy (the grid
 // runs its independent models one after the other, each on its own column of the (m, G) arrays);
-// everything else (ragged blocks, fp64 state, K > kPanelMaxK): the generic kernels.
+// everything else (ragged blocks, fp64 state, K > kPanelWideMaxK): the generic kernels.
 int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_active, int n_active,
                       const int32_t* h_active) {
     viprs_plan* P = S->plan;
@@ -169,9 +169,9 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         EStepArgs<float> A = make_args<float>(S, dq);
         A.active = d_active;
         A.n_active = n_active;
-        const bool panel_ok = !P->dense_h.empty() && (model == kGenGrid || S->width <= kPanelMaxK);
+        const bool panel_ok = !P->dense_h.empty() && (model == kGenGrid || S->width <= kPanelWideMaxK);
         if (panel_ok && model == kGenMixture) {
-            rc = launch_panel_u(P, A, kPanelMixture);
+            rc = launch_panel_u(P, A, S->width <= kPanelMaxK ? kPanelMixture : kPanelMixtureWide);
         } else if (panel_ok && model == kGenGrid && use_grid_mfma(P, A.width)) {
             // matrix-core path: chunks of 32 models, each LD row read once per chunk
             for (int off = 0; off < n_active && rc == VIPRS_OK; off += kGridModels) {

@@ -433,6 +433,30 @@ struct MixtureModel {
     }
 };
 
+// e_step_mixture for kPanelMaxK < K <= kPanelWideMaxK components: the K + 1 components of one SNP on K + 1 lanes as
+// in MixtureModel, but (i) the component inputs of the coming SNPs are prefetched from global memory into a ring of
+// registers (the (m, K) arrays keep a SNP's K values contiguous: one 128-byte line per SNP and array) and the
+// per-component outputs are stored straight from the chain -- no LDS staging that would grow with K; (ii) the
+// reference's ordered sums (softmax denominator e_step.hpp:231-240, eta :519-523) run as scalar chains over
+// v_readlane values: KMAX terms whatever K is -- the terms of lanes > K are exactly neutral (e = +0, gamma = 0).
+template <int KMAX>
+struct MixtureWideModel {
+    static constexpr bool kLaneParallel = true;
+    static constexpr bool kWide = true;
+    static constexpr int kMax = KMAX;
+    struct In { float lnp, beta, eta_old; int K; };
+    static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {
+        In in;
+        in.K = A.width;
+        in.lnp = live ? A.log_null_pi[j] : 0.0f;
+        in.beta = live ? A.std_beta[j] : 0.0f;
+        in.eta_old = live ? A.eta[j] : 0.0f;
+        return in;
+    }
+};
+template <typename M, typename = void> struct is_wide_mixture { static constexpr bool value = false; };
+template <typename M> struct is_wide_mixture<M, std::enable_if_t<M::kWide>> { static constexpr bool value = true; };
+
 // One role of the sweep kernel below: a workgroup either works as member `wg % team_size` of team `wg / team_size`
 // on the statically assigned blocks of a team class (TEAM), or pulls blocks from the small-block queue.
 template <typename U, typename MODEL, bool SYM, int NW, bool TEAM, int CPL>
@@ -449,7 +473,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     float* lmx = lT + 2 * kPanel * kPanel;              // mixture chain only (kMixLdsFloats)
     // upper-triangular form: eta_diff of the last two panels and the running second-pass sums s[j] of the block
     // (panel_upper_lds_floats; behind the mixture scratch)
-    float* led = lmx + (MODEL::kLaneParallel ? kMixLdsFloats : 0);
+    float* led = lmx + ((MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value) ? kMixLdsFloats : 0);
     float* ls = led + 2 * kPanel;
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     __shared__ int s_blk;
@@ -628,7 +652,92 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     }
 
                     PPROF(2, true);
-                    if constexpr (MODEL::kLaneParallel) {
+                    if constexpr (is_wide_mixture<MODEL>::value) {
+                        constexpr int KMAX = MODEL::kMax;
+                        const int K = in.K;
+                        const int kc = min(lane, K - 1);                   // lanes >= K: harmless copies of component K - 1
+                        const bool comp = lane < K;
+                        float dvec = 0.0f, avec = 0.0f;                    // lane j: eta_diff / dq * eta_diff of SNP j
+                        // component inputs of SNP (r0 + jj), lanes 0 .. K-1; SNPs past the block are clamped (never used)
+                        const int64_t jlast = s0 + b - 1;
+                        auto cptr = [&](const float* __restrict__ arr, int jj) {
+                            return arr + min(s0 + r0 + jj, jlast) * K + kc;
+                        };
+                        static_assert(kChainPrefetch == 16 && kPanel == 64, "window indexing");
+                        float win[kChainPrefetch], rmm[kChainPrefetch], rsv[kChainPrefetch], rul[kChainPrefetch];
+#pragma unroll
+                        for (int k = 0; k < kChainPrefetch; ++k) {
+                            win[k] = drow[k];
+                            rmm[k] = *cptr(A.mu_mult, k);
+                            rsv[k] = *cptr(A.shvt, k);
+                            rul[k] = *cptr(A.u_logs, k);
+                        }
+#pragma unroll 1
+                        for (int g = 0; g < kPanel / kChainPrefetch; ++g) {
+#pragma unroll
+                        for (int k = 0; k < kChainPrefetch; ++k) {
+                            const int jj = kChainPrefetch * g + k;                             // wave-uniform
+                            const float drow_jj = win[k];
+                            const float cmm = rmm[k], csv = rsv[k], cul = rul[k];
+                            {
+                                const U* __restrict__ src = (g < kPanel / kChainPrefetch - 1)
+                                    ? dptr + (int64_t)min(jj + kChainPrefetch, last) * stride
+                                    : nptr + (int64_t)min(k, b - 1 - rn0) * stride;
+                                win[k] = static_cast<float>(*src);
+                                // (the ring runs on into the next panel; past the block it re-reads the last SNP)
+                                rmm[k] = *cptr(A.mu_mult, jj + kChainPrefetch);
+                                rsv[k] = *cptr(A.shvt, jj + kChainPrefetch);
+                                rul[k] = *cptr(A.u_logs, jj + kChainPrefetch);
+                            }
+                            const float qj = rl(qc, jj), lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
+                            const float r = rl(in.beta, jj) - qj;                              // :505
+                            const float mu = cmm * r;                                          // :509
+                            const float t = csv * mu;
+                            float u = __builtin_fmaf(t, t, cul);                               // :511
+                            u = (lane == K) ? lnp : u;
+                            // max over lanes 0..K (order-free): prefix max inside each row of 16 lanes, rows combined
+                            float mx = dpp_max_shr<1>(u);
+                            mx = dpp_max_shr<2>(mx);
+                            mx = dpp_max_shr<4>(mx);
+                            mx = dpp_max_shr<8>(mx);
+                            const float m_lo = rl(mx, 15), m_hi = rl(mx, K);
+                            mx = (K >= 16) ? fmaxf(m_lo, m_hi) : m_hi;                         // c_max, :58-71
+                            float e = expf_glibc_nonpos<kLookupPerLane>(u - mx, tab);
+                            e = (lane <= K) ? e : 0.0f;                                        // neutral terms beyond the null component
+                            // softmax denominator, :231-240: s = ((e_0 + e_1) + ...) + e_null, a scalar chain
+                            float ssum = rl(e, 0);
+#pragma unroll
+                            for (int i = 1; i <= KMAX; ++i) ssum += rl(e, i);
+                            const float gam = comp ? e / ssum : 0.0f;                          // :239
+                            // eta_diff, :519-523: d = fma(gam_k, mu_k, d) for k = 0 .. K-1 (gam = 0 beyond: exact no-ops)
+                            float d = -eta_old;
+#pragma unroll
+                            for (int i = 0; i < KMAX; ++i) d = __builtin_fmaf(rl(gam, i), rl(mu, i), d);
+                            const bool livej = jj < nrows;                                     // wave-uniform
+                            const float a = livej ? dq * d : 0.0f;
+                            if (comp && livej && member == 0) {
+                                const int64_t o = (s0 + r0 + jj) * K + lane;                   // (m, K) C-order
+                                A.var_mu[o] = mu;
+                                A.var_gamma[o] = gam;
+                            }
+                            int l = lane;
+                            asm volatile("" : "+v"(l));
+                            const bool me = (l == jj);
+                            dvec = me ? d : dvec;
+                            avec = me ? a : avec;
+                            qc = __builtin_fmaf(drow_jj, a, qc);
+                            if (SYM) qc = (me && livej) ? qc - d : qc;                         // :527
+                        }
+                        }
+#pragma unroll
+                        for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[k];
+                        if (member == 0 && live) {
+                            A.eta_diff[j] = dvec;
+                            if (TEAM) A.eta_out[j] = in.eta_old + dvec; else A.eta[j] = in.eta_old + dvec;   // :536
+                        }
+                        a_prev = avec;
+                        if (!SYM) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
+                    } else if constexpr (MODEL::kLaneParallel) {
                         // Mixture chain: the K components (and the null component, lane K) of ONE SNP
                         // are evaluated on K + 1 lanes -- one expf, one divide per SNP instead of K + 1
                         // and K; the ordered sums of the reference (softmax denominator, e_step.hpp:231-240;

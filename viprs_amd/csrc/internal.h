@@ -175,7 +175,7 @@ int comm_reduce_on_stream(viprs_comm* C, double* d_vec, int n, int group, hipStr
 
 // ---- kernel families (one translation unit per family and LD element type) ------------------------
 enum { kGenSpikeSlab = 0, kGenMixture = 1, kGenGrid = 2 };
-enum { kPanelSpikeSlab = 0, kPanelGridColumn = 1, kPanelMixture = 2 };
+enum { kPanelSpikeSlab = 0, kPanelGridColumn = 1, kPanelMixture = 2, kPanelMixtureWide = 3 };
 enum { kBandSpikeSlab = 0, kBandGridColumn = 1, kBandMixture = 2 };
 
 // generic kernels over one block list: `dense` = the repacked dense blocks, otherwise the ragged blocks
