@@ -417,8 +417,8 @@ def main():
                 "bound": "hbm",
                 "kernel": ("estep_grid_mfma_kernel (one workgroup per LD block, LD read once for all models)"
                            + (" + estep_grid_upper_epilogue_kernel" if ld.low_memory else "")) if args.model == "grid" else
-                          ("estep_panel_kernel (3 size classes on 3 streams; the largest two share blocks between CUs)"
-                           + (" + estep_upper_epilogue_kernel" if ld.low_memory else "")),
+                          ("estep_sweep_kernel (ONE launch per sweep: team workgroups for the large LD blocks, small-block workers "
+                           "behind them" + ("; the upper-triangular form's second pass runs inside it" if ld.low_memory else "") + ")"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n_gpus),
                 "traffic": traffic, "algorithmic_bytes_per_launch": int(per_rank[0]),
                 "kernel_ms_avg": k_max_ms, "kernel_ms_p10": pct(k_ms, 10), "kernel_ms_p50": pct(k_ms, 50),
