@@ -1,0 +1,25 @@
+"""A/B of two builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
+    python tools/ab_bench.py LIB_A LIB_B [upper] [int8]   (each library runs in its own subprocess, 3 rounds)"""
+import os, subprocess, sys
+args = [a for a in sys.argv[3:]]
+code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd())
+from viprs_amd.plan import DeviceState, LDPlan
+from viprs_amd.utils import synthetic as syn
+upper = "upper" in sys.argv; dt = np.int8 if "int8" in sys.argv else np.float32
+ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper); ds = DeviceState(plan)
+ds.upload("std_beta", inp.std_beta)
+for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"): ds.upload(k, getattr(inp, k))
+for _ in range(5): ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
+ds.synchronize(); plan.timing_reset()
+for _ in range(30): ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
+ds.synchronize(); t = np.array(plan.timing_history(which=1))
+print("%.4f %.4f %.4f" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90)))
+'''
+for rnd in range(3):
+    for name, lib in (("A", sys.argv[1]), ("B", sys.argv[2])):
+        env = dict(os.environ, VIPRS_HIP_LIB=os.path.abspath(lib))
+        out = subprocess.run([sys.executable, "-c", code] + args, env=env, capture_output=True, text=True)
+        print(rnd, name, os.path.basename(lib), out.stdout.strip() or out.stderr[-300:], flush=True)

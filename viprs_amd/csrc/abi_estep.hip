@@ -95,7 +95,11 @@ int run_spike_slab(viprs_state* S, double dq) {
         HIP_TRY(hipGetLastError());
     }
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
-    HIP_TRY(hipEventRecord(ev[0], P->stream));
+    // two HIP events per sweep when the dense kernels are all there is (the common case): [2] .. [3] then also
+    // stand for the whole sweep; every event record costs stream time
+    const bool dense_only = S->float_dtype == VIPRS_F32 && !P->dense_h.empty() && P->ragged_h.empty();
+    P->ev_dense_only[P->sweeps % viprs_plan::kRing] = dense_only;
+    if (!dense_only) HIP_TRY(hipEventRecord(ev[0], P->stream));
     int rc = VIPRS_OK;
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
@@ -119,7 +123,7 @@ int run_spike_slab(viprs_state* S, double dq) {
         if (rc == VIPRS_OK) rc = launch_generic_u<double>(P, A, kGenSpikeSlab, false);
     }
     if (rc != VIPRS_OK) return rc;
-    HIP_TRY(hipEventRecord(ev[1], P->stream));
+    if (!dense_only) HIP_TRY(hipEventRecord(ev[1], P->stream));
     P->sweeps++;
     return VIPRS_OK;
 }
@@ -163,7 +167,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
     int rc = sweep_prologue(P, model == kGenGrid ? n_active : 1);
     if (rc != VIPRS_OK) return rc;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
-    HIP_TRY(hipEventRecord(ev[0], P->stream));
+    P->ev_dense_only[P->sweeps % viprs_plan::kRing] = true;      // [2] .. [3] bracket all kernels of the call
     HIP_TRY(hipEventRecord(ev[2], P->stream));
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
@@ -202,7 +206,6 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
     }
     if (rc != VIPRS_OK) return rc;
     HIP_TRY(hipEventRecord(ev[3], P->stream));
-    HIP_TRY(hipEventRecord(ev[1], P->stream));
     P->sweeps++;
     return VIPRS_OK;
 }
@@ -356,8 +359,8 @@ int viprs_e_step_grid(viprs_plan* P, int float_dtype, int G, const void* std_bet
 static int sweep_ms(viprs_plan* P, int64_t sweep, int which, double* ms) {
     hipEvent_t* ev = P->ev.data() + 4 * (sweep % viprs_plan::kRing);
     float t = 0.f;
-    if (which == 1) {
-        if (P->dense_h.empty()) { *ms = 0.0; return VIPRS_OK; }
+    if (which == 1 || P->ev_dense_only[sweep % viprs_plan::kRing]) {
+        if (which == 1 && P->dense_h.empty() && !P->ev_dense_only[sweep % viprs_plan::kRing]) { *ms = 0.0; return VIPRS_OK; }
         HIP_TRY(hipEventSynchronize(ev[3]));
         HIP_TRY(hipEventElapsedTime(&t, ev[2], ev[3]));
     } else {

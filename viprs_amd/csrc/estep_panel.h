@@ -35,6 +35,12 @@
 
 namespace viprs {
 
+#ifdef VIPRS_SWEEP_TRACE
+// profiling builds: one record {workgroup, team flag, block size, start, end (100 MHz wall clock)} per (workgroup, block)
+__device__ unsigned long long g_sweep_trace[1 << 15][4];
+__device__ unsigned int g_sweep_trace_n;
+#endif
+
 #ifdef VIPRS_PANEL_PROFILE
 #define PPROF(slot, cond) do { if (TEAM && item == 0 && member < 2 && lane == 0 && p < 64 && (cond)) s_pprof[p][slot] = (unsigned)wall_clock64(); } while (0)
 #else
@@ -544,6 +550,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         const BlockDesc bd = A.blocks[blk];
         const int64_t s0 = bd.start;
         const int b = bd.size;
+#ifdef VIPRS_SWEEP_TRACE
+        const unsigned long long trace_t0 = wall_clock64();
+#endif
         unsigned long long* __restrict__ gran =
             TEAM ? A.granules + ((int64_t)model_slot * A.granule_rows + bd.gr_off) * kPanel : nullptr;
         const int stride = bd.stride;
@@ -985,6 +994,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                 // rows past the block are clamped (their sums are never used)
                                 return base + (int64_t)min(r * kPanel + lane, b - 1) * stride + pp * kPanel;
                             };
+                            // (a separate code path for the diagonal tile measured 3 % slower than the run-time flag)
                             int r = uw;
                             while (r <= pp && !mine(r)) r += NW - 1;
                             HalfTileRows<U> h0, h1;                 // columns 0..31 / 32..63 of the current tile
@@ -1025,6 +1035,17 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     qdst[s0 + i] = SYM ? lq[i] : lq[i] + A.dq * ls[i];      // upper form: q[j] += dq * dot (e_step.hpp:335)
         }
         __syncthreads();
+#ifdef VIPRS_SWEEP_TRACE
+        if (tid == 0) {
+            const unsigned k = atomicAdd(&g_sweep_trace_n, 1u);
+            if (k < (1u << 15)) {
+                g_sweep_trace[k][0] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(TEAM ? 1 : 0);
+                g_sweep_trace[k][1] = (unsigned long long)b;
+                g_sweep_trace[k][2] = trace_t0;
+                g_sweep_trace[k][3] = wall_clock64();
+            }
+        }
+#endif
     }
     if (lane == 0 && my_skipped && member == 0) atomicAdd(A0.skipped, my_skipped);
 }

@@ -122,6 +122,7 @@ struct viprs_plan {
     // the stream the kernels are launched on
     static constexpr int kRing = 256;
     std::vector<hipEvent_t> ev;             // 4 * kRing
+    bool ev_dense_only[kRing] = {};         // ring slot: only [2] .. [3] were recorded (they bracket the whole sweep)
     int64_t sweeps = 0;                     // sweeps recorded since the last timing reset
     viprs_state* scratch = nullptr;         // state used by the one-shot host-buffer calls
 

@@ -1,2 +1,3 @@
 #define PANEL_U float
+#define PANEL_TRACE_EXPORT
 #include "launch_panel.inc"
