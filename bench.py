@@ -295,7 +295,11 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (the E-step has no CPU fallback)")
     device = local_rank % ndev
-    comm = RcclComm(rank, world, device) if world > 1 else LocalComm()     # RCCL over xGMI, C ABI; no PyTorch
+    if world > 1 and os.environ.get("VIPRS_BENCH_COMM") == "file":
+        from viprs_amd.parallel import FileComm        # dry runs of the multi-rank logic on a box RCCL cannot span
+        comm = FileComm(rank, world)
+    else:
+        comm = RcclComm(rank, world, device) if world > 1 else LocalComm()     # RCCL over xGMI, C ABI; no PyTorch
 
     def barrier():
         # every rank: device idle (hipDeviceSynchronize), then all ranks arrived (RCCL collective + stream sync)

@@ -179,10 +179,9 @@ constexpr int kStripRowsInFlight = PANEL_STRIP_DEPTH;   // row loads in flight p
 // loads next to their uses, leaving two in flight), and there is no runtime guard around any load
 // (a guard makes hipcc wait vmcnt(0) per row).  FULL = false (partial last panel of a block): rows
 // past its end are clamped to its last row; their a is 0, so fma(R, 0, q) == q leaves q untouched.
-template <typename U, int CPL, bool FULL>
+template <typename U, int CPL, bool FULL, int DEPTH = kStripRowsInFlight>
 __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int last_row, float avec,
                                              float* __restrict__ lq_c) {
-    constexpr int DEPTH = kStripRowsInFlight;
     static_assert(kPanel % DEPTH == 0, "panel must be a whole number of prefetch groups");
     float qv[CPL];
 #pragma unroll
@@ -482,6 +481,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     float* led = lmx + ((MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value) ? kMixLdsFloats : 0);
     float* ls = led + 2 * kPanel;
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
+#ifndef PANEL_TEAM_STRIP_DEPTH
+#define PANEL_TEAM_STRIP_DEPTH kStripRowsInFlight
+#endif
+    // row loads in flight per updater lane: team blocks (the critical path) may take a larger share of the memory system
+    constexpr int kDepth = TEAM ? PANEL_TEAM_STRIP_DEPTH : kStripRowsInFlight;
     __shared__ int s_blk;
 
     const int tid = threadIdx.x;
@@ -967,9 +971,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
                         if (any_a && active) {
                             if (last_row == kPanel - 1)
-                                strip_update<U, CPL, true>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
                             else
-                                strip_update<U, CPL, false>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
                         }
                         if (k == uw) PPROF(6, wave == 1);
                         if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {

@@ -264,6 +264,51 @@ class TorchDistComm:
         self._dist.barrier()
 
 
+class FileComm:
+    """Host-vector collectives through files in a shared directory: a TEST transport that lets the multi-rank host
+    logic (bench.py --gpus N, the models) run with several processes on a box whose GPUs RCCL cannot span (e.g. two
+    ranks on one device).  Never the product path."""
+    device_side = False
+
+    def __init__(self, rank=None, world_size=None, root=None):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        self.root = root or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"viprs_filecomm_{os.getuid()}_{tag}")
+        os.makedirs(self.root, exist_ok=True)
+        self._n = 0
+
+    def _exchange(self, vec):
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        self._n += 1
+        mine = os.path.join(self.root, f"{self._n}_{self.rank}.npy")
+        tmp = mine + ".tmp.npy"
+        np.save(tmp, v)
+        os.replace(tmp, mine)
+        parts = []
+        for r in range(self.world_size):
+            f = os.path.join(self.root, f"{self._n}_{r}.npy")
+            t0 = time.time()
+            while not os.path.exists(f):
+                if time.time() - t0 > 600:
+                    raise TimeoutError(f"FileComm: rank {r} never wrote step {self._n}")
+                time.sleep(0.002)
+            parts.append(np.load(f))
+        return np.stack(parts)
+
+    def allreduce_sum(self, vec):
+        return self._exchange(vec).sum(axis=0)
+
+    def allreduce_max(self, vec):
+        return self._exchange(vec).max(axis=0)
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def close(self):
+        pass
+
+
 def broadcast_from_root(comm, values):
     """Rank 0's `values` (float64 vector) on every rank: an all-reduce of a vector that is zero elsewhere."""
     v = np.asarray(values, dtype=np.float64)
