@@ -41,10 +41,10 @@ def select_best_model(viprs_grid_model, validation_gdl=None, criterion="ELBO"):
     for param in (m.pip, m.post_mean_beta, m.post_var_beta, m.var_gamma, m.var_mu, m.var_tau, m.eta, m.zeta, m.q,
                   m._log_var_tau):
         for c in param:
-            param[c] = param[c][:, best]
+            param[c] = np.ascontiguousarray(param[c][:, best])      # (a strided view is no valid download target)
     for c in m.eta_diff:
         if m.eta_diff[c].ndim == 2:
-            m.eta_diff[c] = m.eta_diff[c][:, best]
+            m.eta_diff[c] = np.ascontiguousarray(m.eta_diff[c][:, best])
     m.sigma_epsilon, m._sigma_g = m.sigma_epsilon[best], m._sigma_g[best]
     m.tau_beta, m.pi = m.tau_beta[best], m.pi[best]
     m.n_models = 1
