@@ -10,7 +10,8 @@ from viprs_amd import _lib as L
 from viprs_amd.plan import DeviceState, LDPlan
 from viprs_amd.utils import synthetic as syn
 upper = "upper" in sys.argv
-ld, ss, inp = syn.make_problem("cfg3", low_memory=upper)
+dt = np.int8 if "int8" in sys.argv else np.float32
+ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
 plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper)
 ds = DeviceState(plan)
 ds.upload("std_beta", inp.std_beta)
@@ -19,7 +20,7 @@ for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"):
 buf = (ctypes.c_ulonglong * (4 << 15))()
 fn = L.lib.viprs_debug_sweep_trace
 for it in range(4):
-    ds.reset(0.01); ds.e_step(1.0)
+    ds.reset(0.01); ds.e_step(ld.dq_scale)
     n = fn(buf, 1 << 15)
 a = np.frombuffer(buf, dtype=np.uint64)[: 4 * n].reshape(n, 4).astype(np.int64)
 wg, team, b, t0, t1 = a[:, 0] >> 32, a[:, 0] & 1, a[:, 1], a[:, 2] * 10.0, a[:, 3] * 10.0       # ns
@@ -27,7 +28,7 @@ T0 = t0.min(); t0 -= T0; t1 -= T0
 print(f"records {n}, sweep {t1.max() / 1e3:.1f} us, kernel ms {plan.last_kernel_ms(1):.3f}")
 print(f"team records {int(team.sum())}: end of team work at {t1[team == 1].max() / 1e3:.1f} us; largest block {b.max()} "
       f"resident {((t1 - t0)[b == b.max()]).max() / 1e3:.1f} us")
-es = 4
+es = np.dtype(dt).itemsize
 for lo in np.arange(0, t1.max(), 50e3):
     hi = lo + 50e3
     ov = np.clip(np.minimum(t1, hi) - np.maximum(t0, lo), 0, None)
