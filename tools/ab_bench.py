@@ -1,5 +1,5 @@
 """A/B of two builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
-    python tools/ab_bench.py LIB_A LIB_B [upper] [int8]   (each library runs in its own subprocess, 3 rounds)"""
+    python tools/ab_bench.py LIB_A LIB_B [upper] [int8] [grid|mix] [uniform]   (each library runs in its own subprocess, 3 rounds)"""
 import os, subprocess, sys
 args = [a for a in sys.argv[3:]]
 code = r'''
@@ -8,13 +8,23 @@ sys.path.insert(0, os.getcwd())
 from viprs_amd.plan import DeviceState, LDPlan
 from viprs_amd.utils import synthetic as syn
 upper = "upper" in sys.argv; dt = np.int8 if "int8" in sys.argv else np.float32
-ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
-plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper); ds = DeviceState(plan)
+sizes = np.full(1700, 650) if "uniform" in sys.argv else None      # uniform: 1700 blocks of 650 SNPs (no large-block tail)
+ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt, sizes=sizes)
+model = "grid" if "grid" in sys.argv else "mixture" if "mix" in sys.argv else "spike_slab"
+width = {"grid": 32, "mixture": 4, "spike_slab": 1}[model]
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper); ds = DeviceState(plan, "float32", model, width)
 ds.upload("std_beta", inp.std_beta)
-for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"): ds.upload(k, getattr(inp, k))
-for _ in range(5): ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
+active, pi0 = None, inp.pi
+if model == "spike_slab":
+    for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"): ds.upload(k, getattr(inp, k))
+else:
+    extra = syn.make_mixture_inputs(ss, width) if model == "mixture" else syn.make_grid_inputs(ss, width)
+    pi0 = extra.pop("pi")
+    for k, a in extra.items(): ds.upload(k, a)
+    if model == "grid": active = np.arange(width, dtype=np.int32)
+for _ in range(5): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
 ds.synchronize(); plan.timing_reset()
-for _ in range(30): ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
+for _ in range(30): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
 ds.synchronize(); t = np.array(plan.timing_history(which=1))
 print("%.4f %.4f %.4f" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90)))
 '''

@@ -17,7 +17,7 @@ for md, t1 in (("1280", "2"), ("1280", "4"), ("1024", "2"), ("1024", "4"), ("115
 CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK="1024", VIPRS_TEAM1="3", VIPRS_LARGE_BLOCK="1920"))
 CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK="1152", VIPRS_TEAM1="2", VIPRS_LARGE_BLOCK="2048", VIPRS_TEAM0="6"))
 CONFIGS.append(dict())
-KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_HELPERS", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK", "VIPRS_ADMIT_FACTOR")
+KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK")
 for cfg in CONFIGS:
     for k in KEYS:
         os.environ.pop(k, None)

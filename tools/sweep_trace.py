@@ -18,7 +18,7 @@ ds.upload("std_beta", inp.std_beta)
 for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"):
     ds.upload(k, getattr(inp, k))
 buf = (ctypes.c_ulonglong * (4 << 15))()
-fn = L.lib.viprs_debug_sweep_trace
+fn = getattr(L.lib, "viprs_debug_sweep_trace_" + ("i8" if dt == np.int8 else "f32"))
 for it in range(4):
     ds.reset(0.01); ds.e_step(ld.dq_scale)
     n = fn(buf, 1 << 15)

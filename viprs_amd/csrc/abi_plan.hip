@@ -75,9 +75,6 @@ static hipError_t launch_expand(const void* up, const int64_t* ipu, const int32_
 viprs_plan::~viprs_plan() {
     delete scratch;
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    for (auto& e : ev_join) if (e) (void)hipEventDestroy(e);
-    if (class_stream[2]) (void)hipStreamDestroy(class_stream[2]);       // [0], [1]: shared per device, never destroyed
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -108,7 +105,6 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
     // environment switches, re-read at every plan creation
-    if (const char* f = getenv("VIPRS_ADMIT_FACTOR")) P->admit_factor = atof(f);
     if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
     {
         SchedConfig c;                          // defaults
@@ -133,30 +129,6 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     P->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking));
-    {   // team classes get the highest stream priority: their workgroups must become co-resident quickly
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        // The two team classes run on streams SHARED by all plans of a device: a team kernel needs all its
-        // workgroups resident at once (members spin on each other's hand-offs), so two team kernels of the
-        // same class from different plans must never be half-resident together.  The shared streams
-        // serialise them; the streams live as long as the process.
-        static std::mutex team_mu;
-        static std::map<int, std::array<hipStream_t, 2>> team_streams;
-        {
-            std::lock_guard<std::mutex> lock(team_mu);
-            auto it = team_streams.find(device);
-            if (it == team_streams.end()) {
-                std::array<hipStream_t, 2> st{};
-                for (int c = 0; c < 2; ++c) HIP_TRY(hipStreamCreateWithPriority(&st[c], hipStreamNonBlocking, prio_hi));
-                it = team_streams.emplace(device, st).first;
-            }
-            P->class_stream[0] = it->second[0];
-            P->class_stream[1] = it->second[1];
-        }
-        HIP_TRY(hipStreamCreateWithPriority(&P->class_stream[2], hipStreamNonBlocking, prio_lo));
-    }
-    HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
-    for (auto& e : P->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     P->ev.assign(4 * viprs_plan::kRing, nullptr);
     for (auto& e : P->ev) HIP_TRY(hipEventCreate(&e));
 
@@ -323,35 +295,17 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
             }
         }
         if (P->low_memory) {
-            std::vector<EpiItem> items;
-            for (int c = 0; c < 3; ++c) {
-                P->epi_begin[c] = (int)items.size();
-                std::vector<EpiItem> cls;
-                for (int i = P->class_begin[c]; i < P->class_begin[c + 1]; ++i)
-                    for (int r0 = 0; r0 < P->dense_h[(size_t)i].size; r0 += kPanel)
-                        cls.push_back({(int32_t)(i - P->class_begin[c]), r0});        // block index inside its class
-                // longest rows first (the item cost is the number of columns right of its rows)
-                const int cb = P->class_begin[c];
-                std::stable_sort(cls.begin(), cls.end(), [&](const EpiItem& x, const EpiItem& y) {
-                    return P->dense_h[(size_t)(cb + x.blk)].size - x.row0 > P->dense_h[(size_t)(cb + y.blk)].size - y.row0;
-                });
-                items.insert(items.end(), cls.begin(), cls.end());
-            }
-            P->epi_begin[3] = (int)items.size();
-            P->n_epi = (int64_t)items.size();
-            // the same items once more with plan-wide block indices, longest first across all classes
-            // (one launch of the batched grid second pass)
+            // (block, 64-row group) items of the batched grid second pass, plan-wide block indices, longest rows
+            // first (the item cost is the number of columns right of its rows)
             std::vector<EpiItem> all;
-            for (int c = 0; c < 3; ++c)
-                for (int k = P->epi_begin[c]; k < P->epi_begin[c + 1]; ++k)
-                    all.push_back({(int32_t)(items[(size_t)k].blk + P->class_begin[c]), items[(size_t)k].row0});
+            for (int i = 0; i < (int)P->dense_h.size(); ++i)
+                for (int r0 = 0; r0 < P->dense_h[(size_t)i].size; r0 += kPanel) all.push_back({(int32_t)i, r0});
             std::stable_sort(all.begin(), all.end(), [&](const EpiItem& x, const EpiItem& y) {
                 return P->dense_h[(size_t)x.blk].size - x.row0 > P->dense_h[(size_t)y.blk].size - y.row0;
             });
+            P->n_epi = (int64_t)all.size();
             HIP_TRY(P->d_epi_all.alloc(all.size()));
             HIP_TRY(hipMemcpy(P->d_epi_all.p, all.data(), sizeof(EpiItem) * all.size(), hipMemcpyHostToDevice));
-            HIP_TRY(P->d_epi.alloc(items.size()));
-            HIP_TRY(hipMemcpy(P->d_epi.p, items.data(), sizeof(EpiItem) * items.size(), hipMemcpyHostToDevice));
         }
     }
     if (!P->ragged_h.empty()) {

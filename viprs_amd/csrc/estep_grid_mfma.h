@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
 // Upper-triangular second pass for all models at once (update_q_factor_matrix, e_step.hpp:266-303):
 //     q[g, j] += dq * dot(eta_diff[g, j+1 .. end), R[j, j+1 .. end))        for every active model g
 // as C[model][row] = sum_k E[model][k] * R[row][k] on the matrix cores -- per (model, row) the same
-// serial fma chain from 0 in column order as estep_upper_epilogue_kernel (the zero lower-left part of
+// serial fma chain from 0 in column order as the spike-and-slab second pass (the zero lower-left part of
 // the repacked block is exactly neutral), with every LD tile read once for all models.  One wave owns
 // 64 rows of a block: LD tiles are loaded row-wise (16 B per lane) and transposed through LDS so that
 // lane n supplies row n as the B operand; the eta_diff tile goes through LDS as [k][model].

@@ -18,8 +18,8 @@
 //
 // Symmetric form: columns LEFT of the current panel (q of SNPs already visited) keep receiving the
 // later rows as well (they are what the next sweep starts from); upper-triangular form: the
-// reference's second pass (update_q_factor, e_step.hpp:331-337) runs as its own fully parallel
-// kernel (estep_upper_epilogue_kernel below).
+// reference's second pass (update_q_factor, e_step.hpp:331-337) is folded into the sweep -- the
+// updater waves extend per-row running sums by one panel of columns per phase (HalfTileRows below).
 //
 // Large blocks (a single CU pulls only ~50 GB/s from HBM) are shared by a TEAM of TS workgroups on
 // TS CUs: see the comment at `team` in the kernel.
@@ -498,20 +498,6 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     const float dq = A0.dq;
     const int n_models = max(1, A0.n_active);          // grid: work items are (block, model) pairs
 
-    // Admission control (optional; thresholds computed by the host).  Blocks are queued in
-    // descending size; workgroup r starts pulling work only once the queue head has reached
-    // admit[r].  The head only moves forward and workgroup 0 is never gated: no deadlock.
-    if (A0.admit != nullptr) {
-        const int th = A0.admit[wg];
-        if (th > 0) {
-            if (tid == 0) {
-                while (__hip_atomic_load(A0.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < th)
-                    __builtin_amdgcn_s_sleep(64);
-            }
-            __syncthreads();
-        }
-    }
-
     // Teams (TS > 1): TS workgroups on TS different CUs share one large block.  Every member runs
     // the (deterministic) serial chain itself, so no a-vector ever has to be communicated; the
     // trailing updates are split by column strip (strip s belongs to member s % TS), and the owner of
@@ -601,6 +587,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         // in each): what a role keeps in registers across phases -- the chain's 64 prefetched tile rows -- is then
         // live in its own branch only and does not add to the other role's register budget.
         if (wave == 0) {
+#ifdef PANEL_CHAIN_PRIO
+        __builtin_amdgcn_s_setprio(PANEL_CHAIN_PRIO);    // the chain wave wins the issue arbitration on its SIMD
+#endif
         for (int p = 0; p < np + 1; ++p) {
             PPROF(0, true);
             {
@@ -967,7 +956,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         // symmetric form: every column except the chain's two panels (left of the
                         // chain = SNPs already visited, their q keeps accumulating for the next
                         // sweep); upper-triangular form: right of the chain only (the rest is the
-                        // reference's second pass, estep_upper_epilogue_kernel)
+                        // reference's second pass)
                         const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
                         if (any_a && active) {
                             if (last_row == kPanel - 1)
@@ -1088,75 +1077,6 @@ static __global__ void commit_team_kernel(EStepArgs<float> A0) {
     for (int i = threadIdx.x; i < bd.size; i += blockDim.x) {
         A.eta[bd.start + i] = A.eta_out[bd.start + i];
         A.q[bd.start + i] = A.q_out[bd.start + i];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Upper-triangular second pass (update_q_factor, e_step.hpp:331-337):
-//     q[j] += dq * dot(eta_diff[j+1 .. end), R[j, j+1 .. end))
-// with the dot a serial fma chain from 0 in column order (e_step.hpp:100-102).  One wave owns 64
-// rows; 64x64 tiles are loaded row-wise (coalesced), transposed through LDS so that lane r walks
-// row r in column order.  Lower-left entries of the repacked block are zero (exactly neutral).
-// ---------------------------------------------------------------------------------------------
-
-template <typename U, int NW>
-__global__ __launch_bounds__(NW * 64) void estep_upper_epilogue_kernel(EStepArgs<float> A0, const EpiItem* items,
-                                                                       int n_items, int32_t* counter) {
-    __shared__ float tile[NW][kPanel * (kPanel + 1)];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
-    float* tl = tile[wave];
-    const int n_models = max(1, A0.n_active);
-    for (;;) {
-        // persistent waves pull (block, 64-row group[, model]) items, longest rows first
-        int item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items * n_models) break;
-        const int ei = item / n_models;
-        const EStepArgs<float> A = select_model(A0, item - ei * n_models);
-        const EpiItem it = items[ei];
-        const BlockDesc bd = A.blocks[it.blk];
-        const int b = bd.size, stride = bd.stride, r0 = it.row0;
-        const int64_t s0 = bd.start;
-        const U* __restrict__ base = ldd + bd.ld_off;
-        const int nrows = min(kPanel, b - r0);
-        float s = 0.0f;
-
-        // A 64 x 64 tile = 16 row-group loads of 4 rows x 64 columns (16 B per lane for fp32), raw bytes kept in
-        // registers; the next tile's loads are all issued before the current one is consumed (the vector
-        // memory queue holds 63 loads per wave: 4-byte loads would throttle here).
-        const int trow = lane >> 4, tcol = (lane & 15) * 4;
-        RawRow<U, 4> cur[kPanel / 4], nxt[kPanel / 4];
-        const U* __restrict__ p0 = base + (int64_t)r0 * stride + tcol;
-#pragma unroll
-        for (int i = 0; i < kPanel / 4; ++i)
-            cur[i] = load_raw<U, 4>(p0 + (int64_t)min(4 * i + trow, nrows - 1) * stride + r0);
-        for (int c0 = r0; c0 < b; c0 += kPanel) {
-            const int cn = (c0 + kPanel < b) ? c0 + kPanel : c0;            // next tile (or this one again)
-#pragma unroll
-            for (int i = 0; i < kPanel / 4; ++i)
-                nxt[i] = load_raw<U, 4>(p0 + (int64_t)min(4 * i + trow, nrows - 1) * stride + cn);
-            const int col = c0 + lane;
-            const float dv = (col < b) ? A.eta_diff[s0 + col] : 0.0f;
-            asm volatile("" ::: "memory");                                  // loads stay up here (hipcc would sink them)
-            // transpose through LDS (pitch 65: conflict-free both ways): lane r walks row r
-#pragma unroll
-            for (int i = 0; i < kPanel / 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tl[(4 * i + trow) * (kPanel + 1) + tcol + e] = cur[i].get(e);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 16
-            for (int i = 0; i < kPanel; ++i) {
-                const float v = tl[lane * (kPanel + 1) + i];
-                const float di = rl(dv, i);
-                if (c0 + i > r0 + lane) s = __builtin_fmaf(v, di, s);      // strictly right of the diagonal
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < kPanel / 4; ++i) cur[i] = nxt[i];
-        }
-        if (lane < nrows) A.q[s0 + r0 + lane] += A.dq * s;
     }
 }
 

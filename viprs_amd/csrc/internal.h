@@ -57,7 +57,6 @@ struct SchedConfig {
 SchedConfig& sched_config();                       // process-wide, read from the environment at plan creation
 constexpr int kClassWaves[3] = {4, 4, 4};
 constexpr int kPlanCounters = 32;                  // work-queue heads of a plan (d_counters), zeroed by every sweep's prologue
-constexpr int kEpiWaves = 4;
 
 template <typename V> struct DevBuf {
     V* p = nullptr;
@@ -91,20 +90,13 @@ struct viprs_plan {
     // covers dense_h[class_begin[c] .. class_begin[c+1])
     int class_begin[4] = {0, 0, 0, 0};
     viprs::DevBuf<viprs::BlockDesc> d_dense, d_ragged;
-    hipStream_t class_stream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    viprs::DevBuf<viprs::EpiItem> d_epi;
     viprs::DevBuf<unsigned long long> d_granules;  // team hand-off granules (one row of 64 per panel of a team block)
     int64_t n_granule_rows = 0;
     viprs::DevBuf<int32_t> d_error;
-    viprs::DevBuf<int32_t> d_admit;                // admission thresholds of the small-block class
-    int admit_grid = 0;
-    double admit_factor = 1.5;
     int grid_mfma = -1;                     // batched grid E-step on the matrix cores: 1 always, 0 never (per-(block,
                                             // model) items), -1 when the plan has enough blocks to fill the CUs (VIPRS_GRID_MFMA)
     int64_t n_epi = 0;
-    int epi_begin[4] = {0, 0, 0, 0};        // per size class ranges of d_epi
-    viprs::DevBuf<viprs::EpiItem> d_epi_all;              // all items, plan-wide block indices, longest first
+    viprs::DevBuf<viprs::EpiItem> d_epi_all;              // upper form, batched grid second pass: (block, 64-row group) items, longest first
     viprs::DevBuf<viprs::EpiItem> d_low_items;            // symmetric form: (block, 128-column tile) items of the batched grid lower pass
     int64_t n_low_items = 0;
     viprs::DevBuf<int32_t> d_lb;

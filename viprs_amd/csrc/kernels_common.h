@@ -47,7 +47,6 @@ struct EStepArgs {
     // bottom_mod - 1 take from the small end: at any time the chip then works on a MIX of bandwidth-bound (large)
     // and chain-bound (small) blocks instead of all workgroups moving from large to small blocks in lockstep.
     int32_t bottom_mod;
-    const int32_t* admit;        // per-workgroup admission threshold on the queue head (may be null)
     unsigned long long* granules; // team kernels: {tag, value} hand-off granules (zeroed before every launch)
     int32_t* error;              // set to non-zero when a bounded spin gives up
     int32_t n_teams;             // team kernels: number of teams in the launch

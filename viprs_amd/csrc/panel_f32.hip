@@ -1,3 +1,3 @@
 #define PANEL_U float
-#define PANEL_TRACE_EXPORT
+#define PANEL_TAG f32
 #include "launch_panel.inc"

@@ -1,2 +1,3 @@
 #define PANEL_U int16_t
+#define PANEL_TAG i16
 #include "launch_panel.inc"

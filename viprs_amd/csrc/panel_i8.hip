@@ -1,2 +1,3 @@
 #define PANEL_U int8_t
+#define PANEL_TAG i8
 #include "launch_panel.inc"
