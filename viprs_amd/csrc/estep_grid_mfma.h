@@ -54,6 +54,7 @@ constexpr int kGridLdsFloats = 2 * kGridIoFloats + 2 * kGridAFloats + 2 * kGridD
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // ---- one 64-column tile on the matrix cores, split so that loads can run ahead of the MFMAs --------
 // Q[model][c0 .. c0+63] += sum_k a[model][k] * R[row0 + k][c0 ..] for the 64 rows of a panel, k
@@ -363,12 +364,13 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                     const float* drow = dg + (p & 1) * kGridDiagFloats + 32 * ch;
                     float* qmine = qx + (p & 1) * kGridQxFloats + cg * kGridQxPitch + 32 * ch;
                     // this lane's 32 columns of its model's q
-                    float qv[32];
+                    // (register pairs: the row application below is v_pk_fma_f32, two columns per instruction)
+                    f32x2 qv[16];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(qmine + 4 * i);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) qv[4 * i + e] = has_model ? v[e] : 0.0f;
+                        qv[2 * i] = has_model ? f32x2{v[0], v[1]} : f32x2{0.0f, 0.0f};
+                        qv[2 * i + 1] = has_model ? f32x2{v[2], v[3]} : f32x2{0.0f, 0.0f};
                     }
                     const float betav = A.std_beta[s0 + min(r0 + lane, b - 1)];
 #ifdef VIPRS_GRID_PROFILE
@@ -376,19 +378,18 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
 #endif
                     GPROF(2, true);
                     // row jj of the diagonal tile for this half: register c <-> column 32 h + ((c + 16 g4) & 31)
-                    float rw[32];
-                    auto load_row = [&](float (&dst)[32], int jr, int g4) {
+                    f32x2 rw[16];
+                    auto load_row = [&](f32x2 (&dst)[16], int jr, int g4) {
                         const float* rp = drow + jr * kPanel;
                         const int o0 = 16 * (g4 & 1), o1 = 16 * ((g4 + 1) & 1);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const f32x4 x = *reinterpret_cast<const f32x4*>(rp + o0 + 4 * i);
                             const f32x4 y = *reinterpret_cast<const f32x4*>(rp + o1 + 4 * i);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                dst[4 * i + e] = x[e];
-                                dst[16 + 4 * i + e] = y[e];
-                            }
+                            dst[2 * i] = f32x2{x[0], x[1]};
+                            dst[2 * i + 1] = f32x2{x[2], x[3]};
+                            dst[8 + 2 * i] = f32x2{y[0], y[1]};
+                            dst[8 + 2 * i + 1] = f32x2{y[2], y[3]};
                         }
                     };
                     load_row(rw, 0, 0);
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                             const float mm_n = iob[0 * kGridIoArr + jn], ulog_n = iob[1 * kGridIoArr + jn],
                                         hvt_n = iob[2 * kGridIoArr + jn], eta_n = iob[3 * kGridIoArr + jn];
                             // the SNP's own q from the half that owns its column
-                            const unsigned qbits = __float_as_uint(qv[k]);
+                            const unsigned qbits = __float_as_uint(qv[k >> 1][k & 1]);
                             auto sw = __builtin_amdgcn_permlane32_swap(qbits, qbits, false, false);
                             const float qcur = __uint_as_float(hi_owner ? sw[1] : sw[0]);
                             const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
@@ -418,14 +419,15 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                             const float a = (live && has_model) ? dq * d : 0.0f;
                             // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order)
                             __builtin_amdgcn_sched_barrier(0);
-                            float rn[32];
+                            f32x2 rn[16];
                             load_row(rn, jn, (jj + 1) >> 4);
+                            const f32x2 a2 = {a, a};
 #pragma unroll
-                            for (int c = 0; c < 32; ++c) {                               // :623
-                                qv[c] = __builtin_fmaf(rw[c], a, qv[c]);
+                            for (int c = 0; c < 16; ++c) {                               // :623, one IEEE fma per column
+                                qv[c] = __builtin_elementwise_fma(rw[c], a2, qv[c]);
                                 asm volatile("" : "+v"(qv[c]));      // apply now (hipcc would sink the chain to its use)
                             }
-                            if (SYM) qv[k] -= (live && owner && has_model) ? d : 0.0f;   // :629
+                            if (SYM) qv[k >> 1][k & 1] -= (live && owner && has_model) ? d : 0.0f;   // :629
                             if (has_model && live && ch == 0) {
                                 iob[0 * kGridIoArr + jj] = mu;
                                 iob[1 * kGridIoArr + jj] = gamma;
@@ -435,22 +437,22 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                             if (ch == 0) lap[jj * kGridModels] = a;
                             mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n;
 #pragma unroll
-                            for (int c = 0; c < 32; ++c) rw[c] = rn[c];
+                            for (int c = 0; c < 16; ++c) rw[c] = rn[c];
                             __builtin_amdgcn_sched_barrier(0);       // keep the prefetch distance at one SNP
                         }
                         // rotate the q registers by one group of 16 columns
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            const float t = qv[c];
-                            qv[c] = qv[16 + c];
-                            qv[16 + c] = t;
+                        for (int c = 0; c < 8; ++c) {
+                            const f32x2 t = qv[c];
+                            qv[c] = qv[8 + c];
+                            qv[8 + c] = t;
                         }
                     }
                     GPROF(3, true);
                     if (has_model) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            *reinterpret_cast<f32x4*>(qmine + 4 * i) = f32x4{qv[4 * i], qv[4 * i + 1], qv[4 * i + 2], qv[4 * i + 3]};
+                            *reinterpret_cast<f32x4*>(qmine + 4 * i) = f32x4{qv[2 * i][0], qv[2 * i][1], qv[2 * i + 1][0], qv[2 * i + 1][1]};
                     }
                 }
             } else {
