@@ -295,11 +295,29 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (the E-step has no CPU fallback)")
     device = local_rank % ndev
+    comm_kind = "rccl" if world > 1 else "none"
     if world > 1 and os.environ.get("VIPRS_BENCH_COMM") == "file":
+        comm_kind = "file transport (VIPRS_BENCH_COMM=file)"
         from viprs_amd.parallel import FileComm        # dry runs of the multi-rank logic on a box RCCL cannot span
         comm = FileComm(rank, world)
+    elif world > 1:
+        # RCCL over xGMI through the C ABI (no PyTorch).  Should the communicator not come up on this node, the run
+        # still completes over the file transport -- with the barriers' file-system latency inside the timed region,
+        # which the JSON line then says (`comm`).
+        from viprs_amd.parallel import FileComm
+        side = FileComm(rank, world)
+        try:
+            comm, err = RcclComm(rank, world, device), ""
+        except Exception as e:                          # noqa: BLE001 -- any failure leads to the same fallback
+            comm, err = None, f"{type(e).__name__}: {e}"
+        n_ok = int(round(float(side.allreduce_sum(np.array([1.0 if comm is not None else 0.0]))[0])))
+        if n_ok != world:
+            if comm is not None:
+                comm.close()
+            comm = side
+            comm_kind = f"file transport (RCCL communicator came up on {n_ok} of {world} ranks; rank {rank}: {err or 'ok'})"
     else:
-        comm = RcclComm(rank, world, device) if world > 1 else LocalComm()     # RCCL over xGMI, C ABI; no PyTorch
+        comm = LocalComm()
 
     def barrier():
         # every rank: device idle (hipDeviceSynchronize), then all ranks arrived (RCCL collective + stream sync)
@@ -411,6 +429,7 @@ def main():
                 "largest_block": int(np.max(sizes_all)),
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
                 "math_mode": args.math, "skipped_snps_last_sweep_rank0": int(skipped),
+                "comm": comm_kind,
                 "parallelism": (f"ld-blocks x{n_gpus} (strong: chain-aware LPT, no data-path collective; RCCL barrier / max only)"
                                 if strong else f"one workload per GPU x{n_gpus}") if n_gpus > 1 else "single GPU",
                 "step": "device state re-init + one E-step sweep over all blocks",

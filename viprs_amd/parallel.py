@@ -134,15 +134,23 @@ class LocalComm:
         pass
 
 
+_COMM_SEQ = 0
+
+
 def _exchange_unique_id(rank, world_size, make_id, timeout_s=300.0):
     """Rank 0's RCCL unique id reaches the other ranks of the node through a file (atomic rename): no
     PyTorch, no extra port.  VIPRS_COMM_ID_FILE names it explicitly; by default it is keyed on the
     launcher (the parent process all ranks share under torch.distributed.run / a shell loop) and on
     MASTER_PORT."""
+    global _COMM_SEQ
     path = os.environ.get("VIPRS_COMM_ID_FILE")
     if not path:
         tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"viprs_comm_{os.getuid()}_{tag}.id")
+    # every communicator of a process gets its own file (all ranks create them in the same order): a rank can never
+    # pick up the id of the previous communicator while rank 0 is still removing that file
+    path = f"{path}.{_COMM_SEQ}"
+    _COMM_SEQ += 1
     if rank == 0:
         uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
