@@ -231,17 +231,16 @@ template <typename U> struct HalfTileRows {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = load_raw<U, C>(rowp + C * i);
     }
-    // s += sum_c R[row, c0 + c] * ed[c0 + c] in column order (diag: columns right of the row's own column only)
-    template <int C0>
-    __device__ __forceinline__ float accumulate(float s, float edv, bool diag, int lane) const {
+    // s += sum_c R[row, c0 + c] * ed[c0 + c] in column order
+    // `ed`: eta_diff of the 32 columns, wave-uniform (read once per column half and phase, not once per tile).  No
+    // mask for the diagonal tile: the repacked block holds exact zeros on and left of the diagonal (abi_plan.hip,
+    // repack_dense_kernel on a zeroed buffer), and fma(0, e, s) == s bit for bit -- s starts at +0 and a sum of
+    // products is never -0 in round-to-nearest.
+    __device__ __forceinline__ float accumulate(float s, const float (&ed)[kPanel / 2]) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
 #pragma unroll
-            for (int e = 0; e < C; ++e) {
-                const int c = C0 + C * i + e;
-                const float t = __builtin_fmaf(v[i].get(e), rl(edv, c), s);
-                s = (!diag || c > lane) ? t : s;
-            }
+            for (int e = 0; e < C; ++e) s = __builtin_fmaf(v[i].get(e), ed[C * i + e], s);
         }
         return s;
     }
@@ -987,21 +986,38 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                 // rows past the block are clamped (their sums are never used)
                                 return base + (int64_t)min(r * kPanel + lane, b - 1) * stride + pp * kPanel;
                             };
-                            // (a separate code path for the diagonal tile measured 3 % slower than the run-time flag)
                             int r = uw;
                             while (r <= pp && !mine(r)) r += NW - 1;
-                            HalfTileRows<U> h0, h1;                 // columns 0..31 / 32..63 of the current tile
-                            if (r <= pp) h0.load(rowptr(r));
-                            while (r <= pp) {
-                                int rn = r + NW - 1;
-                                while (rn <= pp && !mine(rn)) rn += NW - 1;
-                                h1.load(rowptr(r) + kPanel / 2);
-                                float* __restrict__ sl = ls + r * kPanel + lane;
-                                float sv = h0.template accumulate<0>(*sl, edv, r == pp, lane);
-                                if (rn <= pp) h0.load(rowptr(rn));
-                                *sl = h1.template accumulate<kPanel / 2>(sv, edv, r == pp, lane);
-                                r = rn;
-                            }
+                            // Column half by column half (a row's sum still takes its columns in order): the 32 eta_diff
+                            // values of a half are read into SGPRs once and serve all tiles of the wave; the two row
+                            // buffers alternate between consecutive tiles.
+                            const int r_first = r;
+                            auto second_pass_half = [&](auto half_c) {
+                                constexpr int H = decltype(half_c)::value;
+                                float ed[kPanel / 2];
+#pragma unroll
+                                for (int c = 0; c < kPanel / 2; ++c) ed[c] = rl(edv, H * (kPanel / 2) + c);
+                                HalfTileRows<U> h0, h1;
+                                int r = r_first;
+                                if (r <= pp) h0.load(rowptr(r) + H * (kPanel / 2));
+                                while (r <= pp) {
+                                    int rn = r + NW - 1;
+                                    while (rn <= pp && !mine(rn)) rn += NW - 1;
+                                    if (rn <= pp) h1.load(rowptr(rn) + H * (kPanel / 2));
+                                    float* __restrict__ sl = ls + r * kPanel + lane;
+                                    *sl = h0.accumulate(*sl, ed);
+                                    r = rn;
+                                    if (r > pp) break;
+                                    rn = r + NW - 1;
+                                    while (rn <= pp && !mine(rn)) rn += NW - 1;
+                                    if (rn <= pp) h0.load(rowptr(rn) + H * (kPanel / 2));
+                                    sl = ls + r * kPanel + lane;
+                                    *sl = h1.accumulate(*sl, ed);
+                                    r = rn;
+                                }
+                            };
+                            second_pass_half(std::integral_constant<int, 0>{});
+                            second_pass_half(std::integral_constant<int, 1>{});
                         }
                     }
                 }
