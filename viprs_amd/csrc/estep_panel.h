@@ -360,7 +360,7 @@ struct GridColumnModel {
 
 // e_step_mixture (e_step.hpp:496-537) for K <= kPanelMaxK components ((m, K) arrays C-ordered).
 struct MixtureModel {
-    // the chain evaluates the K + 1 components of ONE SNP on K + 1 lanes (see the chain in estep_panel_kernel)
+    // the chain evaluates the K + 1 components of ONE SNP on K + 1 lanes (see the chain in panel_role)
     static constexpr bool kLaneParallel = true;
     struct In { float mm[kPanelMaxK], sv[kPanelMaxK], ulog[kPanelMaxK]; float lnp, beta, eta_old; int K; };
     static __device__ __forceinline__ In load(const EStepArgs<float>& A, int64_t j, bool live) {

@@ -55,7 +55,7 @@ struct EStepArgs {
     unsigned long long* skipped; // skip-branch counter (e_step.hpp:410-413)
     // row addressing for the generic kernels: row j holds rowlen[j] elements starting at element
     // rowstart[j] of ld_rows, covering columns lb[j] .. lb[j] + rowlen[j] - 1.  (Either the caller's
-    // own concatenated layout or the repacked dense blocks, see api.hip.)
+    // own concatenated layout or the repacked dense blocks, see abi_plan.hip.)
     const int32_t* lb;
     const int64_t* rowstart;
     const int32_t* rowlen;
