@@ -231,6 +231,47 @@ template <typename U> struct HalfTileRows {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = load_raw<U, C>(rowp + C * i);
     }
+    // The same half tile with COALESCED loads: instruction i covers rows i * 64 / N .. of the row panel, N lanes per
+    // row (one 16-byte piece each) -- 8 .. 32 cache lines per instruction instead of 64.  `to_rows` then hands every
+    // lane the N pieces of its own row through a 32-row LDS buffer of the wave (two rounds; pieces rotated by the row
+    // so that both the 16-byte writes and the 16-byte reads are conflict-free).
+    static constexpr int kRowBytes = N * 16;
+    static constexpr int kRowsPerLoad = kPanel / N;
+    static constexpr int kBufBytes = 32 * kRowBytes;
+    static __device__ __forceinline__ int rot(int row) { return (row / (8 / N)) % N; }
+    __device__ __forceinline__ void load_co(const U* __restrict__ col0, int64_t stride, int row0, int b, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int row = min(row0 + i * kRowsPerLoad + lane / N, b - 1);      // rows past the block: clamped, never used
+            v[i] = load_raw<U, C>(col0 + (int64_t)row * stride + (lane % N) * C);
+        }
+    }
+    __device__ __forceinline__ void to_rows(char* __restrict__ buf, int lane) {
+        static_assert(N == 2 || N == 4 || N == 8, "pieces per row");
+        RawRow<U, C> out[N];
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+#pragma unroll
+            for (int k = 0; k < N / 2; ++k) {
+                const int i = round * (N / 2) + k;
+                const int row = k * kRowsPerLoad + lane / N;                      // 0 .. 31 within the round
+                const int slot = (lane % N + rot(row)) % N;
+                *reinterpret_cast<uint4*>(buf + row * kRowBytes + slot * 16) = uint4{v[i].w[0], v[i].w[1], v[i].w[2], v[i].w[3]};
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == round) {
+                const int row = lane & 31;
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(buf + row * kRowBytes + ((c + rot(row)) % N) * 16);
+                    out[c].w[0] = t.x; out[c].w[1] = t.y; out[c].w[2] = t.z; out[c].w[3] = t.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = out[c];
+    }
     // s += sum_c R[row, c0 + c] * ed[c0 + c] in column order
     // `ed`: eta_diff of the 32 columns, wave-uniform (read once per column half and phase, not once per tile).  No
     // mask for the diagonal tile: the repacked block holds exact zeros on and left of the diagonal (abi_plan.hip,
@@ -479,7 +520,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     // (panel_upper_lds_floats; behind the mixture scratch)
     float* led = lmx + ((MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value) ? kMixLdsFloats : 0);
     float* ls = led + 2 * kPanel;
+    // upper-triangular form: one 32-row transposition buffer per updater wave (HalfTileRows::to_rows), behind ls[qcap]
+    char* tbuf = reinterpret_cast<char*>(ls + qcap) + (threadIdx.x >> 6 ? (threadIdx.x >> 6) - 1 : 0) * kPanelUpperTransposeBytes;
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
+    constexpr bool kSecondPassViaLds = !(MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value);
 #ifndef PANEL_TEAM_STRIP_DEPTH
 #define PANEL_TEAM_STRIP_DEPTH kStripRowsInFlight
 #endif
@@ -982,10 +1026,6 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             // this wave's tiles: row panels r = uw, uw + NU, ... <= pp (teams: of the member's own strips);
                             // the next tile's 16 row loads are in flight while the current tile is accumulated
                             auto mine = [&](int r) { return !TEAM || (((r * kPanel) / kSW) % TS) == member; };
-                            auto rowptr = [&](int r) {
-                                // rows past the block are clamped (their sums are never used)
-                                return base + (int64_t)min(r * kPanel + lane, b - 1) * stride + pp * kPanel;
-                            };
                             int r = uw;
                             while (r <= pp && !mine(r)) r += NW - 1;
                             // Column half by column half (a row's sum still takes its columns in order): the 32 eta_diff
@@ -998,20 +1038,29 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #pragma unroll
                                 for (int c = 0; c < kPanel / 2; ++c) ed[c] = rl(edv, H * (kPanel / 2) + c);
                                 HalfTileRows<U> h0, h1;
+                                const U* __restrict__ col0 = base + pp * kPanel + H * (kPanel / 2);
+                                // coalesced loads + transposition through the wave's LDS buffer; the K <= 8 mixture (whose
+                                // chain scratch takes that LDS) loads lane-per-row
+                                auto fetch = [&](HalfTileRows<U>& h, int rr) {
+                                    if constexpr (kSecondPassViaLds) h.load_co(col0, stride, rr * kPanel, b, lane);
+                                    else h.load(col0 + (int64_t)min(rr * kPanel + lane, b - 1) * stride);
+                                };
                                 int r = r_first;
-                                if (r <= pp) h0.load(rowptr(r) + H * (kPanel / 2));
+                                if (r <= pp) fetch(h0, r);
                                 while (r <= pp) {
                                     int rn = r + NW - 1;
                                     while (rn <= pp && !mine(rn)) rn += NW - 1;
-                                    if (rn <= pp) h1.load(rowptr(rn) + H * (kPanel / 2));
+                                    if (rn <= pp) fetch(h1, rn);
                                     float* __restrict__ sl = ls + r * kPanel + lane;
+                                    if constexpr (kSecondPassViaLds) h0.to_rows(tbuf, lane);
                                     *sl = h0.accumulate(*sl, ed);
                                     r = rn;
                                     if (r > pp) break;
                                     rn = r + NW - 1;
                                     while (rn <= pp && !mine(rn)) rn += NW - 1;
-                                    if (rn <= pp) h0.load(rowptr(rn) + H * (kPanel / 2));
+                                    if (rn <= pp) fetch(h0, rn);
                                     sl = ls + r * kPanel + lane;
+                                    if constexpr (kSecondPassViaLds) h1.to_rows(tbuf, lane);
                                     *sl = h1.accumulate(*sl, ed);
                                     r = rn;
                                 }

@@ -12,7 +12,10 @@ constexpr int kStrip = 256;         // padding unit of the per-block q arrays (o
 // panel kernels (estep_panel.h): LDS carve (floats) q[qcap] | a[2][64] | T[2][64*64]
 __host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
 // upper-triangular form: eta_diff[2][64] of the last two panels + the running second-pass sums s[qcap]
-__host__ __device__ constexpr int panel_upper_lds_floats(int qcap) { return 2 * kPanel + qcap; }
+constexpr int kPanelUpperTransposeBytes = 32 * 128;         // per updater wave: 32 rows of a half tile (fp32: 128 B per row)
+__host__ __device__ constexpr int panel_upper_lds_floats(int qcap, int n_waves = 4) {
+    return 2 * kPanel + qcap + (n_waves - 1) * kPanelUpperTransposeBytes / 4;
+}
 constexpr int kPanelMaxK = 8;       // mixture components the lane-parallel panel chain handles with DPP scans
 constexpr int kPanelWideMaxK = 31;  // ... and with scalar chains over v_readlane values (MixtureWideModel)
 // LDS of the lane-parallel mixture chain: mu_mult | sqrt_half_var_tau | u_logs | var_mu | var_gamma, [64 SNPs][K]
