@@ -52,7 +52,7 @@ struct SchedConfig {
     int class_team_mix[3] = {4, 1, 1};
     bool team_env = false;                         // VIPRS_TEAM0/1 given: they apply to every model
     // small-block queue: every `bottom_mod`-th workgroup pulls from the SMALL end of the size-sorted queue (0 = off)
-    int bottom_mod = 3;                            // VIPRS_BOTTOM_MOD
+    int bottom_mod = 0;                            // VIPRS_BOTTOM_MOD
 };
 SchedConfig& sched_config();                       // process-wide, read from the environment at plan creation
 constexpr int kClassWaves[3] = {4, 4, 4};
