@@ -79,3 +79,18 @@ def test_cfg3_grid_32_models_equal_oracle_on_four_columns(genome):
     for k in H.STATE:
         for g in cols:
             assert np.array_equal(got[k][:, g], ref[k][:, g]), (k, int(g), int((got[k][:, g] != ref[k][:, g]).sum()))
+
+
+def test_cfg3_int8_upper_whole_state_equals_oracle(gpu):
+    """The combination the reference runs by default on its published LD stores: int8-quantised LD
+    (dq_scale = 1 / 127), upper-triangular form (second pass on coalesced 32-byte row pieces)."""
+    from viprs_amd.plan import LDPlan
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=True, ld_dtype=np.int8)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)
+    try:
+        ref = H.run_oracle(ld, inp, inp.state_copy(), sweeps=1)
+        got = _sweep(plan, "spike_slab", 1, {k: getattr(inp, k) for k in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult")},
+                     inp.pi, ld.dq_scale)
+        H.assert_state_equal(got, ref)
+    finally:
+        plan.close()
