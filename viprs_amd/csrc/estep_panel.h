@@ -219,8 +219,10 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
 // done PROGRESSIVELY inside the sweep: when the chain has finished column panel `pp`, the tiles R[r, pp] of all
 // row panels r <= pp extend the running sums s[j] of their rows by the panel's 64 columns -- columns still arrive in
 // ascending order for every row, so the sums are the reference's, bit for bit.  One wave per tile, lane = row: each
-// lane walks its own row (16-byte loads along the row; the four loads of a 64-byte line hit L1), eta_diff of the
-// panel comes in by v_readlane.  DIAG: the tile on the diagonal counts columns right of the row only.
+// lane runs the fma chain of its own row; the tile is loaded coalesced and handed to the rows through LDS (load_co /
+// to_rows) or, where that LDS is not available, lane by lane along the rows (load); eta_diff of a column half sits in
+// SGPRs for all tiles of a wave and phase.  The tile on the diagonal needs no mask: its entries on and left of the
+// diagonal are stored zeros.
 // (half a tile = 32 columns of 64 rows per unit, so that the next unit's loads can be in flight while the current one
 // is accumulated without a second tile's worth of registers)
 template <typename U> struct HalfTileRows {
@@ -1024,7 +1026,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         const float edv = led[(pp & 1) * kPanel + lane];
                         if (__ballot(edv != 0.0f) != 0) {
                             // this wave's tiles: row panels r = uw, uw + NU, ... <= pp (teams: of the member's own strips);
-                            // the next tile's 16 row loads are in flight while the current tile is accumulated
+                            // the next tile's loads of the same column half are in flight while the current one is accumulated
                             auto mine = [&](int r) { return !TEAM || (((r * kPanel) / kSW) % TS) == member; };
                             int r = uw;
                             while (r <= pp && !mine(r)) r += NW - 1;
