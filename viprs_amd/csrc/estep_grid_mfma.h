@@ -399,14 +399,18 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                     for (int g4 = 0; g4 < kPanel / 16; ++g4) {
                         const bool hi_owner = g4 >= 2;                                   // columns 32.. belong to half 1
                         const bool owner = (ch == 1) == hi_owner;
+                        // (one LDS base per group of 16 SNPs: the SNP index inside the group is an immediate offset)
+                        float* const iog = iob + 16 * g4;
+                        float* const lag = lap + 16 * g4 * kGridModels;
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
                             const int jj = 16 * g4 + k;                                  // wave-uniform
                             const bool live = jj < nrows;
                             // next SNP's inputs: in flight while this one is evaluated
                             const int jn = min(jj + 1, kPanel - 1);
-                            const float mm_n = iob[0 * kGridIoArr + jn], ulog_n = iob[1 * kGridIoArr + jn],
-                                        hvt_n = iob[2 * kGridIoArr + jn], eta_n = iob[3 * kGridIoArr + jn];
+                            const int kn = (k < 15) ? k + 1 : ((g4 < kPanel / 16 - 1) ? 16 : 15);   // = jn - 16 g4
+                            const float mm_n = iog[0 * kGridIoArr + kn], ulog_n = iog[1 * kGridIoArr + kn],
+                                        hvt_n = iog[2 * kGridIoArr + kn], eta_n = iog[3 * kGridIoArr + kn];
                             // the SNP's own q from the half that owns its column
                             const unsigned qbits = __float_as_uint(qv[k >> 1][k & 1]);
                             auto sw = __builtin_amdgcn_permlane32_swap(qbits, qbits, false, false);
@@ -429,12 +433,12 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                             }
                             if (SYM) qv[k >> 1][k & 1] -= (live && owner && has_model) ? d : 0.0f;   // :629
                             if (has_model && live && ch == 0) {
-                                iob[0 * kGridIoArr + jj] = mu;
-                                iob[1 * kGridIoArr + jj] = gamma;
-                                iob[2 * kGridIoArr + jj] = d;
-                                iob[3 * kGridIoArr + jj] = eta_old + d;                   // :633
+                                iog[0 * kGridIoArr + k] = mu;
+                                iog[1 * kGridIoArr + k] = gamma;
+                                iog[2 * kGridIoArr + k] = d;
+                                iog[3 * kGridIoArr + k] = eta_old + d;                    // :633
                             }
-                            if (ch == 0) lap[jj * kGridModels] = a;
+                            if (ch == 0) lag[k * kGridModels] = a;
                             mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n;
 #pragma unroll
                             for (int c = 0; c < 16; ++c) rw[c] = rn[c];
