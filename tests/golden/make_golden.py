@@ -29,9 +29,9 @@ def ld_arrays(ld):
                 dq_scale=np.float64(ld.dq_scale), low_memory=np.bool_(ld.low_memory), block_start=ld.block_start)
 
 
-def spike_slab(name, sizes, low_memory, ld_dtype=np.float32, T=np.float32, seed=101, banded=None):
+def spike_slab(name, sizes, low_memory, ld_dtype=np.float32, T=np.float32, seed=101, banded=None, ld_kind="ar1"):
     ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed,
-                                   float_precision=T)
+                                   float_precision=T, kind=ld_kind)
     if banded is not None:
         ld = banded(ld)
     out = dict(kind="e_step", **ld_arrays(ld), std_beta=inp.std_beta, u_logs=inp.u_logs,
@@ -70,8 +70,8 @@ def to_banded(width):
     return f
 
 
-def mixture(name, sizes, low_memory, K=4, seed=103):
-    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, seed=seed)
+def mixture(name, sizes, low_memory, K=4, seed=103, ld_kind="ar1", ld_dtype=np.float32):
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, seed=seed, kind=ld_kind, ld_dtype=ld_dtype)
     mix, st = _mixture_inputs(ld, ss, K)
     out = dict(kind="e_step_mixture", **ld_arrays(ld), std_beta=inp.std_beta, log_null_pi=mix["log_null_pi"],
                u_logs=mix["u_logs"], sqrt_half_var_tau=mix["shvt"], mu_mult=mix["mu_mult"])
@@ -88,8 +88,8 @@ def mixture(name, sizes, low_memory, K=4, seed=103):
     print(name)
 
 
-def grid(name, sizes, low_memory, G=32, active=None, seed=107):
-    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, seed=seed)
+def grid(name, sizes, low_memory, G=32, active=None, seed=107, ld_kind="ar1", ld_dtype=np.float32):
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, seed=seed, kind=ld_kind, ld_dtype=ld_dtype)
     g, st = _grid_inputs(ld, ss, G)
     active = np.arange(G, dtype=np.int32) if active is None else np.asarray(active, dtype=np.int32)
     out = dict(kind="e_step_grid", **ld_arrays(ld), std_beta=inp.std_beta, u_logs=g["u_logs"],
@@ -107,8 +107,28 @@ def grid(name, sizes, low_memory, G=32, active=None, seed=107):
     print(name)
 
 
+def far_field():
+    """Round 3: fixtures whose FAR field matters (non-Toeplitz long-range blocks / sample correlations of simulated
+    genotypes, viprs_amd/utils/synthetic.py).  With the AR(1) blocks above every LD entry more than ~128 columns off
+    the diagonal is below half an ulp of q; here zeroing them changes every output (tests/test_synthetic.py)."""
+    spike_slab("ss_lr_sym_f32", [420, 37], False, ld_kind="longrange", seed=111)
+    spike_slab("ss_lr_upper_f32", [420, 37], True, ld_kind="longrange", seed=111)
+    spike_slab("ss_sample_sym_int8", [400], False, ld_dtype=np.int8, ld_kind="sample", seed=112)
+    spike_slab("ss_sample_upper_int8", [400, 66], True, ld_dtype=np.int8, ld_kind="sample", seed=112)
+    spike_slab("ss_lr_upper_int16", [330], True, ld_dtype=np.int16, ld_kind="longrange", seed=113)
+    mixture("mix_k4_lr_sym_int8", [450], False, ld_kind="longrange", ld_dtype=np.int8, seed=114)
+    mixture("mix_k4_lr_upper_f32", [330], True, ld_kind="longrange", seed=114)
+    grid("grid_g32_lr_sym_int8", [390], False, ld_kind="longrange", ld_dtype=np.int8, seed=115,
+         active=[0, 31, 5, 12, 13, 22])
+    grid("grid_g32_sample_upper_int8", [400], True, ld_kind="sample", ld_dtype=np.int8, seed=116,
+         active=[7, 1, 30])
+
+
 if __name__ == "__main__":
     assert O.have_reference(), "oracle/_ref not built: run `make -C oracle` where /root/reference exists"
+    if sys.argv[1:] == ["far_field"]:          # add the round-3 fixtures without touching the older files
+        far_field()
+        sys.exit(0)
     spike_slab("ss_cfg1_sym_f32", [500], False)                     # BASELINE configs[0]
     spike_slab("ss_cfg1_upper_f32", [500], True)
     spike_slab("ss_ragged3_sym_f32", [37, 128, 300], False)        # block discovery, partial panels
@@ -122,3 +142,4 @@ if __name__ == "__main__":
     mixture("mix_k4_upper", [50, 210], True)
     grid("grid_g32_sym", [64, 150], False)
     grid("grid_g32_partial_upper", [64, 150], True, active=[3, 9, 30, 17])
+    far_field()

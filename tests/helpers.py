@@ -30,6 +30,31 @@ def run_hip(ld, inp, state, sweeps=1):
     return st
 
 
+def cut_far_field(ld, width=128):
+    """A copy of `ld` (block LD of `synthetic.make_ld`, either form) with every entry more than `width`
+    columns off the diagonal set to 0 -- the probe for "does this input exercise the far field at all"."""
+    import copy
+    out = copy.copy(ld)
+    data = ld.ld_data.copy()
+    for bi in range(len(ld.block_start) - 1):
+        s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+        b = e - s
+        if b <= width + 1:
+            continue
+        o = int(ld.ld_indptr[s])
+        if ld.low_memory:
+            for r in range(b - 1 - width):           # row r holds columns r+1 .. b-1
+                n = b - 1 - r
+                data[o + width:o + n] = 0
+                o += n
+        else:
+            M = data[o:o + b * b].reshape(b, b)
+            i = np.arange(b)
+            M[np.abs(i[:, None] - i[None, :]) > width] = 0
+    out.ld_data = data
+    return out
+
+
 def assert_close(got, ref, rtol=RTOL_F32, what=""):
     """|got - ref| <= rtol * max(|ref|, floor), floor = 1e-7 * max|ref| (SURVEY.md 8c parity metric)."""
     scale = float(np.max(np.abs(ref))) if ref.size else 0.0

@@ -46,7 +46,26 @@ def _initial(fx):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 12
+    assert len(FIXTURES) >= 21
+
+
+FAR = [p for p in FIXTURES if "_lr_" in os.path.basename(p) or "_sample_" in os.path.basename(p)]
+
+
+@pytest.mark.parametrize("path", FAR, ids=[os.path.basename(p)[:-4] for p in FAR])
+def test_far_field_fixtures_are_sensitive_to_the_far_field(path):
+    """The round-3 fixtures exist because AR(1) LD cannot see a wrong far-from-diagonal update: cutting every
+    entry more than 128 columns off the diagonal must change what the oracle computes from them."""
+    from types import SimpleNamespace
+    fx = _load(path)
+    ld = SimpleNamespace(ld_data=fx["ld_data"], ld_indptr=fx["ld_indptr"], block_start=fx["block_start"],
+                         low_memory=bool(fx["low_memory"]))
+    cut = dict(fx, ld_data=H.cut_far_field(ld, 128).ld_data)
+    st, st_cut = _initial(fx), _initial(fx)
+    _call(O, fx, st, kind="restated")
+    _call(O, cut, st_cut, kind="restated")
+    assert np.array_equal(st["q"], fx["out1_q"])
+    assert (st_cut["q"] != st["q"]).mean() > 0.5 * (st["q"] != fx["in_q"]).mean()
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])

@@ -1,7 +1,8 @@
 """GPU: the WHOLE 1.1 M-SNP state of BASELINE configs[2..4] against the oracle, bit for bit, in BOTH LD forms.
 
 One sweep from the standard start (var_gamma = pi, everything else 0) over the genome-wide workload
-(1 700 LD blocks, 953 M LD entries): spike-and-slab, the K = 4 sparse mixture and the 32-model grid
+(1 700 LD blocks, 953 M LD entries of the generator's long-range, non-Toeplitz kind: every entry of every
+block changes the result, see tests/test_gpu_farfield.py): spike-and-slab, the K = 4 sparse mixture and the 32-model grid
 (oracle on 4 of its columns -- the models of a grid are independent).  The symmetric form AND the
 upper-triangular form, which is the reference's default (`low_memory=True`, VIPRS.py:75).  The
 single-threaded oracle needs a few seconds per case on the GPU box's host.
@@ -20,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def genome(request, gpu):
     from viprs_amd.plan import LDPlan
     low_memory = request.param
-    ld, ss, inp = syn.make_problem("cfg3", low_memory=low_memory)
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=low_memory, kind="longrange")
     plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory)
     yield ld, ss, inp, plan
     plan.close()
@@ -85,7 +86,7 @@ def test_cfg3_int8_upper_whole_state_equals_oracle(gpu):
     """The combination the reference runs by default on its published LD stores: int8-quantised LD
     (dq_scale = 1 / 127), upper-triangular form (second pass on coalesced 32-byte row pieces)."""
     from viprs_amd.plan import LDPlan
-    ld, ss, inp = syn.make_problem("cfg3", low_memory=True, ld_dtype=np.int8)
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=True, ld_dtype=np.int8, kind="longrange")
     plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)
     try:
         ref = H.run_oracle(ld, inp, inp.state_copy(), sweeps=1)

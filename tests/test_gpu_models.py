@@ -9,6 +9,9 @@ from viprs_amd.utils import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 STATE = ("var_gamma", "var_mu", "eta", "q", "eta_diff")
+# long-range, non-Toeplitz LD: every entry of a block changes the result (synthetic.py; AR(1) blocks are blind
+# to everything further than ~2 panels from the diagonal)
+KIND = "longrange"
 
 
 def _run_mix(mod, ld, inp, mix, st0, sweeps, **kw):
@@ -26,7 +29,7 @@ def _run_mix(mod, ld, inp, mix, st0, sweeps, **kw):
 @pytest.mark.parametrize("K", [1, 4, 8, 9, 10, 15, 16, 20, 31, 33])
 def test_mixture_matches_oracle(gpu, K, low_memory):
     from viprs_amd.vi import e_step_hip as S
-    ld, ss, inp = syn.make_problem(sizes=[70, 1400, 333, 2400], low_memory=low_memory, seed=31)   # single workgroups + a team block
+    ld, ss, inp = syn.make_problem(sizes=[70, 1400, 333, 2400], low_memory=low_memory, seed=31, kind=KIND)   # single workgroups + a team block
     mix, st0 = _mixture_inputs(ld, ss, K)
     ref = _run_mix(O, ld, inp, mix, st0, 2)
     got = _run_mix(S, ld, inp, mix, st0, 2)
@@ -40,7 +43,7 @@ def test_mixture_matches_oracle(gpu, K, low_memory):
 def test_grid_matches_oracle(gpu, low_memory, mfma, monkeypatch):
     from viprs_amd.vi import e_step_hip as S
     monkeypatch.setenv("VIPRS_GRID_MFMA", mfma)
-    ld, ss, inp = syn.make_problem(sizes=[130, 1300, 64], low_memory=low_memory, seed=33)
+    ld, ss, inp = syn.make_problem(sizes=[130, 1300, 64], low_memory=low_memory, seed=33, kind=KIND)
     g, st0 = _grid_inputs(ld, ss, 32)
     active = np.array([31, 0, 7, 8, 21], dtype=np.int32)[::1]
     out = {}
@@ -73,7 +76,7 @@ def test_grid_mfma_model_counts(gpu, G, n_active, low_memory, monkeypatch):
     """Batched kernel: fewer than / exactly / more than 32 models (chunks of 32), scattered active lists."""
     from viprs_amd.vi import e_step_hip as S
     monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
-    ld, ss, inp = syn.make_problem(sizes=[200, 96, 333], low_memory=low_memory, seed=35)
+    ld, ss, inp = syn.make_problem(sizes=[200, 96, 333], low_memory=low_memory, seed=35, kind=KIND)
     g, st0 = _grid_inputs(ld, ss, G)
     active = np.random.default_rng(G).permutation(G)[:n_active].astype(np.int32)
     ref = _run_grid(O, ld, inp, g, st0, active)
@@ -88,7 +91,7 @@ def test_grid_mfma_model_counts(gpu, G, n_active, low_memory, monkeypatch):
 def test_grid_mfma_quantised_ld(gpu, ld_dtype, low_memory, monkeypatch):
     from viprs_amd.vi import e_step_hip as S
     monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
-    ld, ss, inp = syn.make_problem(sizes=[150, 520, 77], low_memory=low_memory, ld_dtype=ld_dtype, seed=36)
+    ld, ss, inp = syn.make_problem(sizes=[150, 520, 77], low_memory=low_memory, ld_dtype=ld_dtype, seed=36, kind=KIND)
     g, st0 = _grid_inputs(ld, ss, 12)
     active = np.arange(12, dtype=np.int32)
     ref = _run_grid(O, ld, inp, g, st0, active)
@@ -104,7 +107,7 @@ def test_grid_mfma_block_shapes(gpu, monkeypatch):
     from viprs_amd.vi import e_step_hip as S
     monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
     sizes = [1, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 2, 321, 448, 449]
-    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=False, seed=37)
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=False, seed=37, kind=KIND)
     g, st0 = _grid_inputs(ld, ss, 9)
     active = np.array([8, 0, 3, 4, 1, 7], dtype=np.int32)
     ref = _run_grid(O, ld, inp, g, st0, active, sweeps=3)
@@ -120,7 +123,7 @@ def test_grid_upper_batched_equals_item_path(gpu, ld_dtype, monkeypatch):
     res = {}
     for mfma in ("0", "1"):
         monkeypatch.setenv("VIPRS_GRID_MFMA", mfma)
-        ld, ss, inp = syn.make_problem(sizes=[257, 700, 31, 129], low_memory=True, ld_dtype=ld_dtype, seed=38)
+        ld, ss, inp = syn.make_problem(sizes=[257, 700, 31, 129], low_memory=True, ld_dtype=ld_dtype, seed=38, kind=KIND)
         g, st0 = _grid_inputs(ld, ss, 11)
         res[mfma] = _run_grid(S, ld, inp, g, st0, np.arange(11, dtype=np.int32), sweeps=3)
     H.assert_state_equal(res["1"], res["0"])
@@ -131,7 +134,7 @@ def test_very_large_blocks_all_models(gpu, low_memory, monkeypatch):
     """LD blocks far beyond BASELINE's largest (6 000 SNPs): 13 000- and 9 001-SNP blocks through the
     8-CU teams, the mixture teams and the batched grid kernel -- bit-for-bit against the oracle."""
     from viprs_amd.vi import e_step_hip as S
-    ld, ss, inp = syn.make_problem(sizes=[13000, 9001, 65], low_memory=low_memory, seed=47)
+    ld, ss, inp = syn.make_problem(sizes=[13000, 9001, 65], low_memory=low_memory, seed=47, kind=KIND)
     st0 = inp.state_copy()
     H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=1), H.run_oracle(ld, inp, st0, sweeps=1))
     mix, mst0 = _mixture_inputs(ld, ss, 4)

@@ -40,6 +40,22 @@ def test_e_step_bit_exact_all_dtypes(low_memory, T, ld_dtype, indptr_dtype):
 
 
 @needs_ref
+@pytest.mark.parametrize("low_memory", [False, True])
+@pytest.mark.parametrize("ld_dtype", [np.int8, np.int16, np.float32])
+@pytest.mark.parametrize("kind", ["longrange", "sample"])
+def test_e_step_bit_exact_on_far_field_ld(low_memory, ld_dtype, kind):
+    """LD whose far field matters (synthetic.py): the upper form's second pass (`dot`, e_step.hpp:82-104) now
+    sums terms that are NOT negligible -- the reference build's summation order is the sequential fma chain."""
+    ld, ss, inp = syn.make_problem(sizes=[37, 700, 300], low_memory=low_memory, ld_dtype=ld_dtype, seed=23, kind=kind)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, kind="reference", sweeps=3)
+    got = H.run_oracle(ld, inp, st0, kind="restated", sweeps=3)
+    H.assert_state_equal(got, ref)
+    cut = H.run_oracle(H.cut_far_field(ld, 128), inp, st0, kind="reference", sweeps=1)
+    assert (cut["q"] != H.run_oracle(ld, inp, st0, kind="reference", sweeps=1)["q"]).sum() > ld.m // 2
+
+
+@needs_ref
 def test_threads1_is_deterministic_and_skip_branch_is_hit():
     ld, ss, inp = _problem([500], False)
     st0 = inp.state_copy()

@@ -2,8 +2,20 @@
 
 The reference gets these arrays from magenpy (`LDMatrix.load()` -> ld_data / ld_indptr /
 leftmost_idx, VIPRS.py:167-172; `std_beta`, `n_per_snp`, BayesPRSModel.py:133-136); magenpy is
-not part of the reference tree, so benchmarks and tests use analytic AR(1) blocks instead:
-R[i, j] = rho^|i-j| inside a block (positive definite), nothing across blocks.
+not part of the reference tree, so benchmarks and tests use synthetic blocks instead (nothing
+across blocks).  Three kinds of block (`make_ld(kind=...)`):
+
+* ``"ar1"``  -- analytic R[i, j] = rho^|i-j| (Toeplitz, positive definite, cheapest).  Entries more than
+  ~2 panels off the diagonal are below half an ulp of `q`, so an E-step result does NOT depend on them:
+  good for timing, blind as a parity input for everything far from the diagonal.
+* ``"longrange"`` -- S (alpha A + (1 - alpha)(U U^T + D)) S: A the AR(1) matrix, U a b x 2 factor loading
+  with entries of magnitude 0.3-0.7, D = diag(1 - |u_i|^2), S random signs.  Unit diagonal, positive
+  definite, NOT Toeplitz, every entry of a block is O(0.05-0.3) wherever it sits: each LD entry the
+  kernel streams changes the result.  O(b) parameters per block, so summary statistics stay cheap at
+  genome scale.
+* ``"sample"`` -- SURVEY 8d's "realistic" variant: the sample correlation of n = 4 b simulated AR(1)
+  genotypes (noise of size 1/sqrt(n) everywhere in the block on top of the AR(1) decay).  O(b^3): for
+  blocks up to a few thousand SNPs.
 """
 from dataclasses import dataclass, field
 
@@ -39,6 +51,8 @@ class SyntheticLD:
     low_memory: bool
     dq_scale: float = 1.0
     meta: dict = field(default_factory=dict)
+    kind: str = "ar1"
+    params: list = None            # "longrange": per block (alpha, U (b, r) with the signs folded in, signs (b,))
 
     @property
     def m(self):
@@ -65,15 +79,83 @@ def _fill_block(data, off, b, row, low_memory):
     else:
         vals = np.concatenate([row[::-1], row[1:]])         # R[r, :] = vals[b-1-r : 2b-1-r]
         dst = data[off:off + b * b].reshape(b, b)
-        for r in range(b):
-            dst[r] = vals[b - 1 - r:2 * b - 1 - r]
+        dst[...] = np.lib.stride_tricks.as_strided(vals[b - 1:], shape=(b, b), strides=(-vals.itemsize, vals.itemsize))
+
+
+def _store_dense_block(data, off, R, low_memory, ld_dtype, quant_max):
+    """Write the dense b x b correlation matrix `R` (float) of one block into `data` at `off` in the symmetric
+    (whole rows) or the upper-triangular layout (row j = R[j, j+1:]), quantised magenpy-style for integer LD."""
+    b = R.shape[0]
+    if quant_max is not None:
+        R = np.round(R * min(float(quant_max), 2.0 ** 30 if ld_dtype == np.int32 else 2.0 ** 52))
+    if low_memory:
+        o = off
+        for r in range(b - 1):
+            data[o:o + b - 1 - r] = R[r, r + 1:]
+            o += b - 1 - r
+    else:
+        dst = data[off:off + b * b].reshape(b, b)
+        if dst is not R:
+            dst[...] = R
+
+
+def _longrange_params(rng, b, n_factors=2):
+    """(alpha, U with the signs folded in, signs): R = S (alpha A + (1 - alpha)(U0 U0^T + D)) S."""
+    alpha = float(rng.uniform(0.4, 0.7))
+    signs = np.where(rng.random(b) < 0.5, -1.0, 1.0)
+    U0 = rng.uniform(0.3, 0.7, (b, n_factors)) * np.where(rng.random((b, n_factors)) < 0.5, -1.0, 1.0)
+    # |u_i|^2 <= 0.98 < 1 for two factors: D = diag(1 - |u_i|^2) > 0
+    return alpha, U0 * signs[:, None], signs
+
+
+def _longrange_block(b, rho, alpha, U, signs, out=None):
+    """Dense float32 long-range block: alpha s_i s_j rho^|i-j| + (1 - alpha) u_i . u_j off the diagonal, 1 on it.
+    Built from outer products (exactly symmetric), a handful of passes over the b x b array."""
+    f32 = np.float32
+    pw = np.power(np.float64(rho), np.arange(b)).astype(f32)
+    vals = np.concatenate([pw[::-1], pw[1:]])
+    T = np.lib.stride_tricks.as_strided(vals[b - 1:], shape=(b, b), strides=(-vals.itemsize, vals.itemsize))
+    M = np.empty((b, b), dtype=f32) if out is None else out
+    Uf = (U * np.sqrt(1.0 - alpha)).astype(f32)
+    np.multiply.outer(Uf[:, 0], Uf[:, 0], out=M)
+    for k in range(1, Uf.shape[1]):
+        M += np.multiply.outer(Uf[:, k], Uf[:, k])
+    sf = signs.astype(f32)
+    tmp = np.multiply(T, (sf * f32(alpha))[:, None])
+    tmp *= sf[None, :]
+    M += tmp
+    np.fill_diagonal(M, 1.0)
+    return M
+
+
+def _sample_block(rng, b, rho, n_mult=4):
+    """Sample correlation (float64) of n = n_mult * b AR(1) genotype vectors (the "realistic" variant)."""
+    n = n_mult * b
+    Z = rng.standard_normal((n, b))
+    X = np.empty((n, b))
+    X[:, 0] = Z[:, 0]
+    sd = np.sqrt(1.0 - rho * rho)
+    for t in range(1, b):
+        X[:, t] = rho * X[:, t - 1] + sd * Z[:, t]
+    X -= X.mean(axis=0)
+    X /= np.sqrt((X * X).sum(axis=0))
+    R = X.T @ X
+    R = 0.5 * (R + R.T)
+    np.fill_diagonal(R, 1.0)
+    return R
+
+
+LD_KINDS = ("ar1", "longrange", "sample")
 
 
 def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8),
-            rho=None):
-    """Block-diagonal AR(1) LD in symmetric (`low_memory=False`: every row of a block stores the whole
+            rho=None, kind="ar1"):
+    """Block-diagonal LD in symmetric (`low_memory=False`: every row of a block stores the whole
     block, diagonal included) or upper-triangular form (`low_memory=True`: row j stores columns
-    j+1 .. block_end-1, left bound j+1) -- the two layouts e_step.hpp:389-392,423-440 consumes."""
+    j+1 .. block_end-1, left bound j+1) -- the two layouts e_step.hpp:389-392,423-440 consumes.
+    `kind`: "ar1" | "longrange" | "sample" (module docstring)."""
+    if kind not in LD_KINDS:
+        raise ValueError(f"unknown LD kind {kind!r}")
     sizes = np.asarray(sizes, dtype=np.int64)
     rng = np.random.default_rng(seed + 1)
     rho = rng.uniform(rho_range[0], rho_range[1], len(sizes)) if rho is None else np.asarray(rho, dtype=np.float64)
@@ -107,9 +189,26 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
             rowlen[s:s + b] = b
             off += b * b
 
+    params = None
+    if kind == "longrange":
+        prng = np.random.default_rng(seed + 3)
+        params = [_longrange_params(prng, int(b)) for b in sizes]
+    elif kind == "sample":
+        # one generator per block so that the thread pool below cannot change the draws
+        params = [np.random.default_rng([seed + 4, bi]) for bi in range(len(sizes))]
+
     def _job(j):
         o, b, bi = j
-        _fill_block(data, o, b, _ar1_row(b, rho[bi], ld_dtype, quant_max), low_memory)
+        if kind == "ar1":
+            _fill_block(data, o, b, _ar1_row(b, rho[bi], ld_dtype, quant_max), low_memory)
+        elif kind == "longrange":
+            direct = (not low_memory) and ld_dtype == np.float32
+            out = data[o:o + b * b].reshape(b, b) if direct else None
+            R = _longrange_block(b, rho[bi], *params[bi], out=out)
+            if not direct:
+                _store_dense_block(data, o, R, low_memory, ld_dtype, quant_max)
+        else:
+            _store_dense_block(data, o, _sample_block(params[bi], b, rho[bi]), low_memory, ld_dtype, quant_max)
 
     if nnz > (1 << 24):
         from concurrent.futures import ThreadPoolExecutor
@@ -120,7 +219,22 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
         for j in jobs:
             _job(j)
     indptr = np.concatenate([[0], np.cumsum(rowlen)]).astype(indptr_dtype)
-    return SyntheticLD(lb, indptr, data, starts, rho, bool(low_memory), dq_scale)
+    return SyntheticLD(lb, indptr, data, starts, rho, bool(low_memory), dq_scale, kind=kind,
+                       params=params if kind == "longrange" else None)
+
+
+def dense_block(ld, bi):
+    """The dense float64 correlation matrix of block `bi`, rebuilt from the stored arrays (dequantised)."""
+    s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+    b = e - s
+    o = int(ld.ld_indptr[s])
+    if ld.low_memory:
+        R = np.eye(b)
+        for r in range(b - 1):
+            R[r, r + 1:] = ld.ld_data[o:o + b - 1 - r] * ld.dq_scale
+            o += b - 1 - r
+        return R + np.triu(R, 1).T
+    return ld.ld_data[o:o + b * b].reshape(b, b).astype(np.float64) * ld.dq_scale
 
 
 @dataclass
@@ -131,8 +245,25 @@ class SyntheticSumstats:
     n: float
 
 
+def _ar1_profile_and_noise(b, rho, idx, coef, zz):
+    """(A beta, e) for the AR(1) matrix A = rho^|i-j|: `A beta` for the sparse vector with entries `coef` at `idx`
+    as a sum of shifted geometric profiles, `e ~ N(0, A)` by the AR(1) recursion driven by `zz`."""
+    k = np.arange(b)
+    rb = np.zeros(b)
+    for c, v in zip(idx, coef):
+        rb += v * np.power(rho, np.abs(k - c))
+    eps = np.empty(b)
+    eps[0] = zz[0]
+    sd = np.sqrt(1.0 - rho * rho)
+    for t in range(1, b):
+        eps[t] = rho * eps[t - 1] + sd * zz[t]
+    return rb, eps
+
+
 def make_sumstats(ld, n=1e5, h2=0.2, pi=0.01, seed=SEED, float_precision=np.float32):
-    """std_beta = R beta + e, e ~ N(0, R / N), beta spike-and-slab."""
+    """std_beta = R beta + e, e ~ N(0, R / N), beta spike-and-slab.  `R` is the block's model
+    matrix (before quantisation); AR(1) and long-range blocks need O(b) work per block, sample-correlation
+    blocks a Cholesky factor of the stored matrix."""
     rng = np.random.default_rng(seed + 2)
     m = ld.m
     causal = rng.random(m) < pi
@@ -140,23 +271,28 @@ def make_sumstats(ld, n=1e5, h2=0.2, pi=0.01, seed=SEED, float_precision=np.floa
     beta = np.zeros(m)
     beta[causal] = rng.normal(0.0, np.sqrt(h2 / n_causal), int(causal.sum()))
     z = rng.standard_normal(m)
+    kind = getattr(ld, "kind", "ar1")
+    zrng = np.random.default_rng(seed + 5) if kind == "longrange" else None
     std_beta = np.empty(m)
     for bi in range(len(ld.rho)):
         s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
         b = e - s
         rho = ld.rho[bi]
-        k = np.arange(b)
-        # R beta for sparse beta: sum of shifted geometric profiles
-        rb = np.zeros(b)
-        for c in np.nonzero(causal[s:e])[0]:
-            rb += beta[s + c] * np.power(rho, np.abs(k - c))
-        # AR(1) noise with covariance R
-        eps = np.empty(b)
-        zz = z[s:e]
-        eps[0] = zz[0]
-        sd = np.sqrt(1.0 - rho * rho)
-        for t in range(1, b):
-            eps[t] = rho * eps[t - 1] + sd * zz[t]
+        idx = np.nonzero(causal[s:e])[0]
+        bb = beta[s:e]
+        if kind == "ar1":
+            rb, eps = _ar1_profile_and_noise(b, rho, idx, bb[idx], z[s:e])
+        elif kind == "longrange":
+            alpha, U, signs = ld.params[bi]
+            d = 1.0 - (U * U).sum(axis=1)
+            ab, ea = _ar1_profile_and_noise(b, rho, idx, signs[idx] * bb[idx], z[s:e])
+            rb = alpha * signs * ab + (1.0 - alpha) * (U @ (U[idx].T @ bb[idx]) + d * bb)
+            zf, zd = zrng.standard_normal(U.shape[1]), zrng.standard_normal(b)
+            eps = np.sqrt(alpha) * signs * ea + np.sqrt(1.0 - alpha) * (U @ zf + np.sqrt(d) * zd)
+        else:
+            R = dense_block(ld, bi)
+            rb = R[:, idx] @ bb[idx]
+            eps = np.linalg.cholesky(R + 1e-6 * np.eye(b)) @ z[s:e]
         std_beta[s:e] = rb + eps / np.sqrt(n)
     return SyntheticSumstats(std_beta.astype(float_precision), np.full(m, float(n)), beta, float(n))
 
@@ -206,9 +342,9 @@ def make_inputs(ss, pi=0.01, sigma_epsilon=0.8, h2=0.2, float_precision=np.float
 
 
 def make_problem(config="cfg1", low_memory=False, ld_dtype=np.float32, seed=SEED, sizes=None,
-                 indptr_dtype=np.int64, float_precision=np.float32):
+                 indptr_dtype=np.int64, float_precision=np.float32, kind="ar1"):
     sizes = block_sizes(config, seed) if sizes is None else np.asarray(sizes)
-    ld = make_ld(sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, indptr_dtype=indptr_dtype)
+    ld = make_ld(sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, indptr_dtype=indptr_dtype, kind=kind)
     ss = make_sumstats(ld, seed=seed, float_precision=float_precision)
     inp = make_inputs(ss, float_precision=float_precision)
     return ld, ss, inp
