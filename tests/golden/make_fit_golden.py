@@ -66,14 +66,17 @@ def install_stubs():
     return GWADataLoader
 
 
-def make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed):
+def make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed, ld_kind="ar1"):
     """Array-backed loader with the attributes VIPRS.__init__/BayesPRSModel.__init__ read
     (VIPRS.py:153-191, BayesPRSModel.py:59-142)."""
     lds, sss, inputs = {}, {}, {}
     for ci, (chrom, sizes) in enumerate(chrom_sizes.items()):
-        ld_sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci)
-        ld_up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci)
+        ld_sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci, kind=ld_kind)
+        ld_up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci, kind=ld_kind)
         ss = syn.make_sumstats(ld_sym, seed=seed + ci)
+        # marginal effects of a second cohort on the same LD (same causal effects, independent noise): what
+        # BayesPRSModel.pseudo_validate() scores the fit against (BayesPRSModel.py:184-187, 397-410)
+        ss.validation_std_beta = syn.make_sumstats(ld_sym, seed=seed + ci, noise_seed=seed + ci + 5000).std_beta
 
         class LOP:
             def __init__(self, l):
@@ -132,15 +135,29 @@ def main():
         ("fit_ss_2chr_upper", VIPRS, {21: [200, 180], 22: [150, 330]}, dict(low_memory=True), {}),
         ("fit_ss_fixed_sigma", VIPRS, {22: [400, 260]}, dict(low_memory=True, fix_params={"sigma_epsilon": 0.85}), {}),
         ("fit_mix_k4_upper", VIPRSMix, {22: [300, 250, 350]}, dict(low_memory=True, K=4), {}),
+        # round 3: LD whose far field matters (long-range, non-Toeplitz blocks), int8-quantised and dequantised
+        # on the fly -- the reference's published store format and its default LD form; the fixture carries the
+        # int8 upper-triangular LD itself
+        ("fit_ss_lr_int8_upper", VIPRS, {22: [420, 300, 180]}, dict(low_memory=True, dequantize_on_the_fly=True),
+         dict(ld_kind="longrange", ld_dtype=np.int8)),
+        ("fit_mix_k4_lr_int8_sym", VIPRSMix, {22: [380, 150, 330]}, dict(low_memory=False, K=4, dequantize_on_the_fly=True),
+         dict(ld_kind="longrange", ld_dtype=np.int8)),
     ]
-    for name, cls, chrom_sizes, kw, fit_kw in cases:
-        gdl, inputs = make_loader(GWADataLoader, chrom_sizes, np.float32, seed=301)
+    for name, cls, chrom_sizes, kw, ld_kw in cases:
+        if ONLY and name not in ONLY:
+            continue
+        fit_kw = {}
+        ld_dtype, ld_kind = ld_kw.get("ld_dtype", np.float32), ld_kw.get("ld_kind", "ar1")
+        gdl, inputs = make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed=301, ld_kind=ld_kind)
         theta_0 = {"pi": 0.01, "sigma_epsilon": 0.8}
         if "K" in kw:                                   # no RNG: explicit mixing proportions
             theta_0 = {"pis": 0.01 * np.array([0.4, 0.3, 0.2, 0.1]), "sigma_epsilon": 0.8}
         model = cls(gdl, **kw)
         model.fit(max_iter=60, theta_0=dict(theta_0), disable_pbar=True, **fit_kw)
-        out = dict(theta0_pi=0.01, theta0_sigma_epsilon=0.8, n=gdl.n, low_memory=kw.get("low_memory", True),
+        model.validation_std_beta = {c: inputs[c][2].validation_std_beta for c in chrom_sizes}
+        out = dict(pseudo_r2=np.float64(model.pseudo_validate()),        # BayesPRSModel.py:397-410
+                   ld_kind=ld_kind, dequantize_on_the_fly=bool(kw.get("dequantize_on_the_fly", False)),
+                   theta0_pi=0.01, theta0_sigma_epsilon=0.8, n=gdl.n, low_memory=kw.get("low_memory", True),
                    K=kw.get("K", 0), theta0_pis=np.asarray(theta_0.get("pis", [])), fix_sigma_epsilon=kw.get("fix_params", {}).get("sigma_epsilon", np.nan),
                    chroms=np.array(sorted(chrom_sizes)),
                    elbo_history=np.array(model.history["ELBO"], dtype=np.float64),
@@ -154,12 +171,16 @@ def main():
             out[f"std_beta_{c}"] = ss.std_beta
             out[f"n_per_snp_{c}"] = ss.n_per_snp
             out[f"rho_{c}"] = ld_sym.rho
+            out[f"validation_std_beta_{c}"] = ss.validation_std_beta
+            if ld_kind != "ar1":                     # AR(1) LD is rebuilt from rho; anything else travels
+                out[f"ld_upper_indptr_{c}"] = ld_up.ld_indptr
+                out[f"ld_upper_data_{c}"] = ld_up.ld_data
             out[f"pip_{c}"] = model.pip[c]
             out[f"post_mean_beta_{c}"] = model.post_mean_beta[c]
             out[f"post_var_beta_{c}"] = model.post_var_beta[c]
             out[f"q_{c}"] = model.q[c]
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-        print(name, "nit", model.optim_result.nit, model.optim_result.message, "ELBO", model.history["ELBO"][-1],
+        print(name, "pseudo R2", out["pseudo_r2"], "nit", model.optim_result.nit, model.optim_result.message, "ELBO", model.history["ELBO"][-1],
               "pi", model.pi, "sig_eps", model.sigma_epsilon)
 
 
@@ -174,9 +195,11 @@ def grid_cases():
         grid = HyperparameterGrid(sigma_epsilon_steps=2, pi_steps=3, n_snps=gdl.m, h2_est=0.2, h2_se=0.1)
         model = VIPRSGrid(gdl, grid, low_memory=True)
         model.fit(pathwise=pathwise, max_iter=80, disable_pbar=True)
+        model.validation_std_beta = {c: inputs[c][2].validation_std_beta for c in chrom_sizes}
+        pseudo_r2 = np.asarray(model.pseudo_validate(), dtype=np.float64)     # one value per grid model
         vr = model.validation_result
         name = "fitgrid_pathwise" if pathwise else "fitgrid_independent"
-        out = dict(n=gdl.n, pathwise=pathwise, chroms=np.array([22]), grid_sigma_epsilon=vr["sigma_epsilon"].to_numpy(),
+        out = dict(pseudo_r2=pseudo_r2, n=gdl.n, pathwise=pathwise, chroms=np.array([22]), grid_sigma_epsilon=vr["sigma_epsilon"].to_numpy(),
                    grid_pi=vr["pi"].to_numpy(), elbo=vr["ELBO"].to_numpy().astype(np.float64),
                    converged=vr["Converged"].to_numpy(), messages=np.array(list(vr["Optimization_message"])),
                    nit=np.array([r.nit for r in model.optim_results]), tau_beta=np.asarray(model.tau_beta, dtype=np.float64),
@@ -187,13 +210,18 @@ def grid_cases():
             out[f"std_beta_{c}"] = ss.std_beta
             out[f"n_per_snp_{c}"] = ss.n_per_snp
             out[f"rho_{c}"] = ld_sym.rho
+            out[f"validation_std_beta_{c}"] = ss.validation_std_beta
             out[f"pip_{c}"] = model.pip[c]
             out[f"post_mean_beta_{c}"] = model.post_mean_beta[c]
+            out[f"post_var_beta_{c}"] = model.post_var_beta[c]
             out[f"q_{c}"] = model.q[c]
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-        print(name, "ELBO", out["elbo"], "nit", out["nit"], out["messages"][:2])
+        print(name, "pseudo R2", pseudo_r2, "ELBO", out["elbo"], "nit", out["nit"], out["messages"][:2])
 
+
+ONLY = sys.argv[1:]          # e.g. `make_fit_golden.py fit_ss_lr_int8_upper`: regenerate the named fixtures only
 
 if __name__ == "__main__":
     main()
-    grid_cases()
+    if not ONLY or any(n.startswith("fitgrid") for n in ONLY):
+        grid_cases()

@@ -26,10 +26,20 @@ def loader_from_fixture(fx):
     for c in fx["chroms"]:
         c = int(c)
         sizes, rho = fx[f"sizes_{c}"], fx[f"rho_{c}"]
-        sym = syn.make_ld(sizes, low_memory=False, rho=rho)
-        up = syn.make_ld(sizes, low_memory=True, rho=rho)
-        ld[c] = LDArrays(symmetric=(sym.ld_left_bound, sym.ld_indptr, sym.ld_data),
-                         upper=(up.ld_left_bound, up.ld_indptr, up.ld_data))
+        if f"ld_upper_data_{c}" in fx:
+            # round-3 fixtures carry their LD (long-range blocks, int8, upper-triangular store); the symmetric
+            # form is its mirror image
+            from viprs_amd.data import mirror_upper_ld
+            ip, data = fx[f"ld_upper_indptr_{c}"], fx[f"ld_upper_data_{c}"]
+            m = ip.shape[0] - 1
+            dq = 1.0 / np.iinfo(data.dtype).max if np.issubdtype(data.dtype, np.integer) else 1.0
+            ld[c] = LDArrays(symmetric=mirror_upper_ld(ip, data), upper=(np.arange(1, m + 1, dtype=np.int32), ip, data),
+                             stored_dtype=data.dtype, dq_scale=dq)
+        else:
+            sym = syn.make_ld(sizes, low_memory=False, rho=rho)
+            up = syn.make_ld(sizes, low_memory=True, rho=rho)
+            ld[c] = LDArrays(symmetric=(sym.ld_left_bound, sym.ld_indptr, sym.ld_data),
+                             upper=(up.ld_left_bound, up.ld_indptr, up.ld_data))
         ss[c] = SumstatsArrays(fx[f"std_beta_{c}"], fx[f"n_per_snp_{c}"])
     return ArrayDataLoader(ld, ss, n=float(fx["n"]))
 
@@ -37,7 +47,8 @@ def loader_from_fixture(fx):
 def build_model(fx, comm=None, e_step="oracle"):
     from viprs_amd.model import VIPRS, VIPRSMix
     K = int(fx["K"])
-    kw = dict(low_memory=bool(fx["low_memory"]), comm=comm)
+    kw = dict(low_memory=bool(fx["low_memory"]), comm=comm,
+              dequantize_on_the_fly=bool(fx["dequantize_on_the_fly"]) if "dequantize_on_the_fly" in fx else False)
     if not np.isnan(float(fx["fix_sigma_epsilon"])):
         kw["fix_params"] = {"sigma_epsilon": float(fx["fix_sigma_epsilon"])}
     if e_step == "oracle":
@@ -68,10 +79,15 @@ def check_against_fixture(model, fx, local_only=False, pi_rtol=2e-4):
         np.testing.assert_allclose(model.pip[c], fx[f"pip_{c}"], rtol=2e-3, atol=2e-6)
         np.testing.assert_allclose(model.post_mean_beta[c], fx[f"post_mean_beta_{c}"], rtol=2e-3, atol=2e-7)
         np.testing.assert_allclose(q[c], fx[f"q_{c}"], rtol=2e-3, atol=2e-6)
+        np.testing.assert_allclose(model.post_var_beta[c], fx[f"post_var_beta_{c}"], rtol=2e-3, atol=1e-9)
+    # pseudo-validation against the marginal effects of a second cohort: the reference's own
+    # BayesPRSModel.pseudo_validate() -> _streamlined_pseudo_r2 (BayesPRSModel.py:397-410, pseudo_metrics.py:130-152)
+    model.validation_std_beta = {int(c): fx[f"validation_std_beta_{int(c)}"] for c in fx["chroms"]}
+    np.testing.assert_allclose(float(model.pseudo_validate()), float(fx["pseudo_r2"]), rtol=1e-4)
 
 
 def test_fit_fixtures_present():
-    assert len(FIT) >= 5
+    assert len(FIT) >= 7
 
 
 @pytest.mark.parametrize("path", FIT, ids=[os.path.basename(p)[:-4] for p in FIT])

@@ -32,6 +32,11 @@ def _check(model, fx, rtol_elbo=2e-6, rtol_post=5e-3):
     assert model.pip[c].shape == fx[f"pip_{c}"].shape == (model.shapes[c], 6)
     np.testing.assert_allclose(model.pip[c], fx[f"pip_{c}"], rtol=rtol_post, atol=5e-6)
     np.testing.assert_allclose(model.post_mean_beta[c], fx[f"post_mean_beta_{c}"], rtol=rtol_post, atol=5e-7)
+    np.testing.assert_allclose(model.post_var_beta[c], fx[f"post_var_beta_{c}"], rtol=rtol_post, atol=1e-9)
+    # per-model pseudo-R^2 from the reference's BayesPRSModel.pseudo_validate (BayesPRSModel.py:397-410,
+    # pseudo_metrics.py:130-152) on the marginal effects of a second cohort
+    r2 = model.pseudo_validate({c: fx[f"validation_std_beta_{c}"]})
+    np.testing.assert_allclose(np.asarray(r2, dtype=np.float64), fx["pseudo_r2"], rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", ["fitgrid_pathwise", "fitgrid_independent"])
@@ -149,6 +154,9 @@ def test_posterior_table_and_pseudo_validation_cpu():
     g2.validation_result = grid.validation_result.copy()
     g2.validation_std_beta = vb
     want_best = int(np.argmax(np.where(grid.valid_terminated_models, r2, -np.inf)))
+    # ... and the reference's own per-model pseudo-R^2 on a second cohort picks the same model
+    r2_ref = grid.pseudo_validate({22: fx["validation_std_beta_22"]})
+    np.testing.assert_allclose(np.asarray(r2_ref, dtype=np.float64), fx["pseudo_r2"], rtol=1e-4)
     select_best_model(g2, criterion="pseudo_validation")
     assert g2.best_model_idx == want_best and g2.pip[22].shape == (gdl.m,)
     assert "Pseudo_Validation_R2" in g2.validation_result.columns

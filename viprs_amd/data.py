@@ -73,15 +73,18 @@ class ArrayDataLoader:
         return self.ld
 
     @classmethod
-    def synthetic(cls, chrom_sizes, ld_dtype=np.float32, seed=7209, n=1e5, forms=("symmetric", "upper"), h2=0.2):
-        """AR(1) block LD + simulated summary statistics (viprs_amd.utils.synthetic) per chromosome;
-        the total heritability `h2` is shared between the chromosomes in proportion to their SNP counts."""
+    def synthetic(cls, chrom_sizes, ld_dtype=np.float32, seed=7209, n=1e5, forms=("symmetric", "upper"), h2=0.2,
+                  kind="ar1"):
+        """Synthetic block LD (`kind`: "ar1" | "longrange" | "sample") + simulated summary statistics
+        (viprs_amd.utils.synthetic) per chromosome; the total heritability `h2` is shared between the
+        chromosomes in proportion to their SNP counts."""
         m_total = float(sum(int(np.sum(s)) for s in chrom_sizes.values()))
         from .utils import synthetic as syn
         ld, ss = {}, {}
         for ci, (chrom, sizes) in enumerate(chrom_sizes.items()):
-            sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci)
-            up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci) if "upper" in forms else None
+            sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci, kind=kind)
+            up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci, kind=kind) \
+                if "upper" in forms else None
             s = syn.make_sumstats(sym, n=n, seed=seed + ci, h2=h2 * float(np.sum(sizes)) / m_total)
             ld[chrom] = LDArrays(
                 symmetric=(sym.ld_left_bound, sym.ld_indptr, sym.ld_data) if "symmetric" in forms else None,

@@ -260,10 +260,11 @@ def _ar1_profile_and_noise(b, rho, idx, coef, zz):
     return rb, eps
 
 
-def make_sumstats(ld, n=1e5, h2=0.2, pi=0.01, seed=SEED, float_precision=np.float32):
+def make_sumstats(ld, n=1e5, h2=0.2, pi=0.01, seed=SEED, float_precision=np.float32, noise_seed=None):
     """std_beta = R beta + e, e ~ N(0, R / N), beta spike-and-slab.  `R` is the block's model
     matrix (before quantisation); AR(1) and long-range blocks need O(b) work per block, sample-correlation
-    blocks a Cholesky factor of the stored matrix."""
+    blocks a Cholesky factor of the stored matrix.  `noise_seed`: same effects `beta`, an independent draw of
+    the noise -- the marginal effects of a second cohort (validation set) on the same LD."""
     rng = np.random.default_rng(seed + 2)
     m = ld.m
     causal = rng.random(m) < pi
@@ -273,6 +274,9 @@ def make_sumstats(ld, n=1e5, h2=0.2, pi=0.01, seed=SEED, float_precision=np.floa
     z = rng.standard_normal(m)
     kind = getattr(ld, "kind", "ar1")
     zrng = np.random.default_rng(seed + 5) if kind == "longrange" else None
+    if noise_seed is not None:
+        z = np.random.default_rng([noise_seed, 0]).standard_normal(m)
+        zrng = np.random.default_rng([noise_seed, 1]) if kind == "longrange" else None
     std_beta = np.empty(m)
     for bi in range(len(ld.rho)):
         s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
