@@ -12,8 +12,11 @@ because a converged state takes the skip branch e_step.hpp:410-413 and reads no 
 E-step sweep runs over every LD block of the workload.  LD and the per-SNP inputs are resident in
 HBM before the timed region starts.
 
-Workload: BASELINE.json configs[2] -- ~1.1 M SNPs in ~1 700 LD blocks (lognormal block sizes, AR(1)
-LD), spike-and-slab prior, fp32 state, fp32 LD, symmetric form.
+Workload: BASELINE.json configs[2] -- ~1.1 M SNPs in ~1 700 LD blocks (lognormal block sizes, SURVEY.md 8d;
+long-range non-Toeplitz block LD by default, `--ld-kind ar1` for the analytic AR(1) blocks of rounds 1-2),
+spike-and-slab prior, fp32 state, fp32 LD, symmetric form.  N = 1 also times, as `config.secondary`,
+configs[3] (mixture K = 4) and configs[4] (grid of 32 models) on the same resident LD, and the reference's
+default LD form (upper-triangular) with fp32 and int8 LD.
 N > 1 (default, "strong"): the blocks of that ONE workload are sharded over the ranks (chain-aware
 LPT, viprs_amd.parallel.shard_blocks; no data-path collective) and `value` = its 1.1 M SNPs per max-
 over-ranks sweep time.  The weak-scaling figure (every rank its own genome-scale workload) is measured
@@ -54,6 +57,10 @@ def parse_args():
     ap.add_argument("--model", default="spike_slab", choices=["spike_slab", "mixture", "grid"],
                     help="spike_slab = the headline (configs[1..2]); mixture = configs[3] (VIPRSMix); grid = configs[4]")
     ap.add_argument("--width", type=int, default=0, help="mixture components K (default 4) / grid models G (default 32)")
+    ap.add_argument("--ld-kind", default="longrange", choices=["ar1", "longrange"],
+                    help="synthetic LD blocks (viprs_amd/utils/synthetic.py): longrange = non-Toeplitz blocks whose every "
+                         "entry changes the result (the data the full-size parity tests run on); ar1 = rho^|i-j| "
+                         "(rounds 1-2; the sweep time does not depend on the values)")
     ap.add_argument("--seed", type=int, default=7209)
     return ap.parse_args()
 
@@ -81,10 +88,12 @@ def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0
       1. threads=1 (the parity reference);
       2. its OpenMP path on all hardware threads -- racy Hogwild, e_step.hpp:384-387: the "reference
          multithreaded-CPU" figure, `value`;
-      3. exact block-parallel: one threads=1 call per LD block, blocks spread over all hardware threads
-         (what joblib over chromosomes does at a finer grain, bin/viprs_fit:1080-1086) -- spike-and-slab only;
-      4. variant 2 from a build with -march=x86-64-v3 (AVX2 + FMA: the portable stand-in for the
+      3. exact block-parallel: one threads=1 call per LD block, blocks handed to all hardware threads by a native
+         OpenMP loop (what joblib over chromosomes does at a finer grain, bin/viprs_fit:1080-1086) -- spike-and-slab
+         only; built with the reference's flags and with -march=x86-64-v3;
+      4. variants 1 and 2 from the build with -march=x86-64-v3 (AVX2 + FMA: the portable stand-in for the
          "-march=native" optimistic-CPU line -- the library is built where /root/reference lives, not here).
+    `best_exact` names the fastest variant whose results are reproducible (1, 3, 4_single_thread).
     Sample of 1, 2, 4: leading blocks of the same workload sized to the time budget (a mixture / grid SNP-update
     costs `width` times a spike-and-slab one); 3 runs the WHOLE workload (its sweep takes tens of ms)."""
     from oracle import oracle as O
@@ -149,76 +158,72 @@ def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0
     if kind == "reference" and O.have_reference("reference_v3"):
         variants["4_openmp_all_threads_racy_march_x86_64_v3"] = m_s / timed(lambda: one(mt, "reference_v3"), 0.15)
         variants["4_single_thread_march_x86_64_v3"] = m_s / timed(lambda: one(1, "reference_v3"), 0.15)
-    if model == "spike_slab":
-        variants["3_block_parallel_exact"] = _block_parallel_exact(ld, inp, kind, cores, budget_s * 0.2)
+    if model == "spike_slab" and kind == "reference":
+        variants["3_block_parallel_exact"] = _block_parallel_exact(ld, inp, "reference", cores, budget_s * 0.15)
+        if O.have_reference("reference_v3"):
+            variants["3_block_parallel_exact_march_x86_64_v3"] = _block_parallel_exact(ld, inp, "reference_v3", cores,
+                                                                                       budget_s * 0.1)
+    exact = {k: v for k, v in variants.items() if "racy" not in k}
+    best = max(exact, key=exact.get)
     return {
         "value": res["all_cores"], "unit": "SNP-updates/s", "cores": mt,
+        "best_exact": {"variant": best, "value": exact[best], "threads": 1 if "single" in best else cores},
         "kind": "reference" if kind == "reference" else "port",
         "sample": f"first {nb} LD blocks ({m_s} SNPs, {nnz_s} LD entries) of the same workload, model={model}"
                   + (f" width={width}" if model != "spike_slab" else "")
                   + f", state re-initialised per call, median; OpenMP threads={mt} (racy, as the reference)"
-                  + "; variant 3 = every block of the workload, one threads=1 call per block on a thread pool",
+                  + "; variants 3 = every block of the WHOLE workload, one threads=1 call per block, native OpenMP loop "
+                    f"over blocks on {cores} threads",
         "single_thread_value": res["threads1"],
         "variants": variants,
     }
 
 
 def _block_parallel_exact(ld, inp, kind, workers, budget_s):
-    """SNP-updates/s of the whole workload with one exact (threads=1) reference call per LD block, blocks
-    dealt to `workers` host threads longest first (ctypes releases the GIL; each call is plain C++)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """SNP-updates/s of the WHOLE workload with one exact (threads=1) reference call per LD block, blocks handed to
+    `workers` OpenMP threads longest first (native loop inside oracle/_ref: ref_shim.cpp `ref_e_step_blocks`)."""
     from oracle import oracle as O
-    bs = ld.block_start
-    order = np.argsort(-np.diff(bs), kind="stable")
-    blocks = []
-    for b in order:
-        s, e = int(bs[b]), int(bs[b + 1])
-        o = int(ld.ld_indptr[s])
-        blocks.append((s, e, np.ascontiguousarray(ld.ld_left_bound[s:e] - s, dtype=np.int32),
-                       np.ascontiguousarray(ld.ld_indptr[s:e + 1] - o), ld.ld_data[o:int(ld.ld_indptr[e])]))
-    workers = max(1, min(workers, len(blocks)))
 
     def sweep():
         st = inp.state_copy()
         t0 = time.perf_counter()
-
-        def run(k):
-            for s, e, lb, ip, data in blocks[k::workers]:
-                O.cpp_e_step(lb, ip, data, inp.std_beta[s:e], st["var_gamma"][s:e], st["var_mu"][s:e], st["eta"][s:e],
-                             st["q"][s:e], st["eta_diff"][s:e], inp.u_logs[s:e], inp.sqrt_half_var_tau[s:e],
-                             inp.mu_mult[s:e], ld.dq_scale, 1, ld.low_memory, kind=kind)
-
-        list(pool.map(run, range(workers)))
+        O.e_step_block_parallel(ld.block_start, ld.ld_left_bound, ld.ld_indptr, ld.ld_data, inp.std_beta,
+                                st["var_gamma"], st["var_mu"], st["eta"], st["q"], st["eta_diff"], inp.u_logs,
+                                inp.sqrt_half_var_tau, inp.mu_mult, ld.dq_scale, workers, ld.low_memory, kind=kind)
         return time.perf_counter() - t0
 
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        sweep()
-        ts, used = [], 0.0
-        while used < budget_s and len(ts) < 10:
-            ts.append(sweep())
-            used += ts[-1]
+    sweep()
+    ts, used = [], 0.0
+    while used < budget_s and len(ts) < 10:
+        ts.append(sweep())
+        used += ts[-1]
     return ld.m / float(np.median(ts))
 
 
 # ---- workload ---------------------------------------------------------------------------------------------
 def build_workload(args, sizes_all, mine, seed, low_memory, ld_dtype):
     """LD + inputs of the blocks `mine` of the workload (`sizes_all`, seed): every random draw is made for the
-    WHOLE workload (block AR(1) coefficients, effects, noise, hyper-parameters M pi / h2), so a block holds
+    WHOLE workload (block LD parameters, effects, noise, hyper-parameters M pi / h2), so a block holds
     the same numbers whichever rank it lands on and however many ranks share the workload."""
     from viprs_amd.utils import synthetic as syn
+    kind = getattr(args, "ld_kind", "ar1")
     rng = np.random.default_rng(seed + 1)
     rho_all = rng.uniform(0.3, 0.8, len(sizes_all))
+    params_all = syn.longrange_params(sizes_all, seed) if kind == "longrange" else None
     if mine is None:
-        ld = syn.make_ld(sizes_all, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, rho=rho_all)
+        ld = syn.make_ld(sizes_all, low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, rho=rho_all, kind=kind,
+                         params=params_all)
         ss = syn.make_sumstats(ld, seed=seed)
         return ld, ss, syn.make_inputs(ss), ld.m
     starts = np.concatenate([[0], np.cumsum(sizes_all)]).astype(np.int64)
     m_all = int(starts[-1])
-    skeleton = syn.SyntheticLD(np.empty(m_all, np.int32), None, None, starts, rho_all, low_memory)
+    skeleton = syn.SyntheticLD(np.empty(m_all, np.int32), None, None, starts, rho_all, low_memory, kind=kind,
+                               params=params_all)
     ss_all = syn.make_sumstats(skeleton, seed=seed)
     inp_all = syn.make_inputs(ss_all)
     idx = np.concatenate([np.arange(starts[b], starts[b + 1]) for b in mine]) if len(mine) else np.zeros(0, np.int64)
-    ld = syn.make_ld(sizes_all[mine], low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, rho=rho_all[mine])
+    ld = syn.make_ld(sizes_all[mine], low_memory=low_memory, ld_dtype=ld_dtype, seed=seed, rho=rho_all[mine], kind=kind,
+                     params=[params_all[b] for b in mine] if params_all is not None else None)
     ss = syn.SyntheticSumstats(ss_all.std_beta[idx], ss_all.n_per_snp[idx], ss_all.beta_true[idx], ss_all.n)
     take = lambda a: np.ascontiguousarray(a[idx])
     inp = syn.EStepInputs(**{k: take(getattr(inp_all, k)) for k in
@@ -229,14 +234,18 @@ def build_workload(args, sizes_all, mine, seed, low_memory, ld_dtype):
 
 
 class Sweep:
-    """Device-resident plan + state of one workload (share) and the timed step."""
+    """Device-resident plan + state of one workload (share) and the timed step.  `plan`: an existing plan of the same
+    LD to put another model's state on (the LD is uploaded once)."""
 
-    def __init__(self, args, ld, ss, inp, device, model, width, low_memory):
+    def __init__(self, args, ld, ss, inp, device, model, width, low_memory, plan=None):
         from viprs_amd.plan import DeviceState, LDPlan
         from viprs_amd.utils import synthetic as syn
         self.ld = ld
-        self.plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory, device=device, math_mode=args.math)
+        self.own_plan = plan is None
+        self.plan = plan if plan is not None else \
+            LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory, device=device, math_mode=args.math)
         self.state = DeviceState(self.plan, "float32", model, width)
+        self.model, self.width = model, width
         self.active = None
         self.host_extra = None
         self.pi0 = inp.pi
@@ -270,13 +279,44 @@ class Sweep:
         barrier()
         return time.perf_counter() - t0
 
+    def algorithmic_bytes(self):
+        """LD element size x entries streamed (the upper-triangular form reads its entries twice) +
+        per-SNP index / input / state bytes of the model (spike-and-slab: 68 B)."""
+        ld, w = self.ld, self.width
+        nnz = int(ld.ld_indptr[-1]) * (2 if ld.low_memory else 1)
+        per_snp = {"spike_slab": STATE_BYTES_PER_SNP, "mixture": 12 + 4 + 4 * (3 * w + 1) + 8 * (2 * w + 3),
+                   "grid": 12 + 4 + 36 * w}[self.model]
+        return ld.ld_data.dtype.itemsize * nnz + per_snp * ld.m
+
     def close(self):
         self.state.close()
-        self.plan.close()
+        if self.own_plan:
+            self.plan.close()
 
 
 def pct(v, q):
     return float(np.percentile(v, q)) if len(v) else None
+
+
+def measure_secondary(name, sw, steps, barrier):
+    """One secondary configuration on one GPU: K timed steps, kernel time from the library's HIP events."""
+    el = sw.run(steps, 3, barrier)
+    k = sw.plan.timing_history(which=1)
+    by = sw.algorithmic_bytes()
+    out = {"name": name, "value": sw.ld.m * steps / el, "unit": "SNP-updates/s", "ms_per_step": el / steps * 1e3,
+           "kernel_ms_avg": float(np.mean(k)), "kernel_ms_p50": pct(k, 50),
+           "roofline_frac": by / (float(np.mean(k)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": int(by), "steps": steps}
+    if sw.model == "grid":
+        out["snp_x_model_updates_per_s"] = out["value"] * sw.width
+    return out
+
+
+def per_rank(comm, rank, world, x):
+    """One scalar per rank -> the vector of all ranks' values, on every rank."""
+    v = np.zeros(world)
+    v[rank] = float(x)
+    return comm.allreduce_sum(v)
 
 
 def main():
@@ -316,6 +356,8 @@ def main():
                 comm.close()
             comm = side
             comm_kind = f"file transport (RCCL communicator came up on {n_ok} of {world} ranks; rank {rank}: {err or 'ok'})"
+        else:
+            side.close()                                # RCCL is up on every rank: the side channel is done
     else:
         comm = LocalComm()
 
@@ -340,58 +382,63 @@ def main():
         ld, ss, inp, _ = build_workload(args, sizes_all, None, seed, args.low_memory, ld_dtype)
         total_snps = float(comm.allreduce_sum(np.array([float(ld.m)]))[0])
     sw = Sweep(args, ld, ss, inp, device, args.model, width, args.low_memory)
-    elapsed = float(comm.allreduce_max(np.array([sw.run(args.steps, args.warmup, barrier)]))[0])
+    my_elapsed = sw.run(args.steps, args.warmup, barrier)
+    elapsed = float(comm.allreduce_max(np.array([my_elapsed]))[0])
     skipped = sw.plan.last_skipped()
     k_ms = sw.plan.timing_history(which=1)
     sweep_ms = sw.plan.timing_history(which=0)
     es = ld_dtype.itemsize
-    nnz_streamed = int(ld.ld_indptr[-1]) * (2 if ld.low_memory else 1)   # upper form is read twice
-    # state bytes per SNP: index (12) + per model column 4 inputs + 5 state reads/writes + std_beta
-    state_bytes = STATE_BYTES_PER_SNP if args.model == "spike_slab" else (
-        12 + 4 + 4 * (3 * width + 1) + 8 * (2 * width + 3) if args.model == "mixture" else 12 + 4 + 36 * width)
-    algo_bytes = es * nnz_streamed + state_bytes * ld.m                   # this rank's share
+    algo_bytes = sw.algorithmic_bytes()                                   # this rank's share
     k_avg_ms = float(np.mean(k_ms)) if k_ms else float("nan")
     # per-rank kernel time and bytes -> node-level achieved bandwidth = all ranks' bytes / slowest rank's kernel time
-    per_rank = comm.allreduce_sum(np.array([float(algo_bytes)]))         # bytes of all ranks
-    k_max_ms = float(comm.allreduce_max(np.array([k_avg_ms]))[0])
-    achieved = float(per_rank[0]) / (k_max_ms * 1e-3) / 1e9
-    model_ms = float(comm.allreduce_max(np.array([rank_time_model(np.diff(ld.block_start), es) * 1e3]))[0])
+    bytes_ranks = per_rank(comm, rank, world, algo_bytes)
+    k_ranks = per_rank(comm, rank, world, k_avg_ms)
+    model_ranks = per_rank(comm, rank, world, rank_time_model(np.diff(ld.block_start), es) * 1e3)
+    snps_ranks = per_rank(comm, rank, world, ld.m)
+    blocks_ranks = per_rank(comm, rank, world, len(ld.block_start) - 1)
+    largest_ranks = per_rank(comm, rank, world, int(np.max(np.diff(ld.block_start))) if ld.m else 0)
+    elapsed_ranks = per_rank(comm, rank, world, my_elapsed)
+    k_max_ms = float(np.max(k_ranks))
+    achieved = float(bytes_ranks.sum()) / (k_max_ms * 1e-3) / 1e9
+    model_ms = float(np.max(model_ranks))
 
     # ---- secondary measurements -----------------------------------------------------------------------------
-    secondary = None
+    secondary = []
     weak = None
     if not args.no_secondary and args.model == "spike_slab":
         half = max(5, args.steps // 2)
-        if world == 1 and not args.low_memory and args.config != "cfg1":
-            # the reference's DEFAULT LD form (low_memory=True, VIPRS.py:75): upper-triangular store + second pass
-            ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, ld_dtype)
-            sw_u = Sweep(args, ld_u, ss_u, inp_u, device, args.model, width, True)
-            el_u = sw_u.run(half, 3, barrier)
-            ku = sw_u.plan.timing_history(which=1)
-            bytes_u = es * int(ld_u.ld_indptr[-1]) * 2 + STATE_BYTES_PER_SNP * ld_u.m
-            secondary = {
-                "ld_form": "upper-triangular (low_memory=True, the reference's default)",
-                "value": ld_u.m * half / el_u, "unit": "SNP-updates/s", "ms_per_step": el_u / half * 1e3,
-                "kernel_ms_avg": float(np.mean(ku)), "kernel_ms_p50": pct(ku, 50),
-                "roofline_frac": bytes_u / (float(np.mean(ku)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": int(bytes_u), "steps": half,
-            }
-            sw_u.close()
-            del ld_u
+        if world == 1 and not args.low_memory and args.ld_dtype == "float32" and args.config != "cfg1":
+            # configs[3] / configs[4] on the LD plan that is already resident (symmetric fp32)
+            for model2, w2, nm in (("mixture", 4, "configs[3]: sparse mixture prior K=4, symmetric fp32 LD"),
+                                   ("grid", 32, "configs[4]: grid of 32 (sigma_eps x pi) models batched per SNP, symmetric fp32 LD")):
+                sw2 = Sweep(args, ld, ss, inp, device, model2, w2, False, plan=sw.plan)
+                secondary.append(measure_secondary(nm, sw2, half, barrier))
+                sw2.close()
+            # the reference's DEFAULT LD form (low_memory=True, VIPRS.py:75): upper-triangular store + second pass;
+            # fp32, and int8 (dq_scale = 1/127): the format of the reference's published LD stores (docs/download_ld.md:6-10)
+            for dt2, nm in ((np.dtype("float32"), "upper-triangular fp32 LD (low_memory=True, the reference's default form), spike-and-slab"),
+                            (np.dtype("int8"), "upper-triangular int8 LD (low_memory=True + the published store format), spike-and-slab")):
+                ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, dt2)
+                sw_u = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True)
+                secondary.append(measure_secondary(nm, sw_u, half, barrier))
+                sw_u.close()
+                del ld_u, sw_u
         if strong:
             # weak scaling beside it: every rank sweeps a whole genome-scale workload of its own
             sw.close()
             ld_w, ss_w, inp_w, _ = build_workload(args, sizes_all, None, args.seed + 1000 * rank, args.low_memory, ld_dtype)
             sw_w = Sweep(args, ld_w, ss_w, inp_w, device, args.model, width, args.low_memory)
-            el_w = float(comm.allreduce_max(np.array([sw_w.run(half, 3, barrier)]))[0])
+            my_w = sw_w.run(half, 3, barrier)
+            el_w = float(comm.allreduce_max(np.array([my_w]))[0])
             tot_w = float(comm.allreduce_sum(np.array([float(ld_w.m)]))[0])
+            kw_ranks = per_rank(comm, rank, world, float(np.mean(sw_w.plan.timing_history(which=1))))
             weak = {"value": tot_w * half / el_w, "unit": "SNP-updates/s", "ms_per_step": el_w / half * 1e3,
-                    "snps_per_gpu": int(ld_w.m), "steps": half,
+                    "snps_per_gpu": int(ld_w.m), "steps": half, "kernel_ms_avg_per_rank": [float(x) for x in kw_ranks],
                     "note": "every rank its own 1.1 M-SNP workload (N x the work of `value`'s config)"}
             sw_w.close()
 
     if rank == 0:
-        traffic = None
+        traffic, traffic_src = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof) and world == 1:
             try:
@@ -399,8 +446,11 @@ def main():
                 if args.model != "spike_slab":
                     key += f"_{args.model}{width}"
                 traffic = json.load(open(prof)).get(key)
+                traffic_src = ("profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 "
+                               "--pmc passes of this command (a constant of the kernel, not measured in this run)")
             except Exception:
                 traffic = None
+        ld_name = {"ar1": "AR(1) block LD", "longrange": "long-range non-Toeplitz block LD (every entry matters)"}[args.ld_kind]
         out = {
             "metric": "SNP-updates/sec/E-step (1M SNPs, ~1700 LD blocks)",
             "value": total_snps * args.steps / elapsed,
@@ -408,7 +458,8 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": ("strong" if strong else "weak") if n_gpus > 1 else "weak",
+            # the series over N is ONE fixed workload sharded by LD block unless --scaling weak was asked for
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -419,22 +470,24 @@ def main():
                              "cfg3max": "configs[2] with one 6 000-SNP block (BASELINE's clip limit)"}[args.config]
                             + {"spike_slab": ", spike-and-slab", "mixture": f", sparse mixture prior K={width} (configs[3])",
                                "grid": f", grid of {width} (sigma_eps x pi) models batched per SNP (configs[4])"}[args.model]
-                            + ", AR(1) block LD"
+                            + ", " + ld_name
                             + (f", ONE workload block-sharded over {n_gpus} GPUs" if strong else
                                (f", one workload per GPU x {n_gpus}" if n_gpus > 1 else "")),
                 "prior": args.model, "prior_width": width,
                 "snp_x_grid_point_updates_per_s": total_snps * width * args.steps / elapsed if args.model == "grid" else None,
                 "snps_total": int(total_snps), "snps_rank0": int(ld.m), "ld_blocks_rank0": int(len(ld.block_start) - 1),
-                "ld_entries_rank0": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype,
+                "ld_entries_rank0": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype, "ld_kind": args.ld_kind,
                 "largest_block": int(np.max(sizes_all)),
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
+                "primary": "`value` is the " + ("upper-triangular" if ld.low_memory else "symmetric") + " LD form; the other "
+                           "form (the reference's default is low_memory=True) is in `secondary`",
                 "math_mode": args.math, "skipped_snps_last_sweep_rank0": int(skipped),
                 "comm": comm_kind,
                 "parallelism": (f"ld-blocks x{n_gpus} (strong: chain-aware LPT, no data-path collective; RCCL barrier / max only)"
                                 if strong else f"one workload per GPU x{n_gpus}") if n_gpus > 1 else "single GPU",
                 "step": "device state re-init + one E-step sweep over all blocks",
                 "time_model_ms": model_ms,
-                "secondary": secondary,
+                "secondary": secondary or None,
             },
             "roofline": {
                 "bound": "hbm",
@@ -443,7 +496,7 @@ def main():
                           ("estep_sweep_kernel (ONE launch per sweep: team workgroups for the large LD blocks, small-block workers "
                            "behind them" + ("; the upper-triangular form's second pass runs inside it" if ld.low_memory else "") + ")"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n_gpus),
-                "traffic": traffic, "algorithmic_bytes_per_launch": int(per_rank[0]),
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_ranks.sum()),
                 "kernel_ms_avg": k_max_ms, "kernel_ms_p10": pct(k_ms, 10), "kernel_ms_p50": pct(k_ms, 50),
                 "kernel_ms_p90": pct(k_ms, 90), "kernel_ms_max": float(np.max(k_ms)) if k_ms else None,
                 "sweep_ms_avg": float(np.mean(sweep_ms)) if sweep_ms else None,
@@ -451,6 +504,15 @@ def main():
                         "kernels' own streams); percentiles are rank 0's per-sweep kernel times",
             },
         }
+        if n_gpus > 1:
+            # self-diagnosing multi-GPU line: what every rank held and how long its kernel took, next to the model
+            out["per_rank"] = {
+                "snps": [int(x) for x in snps_ranks], "ld_blocks": [int(x) for x in blocks_ranks],
+                "largest_block": [int(x) for x in largest_ranks],
+                "algorithmic_bytes": [int(x) for x in bytes_ranks],
+                "kernel_ms_avg": [float(x) for x in k_ranks], "time_model_ms": [float(x) for x in model_ranks],
+                "wall_ms_per_step": [float(x) / args.steps * 1e3 for x in elapsed_ranks],
+            }
         if weak is not None:
             out["weak_scaling"] = weak
         if n_gpus == 1 and args.cpu_seconds > 0:

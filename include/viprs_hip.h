@@ -269,6 +269,9 @@ int viprs_comm_create(viprs_comm** comm, const void* id, int rank, int world_siz
 int viprs_comm_destroy(viprs_comm* comm);
 int viprs_comm_rank(const viprs_comm* comm, int* rank, int* world_size);
 int viprs_comm_allreduce(viprs_comm* comm, double* vec, int n, int group);
+/* bulk exchange at the END of a fit (the posterior of each rank's SNPs, BayesPRSModel.py:333-410 wants all of them):
+ * every rank sends `n` doubles, `recv` receives world_size x n in rank order -- one ncclAllGather.                    */
+int viprs_comm_allgather(viprs_comm* comm, const double* send, int64_t n, double* recv);
 int viprs_comm_barrier(viprs_comm* comm);
 int viprs_state_set_comm(viprs_state* state, viprs_comm* comm);
 /* hipDeviceSynchronize() on `device` (what the bench brackets its timed region with).                   */

@@ -102,6 +102,28 @@ def cpp_e_step(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, e
         raise RuntimeError(f"oracle e_step failed with code {rc}")
 
 
+def e_step_block_parallel(block_start, ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, eta, q, eta_diff,
+                          u_logs, sqrt_half_var_tau, mu_mult, dq_scale, n_threads, low_memory, kind="reference"):
+    """The reference's e_step<T,U,I>(threads=1) once per LD block, blocks spread over `n_threads` OpenMP threads
+    (largest first, dynamic schedule) inside oracle/_ref (ref_shim.cpp `ref_e_step_blocks`): the exact parallel
+    CPU variant (bin/viprs_fit:1080-1086 at LD-block grain).  Same result as ONE threads=1 call, bit for bit."""
+    t, u, i = _common(ld_left_bound, ld_indptr, ld_data, std_beta)
+    T = std_beta.dtype
+    for n, a in (("var_gamma", var_gamma), ("var_mu", var_mu), ("eta", eta), ("q", q),
+                 ("eta_diff", eta_diff), ("u_logs", u_logs), ("sqrt_half_var_tau", sqrt_half_var_tau),
+                 ("mu_mult", mu_mult)):
+        _check_vec(n, a, T)
+    bs = np.ascontiguousarray(block_start, dtype=np.int64)
+    order = np.ascontiguousarray(np.argsort(-np.diff(bs), kind="stable"), dtype=np.int32)
+    rc = _lib(kind).ref_e_step_blocks(t, u, i, ctypes.c_int(len(order)), _p(bs), _p(order), _p(ld_left_bound),
+                                      _p(ld_indptr), _p(ld_data), _p(std_beta), _p(var_gamma), _p(var_mu), _p(eta),
+                                      _p(q), _p(eta_diff), _p(u_logs), _p(sqrt_half_var_tau), _p(mu_mult),
+                                      ctypes.c_double(dq_scale), ctypes.c_int(int(n_threads)),
+                                      ctypes.c_int(bool(low_memory)))
+    if rc != 0:
+        raise RuntimeError(f"reference block-parallel e_step failed with code {rc}")
+
+
 def cpp_e_step_mixture(ld_left_bound, ld_indptr, ld_data, std_beta, var_gamma, var_mu, eta, q,
                        eta_diff, log_null_pi, u_logs, sqrt_half_var_tau, mu_mult, dq_scale, threads,
                        low_memory, kind="restated"):

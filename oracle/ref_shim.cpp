@@ -11,6 +11,7 @@
 // Built by oracle/Makefile into oracle/_ref/libviprs_ref.so with the reference's flags
 // (setup.py:202-221: -O3 -std=c++17 -fopenmp, no -march, HAVE_CBLAS undefined).
 #include <cstdint>
+#include <vector>
 #include "e_step.hpp"   // found through -I/root/reference/viprs/model/vi
 
 namespace {
@@ -46,6 +47,26 @@ void run_e_step_grid(int m, int n_active, int* active, int* lb, void* ip, void* 
     e_step_grid<T, U, I>(m, n_active, active, lb, (I*)ip, (U*)ld, (T*)std_beta, (T*)var_gamma,
                          (T*)var_mu, (T*)eta, (T*)q, (T*)eta_diff, (T*)u_logs, (T*)hvt,
                          (T*)mu_mult, (T)dq_scale, threads, low_memory != 0);
+}
+
+// The reference's coarse, EXACT parallelism (joblib over chromosomes, bin/viprs_fit:1080-1086) at LD-block grain: one
+// e_step<T,U,I>(threads = 1) call per LD block, blocks handed to the OpenMP threads dynamically in the caller's order
+// (largest first).  Blocks share no q entries, so the result equals ONE threads = 1 call over all SNPs bit for bit.
+// bench.py's CPU-baseline variant 3.
+template <typename T, typename U, typename I>
+void run_e_step_blocks(int n_blocks, const int64_t* block_start, const int32_t* order, int* lb, void* ip, void* ld,
+                       void* std_beta, void* var_gamma, void* var_mu, void* eta, void* q, void* eta_diff,
+                       void* u_logs, void* shvt, void* mu_mult, double dq_scale, int n_threads, int low_memory) {
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+    for (int k = 0; k < n_blocks; ++k) {
+        const int b = order[k];
+        const int64_t s = block_start[b], e = block_start[b + 1];
+        std::vector<int> lb_local((size_t)(e - s));
+        for (int64_t j = s; j < e; ++j) lb_local[(size_t)(j - s)] = lb[j] - (int)s;     // window starts relative to the block
+        e_step<T, U, I>((int)(e - s), lb_local.data(), (I*)ip + s, (U*)ld, (T*)std_beta + s, (T*)var_gamma + s,
+                        (T*)var_mu + s, (T*)eta + s, (T*)q + s, (T*)eta_diff + s, (T*)u_logs + s, (T*)shvt + s,
+                        (T*)mu_mult + s, (T)dq_scale, 1, low_memory != 0);
+    }
 }
 
 #define DISPATCH_I(FN, T, U, ...)                                   \
@@ -87,6 +108,14 @@ int ref_e_step(int tcode, int ucode, int icode, int m, int* lb, void* ip, void* 
                void* shvt, void* mu_mult, double dq_scale, int threads, int low_memory) {
     DISPATCH(run_e_step, m, lb, ip, ld, std_beta, var_gamma, var_mu, eta, q, eta_diff, u_logs, shvt,
              mu_mult, dq_scale, threads, low_memory);
+}
+
+int ref_e_step_blocks(int tcode, int ucode, int icode, int n_blocks, const int64_t* block_start, const int32_t* order,
+                      int* lb, void* ip, void* ld, void* std_beta, void* var_gamma, void* var_mu, void* eta, void* q,
+                      void* eta_diff, void* u_logs, void* shvt, void* mu_mult, double dq_scale, int n_threads,
+                      int low_memory) {
+    DISPATCH(run_e_step_blocks, n_blocks, block_start, order, lb, ip, ld, std_beta, var_gamma, var_mu, eta, q,
+             eta_diff, u_logs, shvt, mu_mult, dq_scale, n_threads, low_memory);
 }
 
 int ref_e_step_mixture(int tcode, int ucode, int icode, int m, int K, int* lb, void* ip, void* ld,

@@ -102,3 +102,90 @@ def test_block_shard_slices_ld_rows_into_a_local_numbering():
         np.testing.assert_array_equal(data, ref.ld_data)
         full = np.arange(ld.m, dtype=np.float32)
         np.testing.assert_array_equal(sh.scatter(sh.take(full), np.zeros(ld.m, np.float32))[sh.index], full[sh.index])
+
+
+_BENCH_WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from viprs_amd import _lib, plan as plan_mod
+
+# ---- stubbed device layer: no GPU here; everything ABOVE it (sharding, workload construction, collectives, the JSON
+# line) is bench.py's real multi-rank logic --------------------------------------------------------------------------
+_lib.device_count = lambda: 1
+class _FakeLib:
+    def __getattr__(self, name):
+        return lambda *a, **k: 0
+_lib.lib = _FakeLib()
+_lib.check = lambda rc: None
+
+class FakePlan:
+    def __init__(self, lb, ip, data, low_memory, device=0, math_mode="exact"):
+        self.m = int(lb.shape[0]); self.n = 0
+    def timing_reset(self): self.n = 0
+    def timing_history(self, which=0, capacity=256): return [0.5 + 0.01 * int(os.environ["RANK"])] * max(self.n, 1)
+    def last_skipped(self): return 7
+    def close(self): pass
+
+class FakeState:
+    def __init__(self, plan, dtype, model, width): self.plan = plan
+    def upload(self, name, arr): assert arr.shape[0] == self.plan.m, (name, arr.shape, self.plan.m)
+    def reset(self, pi): pass
+    def e_step(self, dq, active=None, sync=True): self.plan.n += 1; time.sleep(0.001)
+    def synchronize(self): pass
+    def close(self): pass
+
+plan_mod.LDPlan, plan_mod.DeviceState = FakePlan, FakeState
+import bench
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg2", "--cpu-seconds", "0"] + {extra!r}
+bench.main()
+print("RANK_DONE", os.environ["RANK"])
+"""
+
+
+@pytest.mark.parametrize("extra", [[], ["--scaling", "weak"]], ids=["strong", "weak"])
+def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra):
+    """bench.py's N > 1 path run for real with two processes (torch.distributed.run-style environment,
+    VIPRS_BENCH_COMM=file, device layer stubbed): ONE JSON line from rank 0 whose `n_gpus`, `comm`, `snps_total`,
+    `scaling` and per-rank vectors describe a strong-scaling run of ONE sharded workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_BENCH_WORKER.format(root=root, extra=extra))
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+               VIPRS_BENCH_COMM="file", TMPDIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_DONE {r}" in o, o[-3000:]
+    lines = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]   # rank 0 only, one line
+    out = json.loads(lines[0])
+    sizes = bench.config_sizes("cfg2", 7209)
+    weak = "weak" in extra
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["scaling"] == ("weak" if weak else "strong")
+    assert "file transport" in out["config"]["comm"]
+    pr = out["per_rank"]
+    if weak:
+        assert out["config"]["snps_total"] == 2 * int(sizes.sum()) and pr["snps"] == [int(sizes.sum())] * 2
+    else:
+        # ONE workload: the shards partition its blocks, `value` counts its SNPs once
+        assert out["config"]["snps_total"] == int(sizes.sum()) == sum(pr["snps"])
+        assert sum(pr["ld_blocks"]) == len(sizes) and max(pr["largest_block"]) == int(sizes.max())
+        parts = bench.shard_blocks_lpt(sizes, 2)
+        assert pr["snps"] == [int(sizes[p].sum()) for p in parts]
+        assert pr["algorithmic_bytes"] == [int(4 * (sizes[p] ** 2).sum() + 68 * sizes[p].sum()) for p in parts]
+        assert out["weak_scaling"]["snps_per_gpu"] == int(sizes.sum())
+        assert len(out["weak_scaling"]["kernel_ms_avg_per_rank"]) == 2
+    assert out["value"] == pytest.approx(out["config"]["snps_total"] * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)
+    assert pr["kernel_ms_avg"] == pytest.approx([0.5, 0.51]) and len(pr["time_model_ms"]) == 2
+    assert out["roofline"]["kernel_ms_avg"] == pytest.approx(0.51)            # slowest rank
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == sum(pr["algorithmic_bytes"])
+    # the transport cleaned up after itself (ADVICE r2: stale rendezvous files)
+    left = [f for f in os.listdir(tmp_path) if f.startswith("viprs_filecomm")]
+    assert left == [], left

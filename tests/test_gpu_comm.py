@@ -52,7 +52,14 @@ def test_device_sums_through_the_communicator_equal_local_sums(comm):
     es.set_comm(comm)
     es.sums_begin(1.0)
     np.testing.assert_array_equal(es.sums_end(), np.zeros(11))
+    # ... also through the blocking entry points (they used to return before the collective, which
+    # leaves the ranks that do hold blocks waiting in the all-gather)
+    np.testing.assert_array_equal(es.sums(1.0), np.zeros(11))
     es.close()
+    eg = DeviceState(empty, "float32", "grid", 3)
+    eg.set_comm(comm)
+    np.testing.assert_array_equal(eg.sums_column(1, 1.0), np.zeros(11))
+    eg.close()
     empty.close()
 
 

@@ -1,0 +1,93 @@
+"""CPU: the file rendezvous of the multi-GPU path (rank 0's RCCL unique id / FileComm's directory nonce reach the
+other ranks without any rank ever accepting a file of an earlier, crashed run) and the FileComm test transport."""
+import os
+import threading
+
+import numpy as np
+
+from viprs_amd import parallel as P
+
+
+def _run_ranks(world, fn):
+    out, err = [None] * world, []
+
+    def go(r):
+        try:
+            out[r] = fn(r)
+        except Exception as e:              # noqa: BLE001
+            err.append((r, e))
+
+    ts = [threading.Thread(target=go, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not err, err
+    return out
+
+
+def test_root_broadcast_ignores_stale_files_of_a_crashed_run(tmp_path):
+    base = str(tmp_path / "viprs_comm_test.id.0")
+    # litter of an earlier run with the same key: an id file of the old scheme, a stale request, a stale response
+    for name, payload in ((base, b"S" * 128), (base + ".req.1.deadbeefdeadbeef", b""), (base + ".rsp.1.deadbeefdeadbeef", b"S" * 128),
+                          (base + ".rsp.2.0123456789abcdef", b"S" * 128)):
+        with open(name, "wb") as f:
+            f.write(payload)
+    fresh = b"F" * 128
+    bcs = [None] * 3
+
+    def rank(r):
+        bcs[r] = P._RootBroadcast(r, base, (lambda: fresh) if r == 0 else None, timeout_s=30)
+        return bcs[r].payload
+
+    got = _run_ranks(3, rank)
+    assert got == [fresh, fresh, fresh]                     # nobody took the stale id
+    bcs[0].finish()
+    left = [f for f in os.listdir(tmp_path) if ".req." in f or ".rsp." in f]
+    assert left == []                                       # rank 0 swept this base's litter, stale files included
+
+
+def test_exchange_unique_id_rejects_a_malformed_id(tmp_path, monkeypatch):
+    monkeypatch.setenv("VIPRS_COMM_ID_FILE", str(tmp_path / "id"))
+    try:
+        P._exchange_unique_id(0, 2, lambda: b"short")
+    except RuntimeError as e:
+        assert "malformed" in str(e)
+    else:
+        raise AssertionError("a 5-byte id was accepted")
+
+
+def test_launch_key_names_the_parent_process_and_its_start_time(monkeypatch):
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    monkeypatch.setenv("VIPRS_RUN_ID", "abc")
+    k = P._launch_key()
+    parts = k.split("_")
+    assert parts[0] == "29512" and "abc" in parts and str(os.getppid()) in parts
+    assert parts[-1].isdigit() and int(parts[-1]) > 0       # the parent's start time: a reused pid is a different key
+
+
+def test_file_comm_collectives_and_cleanup(tmp_path):
+    root = str(tmp_path / "fc")
+    # an earlier run's directory of the same launch key with step files in it: never read
+    os.makedirs(root + ".0.feedfacefeedface")
+    np.save(root + ".0.feedfacefeedface/1_1.npy", np.array([999.0]))
+    seqs = [P._COMM_SEQ]
+
+    def rank(r):
+        # (threads share the module-level communicator counter; give every rank the same base explicitly)
+        P._COMM_SEQ = seqs[0]
+        c = P.FileComm(r, 3, root=root)
+        s = c.allreduce_sum(np.array([1.0 + r, 10.0]))
+        m = c.allreduce_max(np.array([float(r)]))
+        for _ in range(5):
+            c.barrier()
+        d = c.root
+        c.close()
+        return s, m, d
+
+    res = _run_ranks(3, rank)
+    for s, m, d in res:
+        np.testing.assert_array_equal(s, [6.0, 30.0])
+        np.testing.assert_array_equal(m, [2.0])
+    assert len({d for _, _, d in res}) == 1 and not res[0][2].endswith("feedfacefeedface")
+    assert not os.path.exists(res[0][2])                    # removed by close()

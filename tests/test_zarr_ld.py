@@ -110,14 +110,14 @@ def test_ld_store_round_trip_and_loader_surface(tmp_path):
     np.testing.assert_array_equal(lo.ld_indptr, up.ld_indptr)
     np.testing.assert_array_equal(lo.leftmost_idx, up.ld_left_bound)
     f = m.load(return_symmetric=False, dtype=np.float32)             # dequantised at load time
-    np.testing.assert_allclose(f.ld_data, up.ld_data.astype(np.float32) / 127.0, rtol=1e-7)
+    np.testing.assert_array_equal(f.ld_data, up.ld_data.astype(np.float32) / np.float32(127))   # a division, bit for bit
     with pytest.raises(ValueError, match="upper-triangular"):
         m.load(return_symmetric=True)
     lb, ip, data = m.load_rows(40, 130)                              # the second block only
     np.testing.assert_array_equal(data, up.ld_data[int(up.ld_indptr[40]):int(up.ld_indptr[130])])
     np.testing.assert_array_equal(ip, up.ld_indptr[40:131] - up.ld_indptr[40])
     np.testing.assert_array_equal(m.metadata("bp"), np.arange(up.m))
-    assert m.get_lambda_min() == 0.0
+    assert m.get_lambda_min() == 0.0 and m.get_lambda_min(min_max_ratio=1e-3) == 0.0     # no spectral attributes
     found = Z.find_ld_stores(str(tmp_path))
     assert list(found) == [22] and found[22].n_snps == up.m
 
@@ -192,3 +192,17 @@ def test_two_rank_fit_reads_only_its_blocks_from_the_store(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]
+
+
+@pytest.mark.parametrize("keys", [("min", "max"), ("Min", "Max")])
+def test_lambda_min_from_the_stored_extremal_eigenvalues(tmp_path, keys):
+    """`VIPRS(lambda_min='infer')` calls get_lambda_min(min_max_ratio=1e-3) (VIPRS.py:191): the regulariser that
+    brings lambda_min / lambda_max up to the ratio, max((r lambda_max - lambda_min) / (1 + r), 0)."""
+    up = syn.make_ld([30, 20], low_memory=True, ld_dtype=np.int8, seed=3)
+    for lam_min, lam_max in ((-0.25, 40.0), (0.5, 40.0), (0.01, 40.0)):
+        path = str(tmp_path / f"s{lam_min}_{keys[0]}")
+        Z.write_ld_store(path, up.ld_indptr, up.ld_data,
+                         attrs={"Chromosome": 1, "Spectral properties": {"Extremal": {keys[0]: lam_min, keys[1]: lam_max}}})
+        m = Z.ZarrLDMatrix(path)
+        assert m.get_lambda_min() == pytest.approx(max(-lam_min, 0.0))
+        assert m.get_lambda_min(min_max_ratio=1e-3) == pytest.approx(max((1e-3 * lam_max - lam_min) / 1.001, 0.0))

@@ -95,6 +95,7 @@ _PROTOS = {
     "viprs_comm_destroy": (_i, [_vp]),
     "viprs_comm_rank": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "viprs_comm_allreduce": (_i, [_vp, _vp, _i, _i]),
+    "viprs_comm_allgather": (_i, [_vp, _vp, _i64, _vp]),
     "viprs_comm_barrier": (_i, [_vp]),
     "viprs_state_set_comm": (_i, [_vp, _vp]),
     "viprs_device_synchronize": (_i, [_i]),

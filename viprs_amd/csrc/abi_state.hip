@@ -499,6 +499,10 @@ int viprs_state_sums(viprs_state* S, double one_plus_lambda, double* out) {
     if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EUNSUPPORTED, "device sums: spike-and-slab only");
     viprs_plan* P = S->plan;
     for (int k = 0; k < kNSums; ++k) out[k] = 0.0;
+    if (P->m == 0 && S->comm) {          // an empty rank still takes part in the collective (it contributes zeros)
+        const int rc = sums_enqueue_empty(S, kNSums, kNSums);
+        return rc != VIPRS_OK ? rc : sums_finish(S, out);
+    }
     if (P->m == 0) return VIPRS_OK;
     if (!S->d_var_tau.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp / viprs_state_prep have not been called");
     HIP_TRY(hipSetDevice(P->device));
@@ -753,6 +757,10 @@ int viprs_state_sums_column(viprs_state* S, int g, double one_plus_lambda, doubl
     if (rc != VIPRS_OK) return rc;
     viprs_plan* P = S->plan;
     for (int k = 0; k < kNSums; ++k) out[k] = 0.0;
+    if (P->m == 0 && S->comm) {          // an empty rank still takes part in the collective (it contributes zeros)
+        rc = sums_enqueue_empty(S, kNSums, kNSums);
+        return rc != VIPRS_OK ? rc : sums_finish(S, out);
+    }
     if (P->m == 0) return VIPRS_OK;
     if (S->d_var_tau.n < (size_t)P->m * S->width) return fail(VIPRS_EINVAL, "viprs_state_prep_column has not been called");
     HIP_TRY(hipSetDevice(P->device));

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and prototypes only; the symbols are resolved at run time
 
+#include <map>
 #include "internal.h"
 
 using namespace viprs;
@@ -73,7 +74,10 @@ struct viprs_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;                  // host-vector collectives (viprs_comm_allreduce / barrier)
-    DevBuf<double> d_vec, d_gather;
+    DevBuf<double> d_vec;
+    // one all-gather landing buffer PER STREAM that reduces through this communicator (the plan streams of the states
+    // it is attached to, and `stream` above): reductions on different streams are not ordered against each other
+    std::map<hipStream_t, DevBuf<double>> d_gather;
     double* h_pin = nullptr;
     size_t h_cap = 0;
     ~viprs_comm() {
@@ -88,13 +92,13 @@ namespace viprs {
 int comm_reduce_on_stream(viprs_comm* C, double* d_vec, int n, int group, hipStream_t stream) {
     if (!C || n <= 0) return VIPRS_OK;
     const size_t need = (size_t)C->world * (size_t)n;
-    if (C->d_gather.n < need) {
-        // (growth only: the buffer may still be read by an earlier reduction on another stream)
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(C->d_gather.alloc(std::max<size_t>(need, 4096)));
+    DevBuf<double>& gather = C->d_gather[stream];
+    if (gather.n < need) {
+        HIP_TRY(hipStreamSynchronize(stream));     // (growth only: an earlier reduction on this stream may still read it)
+        HIP_TRY(gather.alloc(std::max<size_t>(need, 4096)));
     }
-    NCCL_TRY(rccl()->AllGather(d_vec, C->d_gather.p, (size_t)n, ncclDouble, C->comm, stream));
-    comm_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(C->d_gather.p, C->world, n, group, d_vec);
+    NCCL_TRY(rccl()->AllGather(d_vec, gather.p, (size_t)n, ncclDouble, C->comm, stream));
+    comm_reduce_kernel<<<(n + 255) / 256, 256, 0, stream>>>(gather.p, C->world, n, group, d_vec);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
 }
@@ -167,6 +171,22 @@ int viprs_comm_allreduce(viprs_comm* C, double* vec, int n, int group) {
     HIP_TRY(hipMemcpyAsync(C->h_pin, C->d_vec.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, C->stream));
     HIP_TRY(hipStreamSynchronize(C->stream));
     std::memcpy(vec, C->h_pin, (size_t)n * sizeof(double));
+    return VIPRS_OK;
+}
+
+int viprs_comm_allgather(viprs_comm* C, const double* send, int64_t n, double* recv) {
+    // bulk exchange of per-SNP vectors (the posterior of every rank's SNPs when fit() returns): ONE ncclAllGather of
+    // n doubles per rank; `recv` holds world_size x n doubles in rank order.  Not an EM-iteration collective.
+    if (!C || ((!send || !recv) && n > 0)) return fail(VIPRS_EINVAL, "null argument");
+    if (n <= 0) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(C->device));
+    DevBuf<double> d_send, d_recv;
+    HIP_TRY(d_send.alloc((size_t)n));
+    HIP_TRY(d_recv.alloc((size_t)n * (size_t)C->world));
+    HIP_TRY(hipMemcpyAsync(d_send.p, send, (size_t)n * sizeof(double), hipMemcpyHostToDevice, C->stream));
+    NCCL_TRY(rccl()->AllGather(d_send.p, d_recv.p, (size_t)n, ncclDouble, C->comm, C->stream));
+    HIP_TRY(hipMemcpyAsync(recv, d_recv.p, (size_t)n * (size_t)C->world * sizeof(double), hipMemcpyDeviceToHost, C->stream));
+    HIP_TRY(hipStreamSynchronize(C->stream));
     return VIPRS_OK;
 }
 

@@ -68,7 +68,9 @@ enum { kLookupPerLane = 0, kLookupLane = 1 };
 template <int LOOKUP>
 __device__ __forceinline__ float expf_glibc_nonpos(float x, const ExpTab& tab, int sel = 0) {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32;
-    const double xd = (double)fmaxf(x, -104.0f);
+    // (a select, not fmaxf: v_max_f32 would turn a NaN argument into -104 and the sigmoid of a NaN into 1.0 -- a NaN in
+    // the summary statistics has to come out as NaN, as it does in the reference)
+    const double xd = (double)((x < -104.0f) ? -104.0f : x);
     const double z = InvLn2N * xd;
     const double kd = rint(z);                 // == (z + 0x1.8p52) - 0x1.8p52 in round-to-nearest
     const double r = fma(InvLn2N, xd, -kd);

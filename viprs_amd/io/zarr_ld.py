@@ -409,8 +409,9 @@ class ZarrLDMatrix:
         if dtype is None or np.dtype(dtype) == data.dtype:
             return data
         if np.issubdtype(data.dtype, np.integer) and np.issubdtype(np.dtype(dtype), np.floating):
-            # dequantise at load time, as magenpy does when a float dtype is asked for
-            return (data.astype(dtype) * np.dtype(dtype).type(self.dq_scale)).astype(dtype)
+            # dequantise at load time, as magenpy does when a float dtype is asked for: a DIVISION by the integer
+            # type's maximum (multiplying by the rounded reciprocal differs in the last bit for some values)
+            return (data.astype(dtype) / np.dtype(dtype).type(np.iinfo(data.dtype).max)).astype(dtype)
         return data.astype(dtype)
 
     def load(self, return_symmetric=False, dtype=None):
@@ -428,12 +429,29 @@ class ZarrLDMatrix:
         data = self._cast(self._data.read(int(ip[start]), int(ip[stop])), dtype)
         return np.arange(start + 1, stop + 1, dtype=np.int32), ip[start:stop + 1] - ip[start], data
 
-    def get_lambda_min(self, min_max_ratio=1e-3):
-        """magenpy stores estimates of the smallest eigenvalue under 'Spectral properties'; 0 when absent."""
+    def get_lambda_min(self, min_max_ratio=0.0):
+        """The ridge penalty `VIPRS(lambda_min='infer')` asks for (`ld_mat.get_lambda_min(min_max_ratio=1e-3)`,
+        VIPRS.py:191), from the extremal eigenvalues magenpy stores under 'Spectral properties' -> 'Extremal':
+        the smallest x >= 0 with (lambda_min + x) >= min_max_ratio (lambda_max + x), scaled as magenpy does:
+        max((r lambda_max - lambda_min) / (1 + r), 0); with r = 0 that is |min(lambda_min, 0)|.  0 when the store
+        has no spectral attributes.  PARITY UNPINNED: magenpy is not in the reference tree (formula and attribute
+        names as recalled from magenpy 0.1.x; both 'min'/'max' and 'Min'/'Max' keys are accepted)."""
         sp = self.attrs.get("Spectral properties") or {}
-        ext = sp.get("Extremal") or {}
-        lam = ext.get("Min", sp.get("Min"))
-        return abs(float(lam)) if lam is not None and float(lam) < 0 else 0.0
+        ext = sp.get("Extremal") or sp.get("extremal") or sp
+
+        def pick(d, *names):
+            for n in names:
+                if isinstance(d, dict) and d.get(n) is not None:
+                    return float(d[n])
+            return None
+
+        lam_min, lam_max = pick(ext, "min", "Min"), pick(ext, "max", "Max")
+        if lam_min is None:
+            return 0.0
+        r = float(min_max_ratio or 0.0)
+        if r > 0.0 and lam_max is not None:
+            return max((r * lam_max - lam_min) / (1.0 + r), 0.0)
+        return abs(min(lam_min, 0.0))
 
 
 def write_ld_store(path, ld_indptr, ld_data, attrs=None, chunks=None, cname="zstd", clevel=5, shuffle=1,

@@ -126,6 +126,7 @@ class VIPRS:
                 self.lambda_min = ld_mat.get_lambda_min(min_max_ratio=1e-3)
 
         self._shard = {}
+        self._block_owner = {}                   # chromosome -> (block starts, owning rank of every block)
         if world > 1:
             from ..plan import plan_blocks
             upper_form = bool(low_memory) or self._expanded
@@ -138,6 +139,7 @@ class VIPRS:
             for c in all_chroms:
                 nb = len(starts[c]) - 1
                 mine = [b for b in range(nb) if owner[k + b] == self.comm.rank]
+                self._block_owner[c] = (starts[c], np.asarray(owner[k:k + nb]))
                 k += nb
                 self._shard[c] = BlockShard(starts[c], mine)
         self.shapes = {}
@@ -470,24 +472,36 @@ class VIPRS:
             return
         chroms = sorted(self._all_shapes)
 
+        world = self.comm.world_size
+        # SNP index set of every rank's shard, per chromosome (the block assignment is the same on every rank)
+        index = {c: [BlockShard(self._block_owner[c][0], np.nonzero(self._block_owner[c][1] == r)[0]).index
+                     for r in range(world)] for c in chroms}
+
         def gather(local):
             tail = next((np.shape(a)[1:] for a in local.values()), None)
             tail_v = self.comm.allreduce_max(np.array([float(tail[0]) if tail else 0.0]))    # grid models: (m, G)
             tail = (int(tail_v[0]),) if tail_v[0] > 0 else ()
             width = int(np.prod(tail)) if tail else 1
-            full = np.zeros((sum(self._all_shapes[c] for c in chroms), width), dtype=np.float64)
+            # ONE all-gather of every rank's own SNPs (padded to the largest shard): m x width values travel in total,
+            # not world x m x width as with a sum of zero-padded full-length vectors
+            n_max = max(sum(len(index[c][r]) for c in chroms) for r in range(world)) * width
+            send = np.zeros(n_max, dtype=np.float64)
             off = 0
             for c in chroms:
                 sh = self._shard[c]
                 if sh.m > 0:
-                    full[off + sh.index] = np.asarray(local[c], dtype=np.float64).reshape(sh.m, width)
-                off += self._all_shapes[c]
-            full = self.comm.allreduce_sum(full.ravel()).reshape(full.shape)
-            out, off = {}, 0
+                    send[off:off + sh.m * width] = np.asarray(local[c], dtype=np.float64).reshape(-1)
+                off += sh.m * width
+            recv = self.comm.allgather(send)
+            out = {}
+            offs = [0] * world
             for c in chroms:
-                a = full[off:off + self._all_shapes[c]].astype(self._T)
-                out[c] = a.reshape((self._all_shapes[c],) + tail)
-                off += self._all_shapes[c]
+                full = np.zeros((self._all_shapes[c], width), dtype=self._T)
+                for r in range(world):
+                    n = len(index[c][r]) * width
+                    full[index[c][r]] = recv[r, offs[r]:offs[r] + n].reshape(-1, width)
+                    offs[r] += n
+                out[c] = full.reshape((self._all_shapes[c],) + tail)
             return out
 
         self.pip, self.post_mean_beta, self.post_var_beta = gather(self.pip), gather(self.post_mean_beta), \

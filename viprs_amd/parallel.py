@@ -130,6 +130,9 @@ class LocalComm:
     def allreduce_max(self, vec):
         return np.asarray(vec, dtype=np.float64)
 
+    def allgather(self, vec):
+        return np.asarray(vec, dtype=np.float64)[None]
+
     def barrier(self):
         pass
 
@@ -137,39 +140,109 @@ class LocalComm:
 _COMM_SEQ = 0
 
 
-def _exchange_unique_id(rank, world_size, make_id, timeout_s=300.0):
-    """Rank 0's RCCL unique id reaches the other ranks of the node through a file (atomic rename): no
-    PyTorch, no extra port.  VIPRS_COMM_ID_FILE names it explicitly; by default it is keyed on the
-    launcher (the parent process all ranks share under torch.distributed.run / a shell loop) and on
-    MASTER_PORT."""
-    global _COMM_SEQ
-    path = os.environ.get("VIPRS_COMM_ID_FILE")
-    if not path:
-        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
-        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"viprs_comm_{os.getuid()}_{tag}.id")
-    # every communicator of a process gets its own file (all ranks create them in the same order): a rank can never
-    # pick up the id of the previous communicator while rank 0 is still removing that file
-    path = f"{path}.{_COMM_SEQ}"
-    _COMM_SEQ += 1
-    if rank == 0:
-        uid = make_id()
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid, path
-    t0 = time.time()
-    while True:
-        try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid, path
-        except FileNotFoundError:
+def _launch_key():
+    """What all ranks of ONE launch share and no other launch does: MASTER_PORT, the launcher's run id, an optional
+    user tag (VIPRS_RUN_ID: ranks started by hand from a long-lived shell), and the parent process -- its pid AND its
+    start time (field 22 of /proc/<pid>/stat), so that a reused pid is a different key."""
+    ppid = os.getppid()
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        start = "0"
+    return "_".join([os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                     os.environ.get("VIPRS_RUN_ID", "none"), str(ppid), start])
+
+
+class _RootBroadcast:
+    """Rank 0's small byte string reaches the other ranks of the node through files, WITHOUT any rank ever accepting
+    a file of an earlier (crashed) run: rank r > 0 drops a request `<base>.req.<r>.<nonce>` with a fresh random nonce
+    and accepts only `<base>.rsp.<r>.<nonce>`; rank 0 answers every request it sees from a helper thread until
+    `finish()`, which also removes whatever requests / responses (its own run's and stale ones) carry this base.
+    No PyTorch, no extra port."""
+
+    def __init__(self, rank, base, payload_fn=None, timeout_s=300.0):
+        import glob
+        import secrets
+        import threading
+        self.rank, self.base = rank, base
+        self._thread = None
+        if rank == 0:
+            self.payload = payload_fn()
+            self._stop = threading.Event()
+            answered = set()
+
+            def serve():
+                while not self._stop.is_set():
+                    for req in glob.glob(f"{base}.req.*"):
+                        if req in answered:
+                            continue
+                        rsp = f"{base}.rsp." + req[len(base) + 5:]
+                        tmp = f"{rsp}.{os.getpid()}.tmp"
+                        try:
+                            with open(tmp, "wb") as f:
+                                f.write(self.payload)
+                            os.replace(tmp, rsp)
+                        except OSError:
+                            continue
+                        answered.add(req)
+                    self._stop.wait(0.005)
+
+            self._thread = threading.Thread(target=serve, daemon=True)
+            self._thread.start()
+            return
+        nonce = secrets.token_hex(8)
+        req, rsp = f"{base}.req.{rank}.{nonce}", f"{base}.rsp.{rank}.{nonce}"
+        with open(req, "wb"):
             pass
-        if time.time() - t0 > timeout_s:
-            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
-        time.sleep(0.01)
+        t0 = time.time()
+        while True:
+            try:
+                with open(rsp, "rb") as f:
+                    self.payload = f.read()
+                break
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rank {rank}: rank 0 did not answer {req} within {timeout_s:.0f} s")
+            time.sleep(0.005)
+        for f in (req, rsp):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+    def finish(self):
+        """Rank 0, once every rank is known to hold the payload (a collective has completed): stop answering and
+        remove the litter of this base, stale files of crashed runs included."""
+        if self._thread is None:
+            return
+        import glob
+        self._stop.set()
+        self._thread.join()
+        self._thread = None
+        for f in glob.glob(f"{self.base}.req.*") + glob.glob(f"{self.base}.rsp.*"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+
+
+def _exchange_unique_id(rank, world_size, make_id, timeout_s=300.0):
+    """Rank 0's RCCL unique id on every rank (`_RootBroadcast`).  VIPRS_COMM_ID_FILE names the rendezvous base
+    explicitly; by default it is keyed on the launch (`_launch_key`).  Returns (id, broadcast): rank 0 calls
+    `broadcast.finish()` after the communicator has come up."""
+    global _COMM_SEQ
+    base = os.environ.get("VIPRS_COMM_ID_FILE")
+    if not base:
+        base = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"viprs_comm_{os.getuid()}_{_launch_key()}.id")
+    # every communicator of a process gets its own base (all ranks create them in the same order)
+    base = f"{base}.{_COMM_SEQ}"
+    _COMM_SEQ += 1
+    bc = _RootBroadcast(rank, base, make_id, timeout_s)
+    if len(bc.payload) != 128:
+        raise RuntimeError(f"rank {rank}: malformed RCCL unique id ({len(bc.payload)} bytes) from {base}")
+    return bc.payload, bc
 
 
 class RcclComm:
@@ -194,18 +267,18 @@ class RcclComm:
             return buf.raw
 
         if self.world_size > 1:
-            uid, path = _exchange_unique_id(self.rank, self.world_size, make_id)
+            uid, bc = _exchange_unique_id(self.rank, self.world_size, make_id)
         else:
-            uid, path = make_id(), None
+            uid, bc = make_id(), None
         self._h = ctypes.c_void_p()
-        L.check(L.lib.viprs_comm_create(ctypes.byref(self._h), uid, self.rank, self.world_size, self.device))
-        if path is not None:
-            self.barrier()                      # every rank has read the id: rank 0 may remove the file
-            if self.rank == 0:
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
+        try:
+            # (rank 0 keeps answering id requests from its helper thread while it blocks in here)
+            L.check(L.lib.viprs_comm_create(ctypes.byref(self._h), uid, self.rank, self.world_size, self.device))
+            if bc is not None:
+                self.barrier()                  # every rank holds the id: rank 0 stops answering and cleans up
+        finally:
+            if bc is not None:
+                bc.finish()
 
     @property
     def handle(self):
@@ -224,6 +297,14 @@ class RcclComm:
 
     def allreduce_max(self, vec):
         return self._reduce(vec, -1)
+
+    def allgather(self, vec):
+        """Every rank's vector (equal lengths) as the rows of a (world_size, n) array: one ncclAllGather."""
+        v = np.ascontiguousarray(vec, dtype=np.float64)
+        out = np.empty((self.world_size, v.size), dtype=np.float64)
+        self._L.check(self._L.lib.viprs_comm_allgather(self.handle, v.ctypes.data_as(ctypes.c_void_p), int(v.size),
+                                                       out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def barrier(self):
         self._L.check(self._L.lib.viprs_comm_barrier(self.handle))
@@ -268,6 +349,12 @@ class TorchDistComm:
     def allreduce_max(self, vec):
         return self._reduce(vec, self._dist.ReduceOp.MAX)
 
+    def allgather(self, vec):
+        t = self._torch.as_tensor(np.array(vec, dtype=np.float64)).to(self.device)
+        parts = [self._torch.empty_like(t) for _ in range(self.world_size)]
+        self._dist.all_gather(parts, t)
+        return np.stack([p.cpu().numpy() for p in parts])
+
     def barrier(self):
         self._dist.barrier()
 
@@ -275,33 +362,61 @@ class TorchDistComm:
 class FileComm:
     """Host-vector collectives through files in a shared directory: a TEST transport that lets the multi-rank host
     logic (bench.py --gpus N, the models) run with several processes on a box whose GPUs RCCL cannot span (e.g. two
-    ranks on one device).  Never the product path."""
+    ranks on one device).  Never the product path.  The directory carries a nonce drawn by rank 0 for THIS
+    communicator (`_RootBroadcast`), so files of an earlier run can never be read as current; every rank removes
+    its own files in `close()`, rank 0 the directory."""
     device_side = False
 
     def __init__(self, rank=None, world_size=None, root=None):
+        global _COMM_SEQ
+        import secrets
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
-        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        self.root = root or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"viprs_filecomm_{os.getuid()}_{tag}")
-        os.makedirs(self.root, exist_ok=True)
+        base = root or os.path.join(os.environ.get("TMPDIR", "/tmp"), f"viprs_filecomm_{os.getuid()}_{_launch_key()}")
+        base = f"{base}.{_COMM_SEQ}"
+        _COMM_SEQ += 1
         self._n = 0
+        self._mine = []
+        if self.world_size > 1:
+            bc = _RootBroadcast(self.rank, base, lambda: secrets.token_hex(8).encode())
+            self.root = f"{base}.{bc.payload.decode()}"
+            os.makedirs(self.root, exist_ok=True)
+            try:
+                self.barrier()                  # every rank holds the nonce
+            finally:
+                bc.finish()
+        else:
+            self.root = f"{base}.{secrets.token_hex(8)}"
+            os.makedirs(self.root, exist_ok=True)
 
     def _exchange(self, vec):
+        if self.root is None:
+            raise ValueError("FileComm is closed")
+        return self._exchange_in(self.root, vec)
+
+    def _exchange_in(self, root, vec):
         v = np.ascontiguousarray(vec, dtype=np.float64)
         self._n += 1
-        mine = os.path.join(self.root, f"{self._n}_{self.rank}.npy")
+        mine = os.path.join(root, f"{self._n}_{self.rank}.npy")
         tmp = mine + ".tmp.npy"
         np.save(tmp, v)
         os.replace(tmp, mine)
+        self._mine.append(mine)
         parts = []
         for r in range(self.world_size):
-            f = os.path.join(self.root, f"{self._n}_{r}.npy")
+            f = os.path.join(root, f"{self._n}_{r}.npy")
             t0 = time.time()
             while not os.path.exists(f):
                 if time.time() - t0 > 600:
                     raise TimeoutError(f"FileComm: rank {r} never wrote step {self._n}")
                 time.sleep(0.002)
             parts.append(np.load(f))
+        # everybody has read step n-2 once everybody has written step n-1 (which precedes reading it): drop it
+        while len(self._mine) > 2:
+            try:
+                os.remove(self._mine.pop(0))
+            except OSError:
+                pass
         return np.stack(parts)
 
     def allreduce_sum(self, vec):
@@ -310,11 +425,30 @@ class FileComm:
     def allreduce_max(self, vec):
         return self._exchange(vec).max(axis=0)
 
+    def allgather(self, vec):
+        return self._exchange(vec)
+
     def barrier(self):
         self._exchange(np.zeros(1))
 
     def close(self):
-        pass
+        """Collective: after one last barrier every rank has finished reading everything older, so each rank removes
+        its own older files, reports `done`, and rank 0 removes the directory once all ranks are done."""
+        if self.root is None:
+            return
+        root, self.root = self.root, None
+        if self.world_size > 1:
+            self._exchange_in(root, np.zeros(1))
+            with open(os.path.join(root, f"done_{self.rank}"), "wb"):
+                pass
+        if self.rank == 0:
+            t0 = time.time()
+            while time.time() - t0 < 10.0 and not all(os.path.exists(os.path.join(root, f"done_{r}"))
+                                                      for r in range(self.world_size if self.world_size > 1 else 0)):
+                time.sleep(0.005)
+            import shutil
+            shutil.rmtree(root, ignore_errors=True)
+        self._mine = []
 
 
 def broadcast_from_root(comm, values):
@@ -323,16 +457,3 @@ def broadcast_from_root(comm, values):
     if comm.world_size == 1:
         return v
     return comm.allreduce_sum(v if comm.rank == 0 else np.zeros_like(v))
-
-
-def assign_chromosomes(costs, world_size):
-    """Static longest-processing-time assignment of whole chromosomes (cost ~ LD entries) to ranks.
-    Returns {chromosome: rank}; deterministic, identical on every rank.  (Kept for callers that want
-    chromosome granularity; the models shard at LD-block granularity, see `shard_blocks`.)"""
-    load = [0.0] * world_size
-    owner = {}
-    for c in sorted(costs, key=lambda k: (-costs[k], str(k))):
-        r = min(range(world_size), key=lambda i: (load[i], i))
-        owner[c] = r
-        load[r] += float(costs[c])
-    return owner

@@ -148,8 +148,15 @@ def _sample_block(rng, b, rho, n_mult=4):
 LD_KINDS = ("ar1", "longrange", "sample")
 
 
+def longrange_params(sizes, seed=SEED):
+    """The per-block parameters of "longrange" LD for a whole workload (one sequential draw: a block keeps its
+    parameters whichever subset of the workload a rank builds)."""
+    prng = np.random.default_rng(seed + 3)
+    return [_longrange_params(prng, int(b)) for b in sizes]
+
+
 def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8),
-            rho=None, kind="ar1"):
+            rho=None, kind="ar1", params=None):
     """Block-diagonal LD in symmetric (`low_memory=False`: every row of a block stores the whole
     block, diagonal included) or upper-triangular form (`low_memory=True`: row j stores columns
     j+1 .. block_end-1, left bound j+1) -- the two layouts e_step.hpp:389-392,423-440 consumes.
@@ -189,10 +196,10 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
             rowlen[s:s + b] = b
             off += b * b
 
-    params = None
     if kind == "longrange":
-        prng = np.random.default_rng(seed + 3)
-        params = [_longrange_params(prng, int(b)) for b in sizes]
+        if params is None:
+            params = longrange_params(sizes, seed)
+        assert len(params) == len(sizes) and all(p[2].shape[0] == int(b) for p, b in zip(params, sizes))
     elif kind == "sample":
         # one generator per block so that the thread pool below cannot change the draws
         params = [np.random.default_rng([seed + 4, bi]) for bi in range(len(sizes))]
