@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements (N = 1: upper-triangular sweep; N > 1: weak scaling)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the multi-threaded CPU variants (default: affinity mask capped by the cgroup quota)")
     ap.add_argument("--model", default="spike_slab", choices=["spike_slab", "mixture", "grid"],
                     help="spike_slab = the headline (configs[1..2]); mixture = configs[3] (VIPRSMix); grid = configs[4]")
     ap.add_argument("--width", type=int, default=0, help="mixture components K (default 4) / grid models G (default 32)")
@@ -82,7 +84,31 @@ def shard_blocks_lpt(sizes, n_parts):
 
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------
-def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0=None):
+def usable_cpus():
+    """Hardware threads this process may really use: the scheduler affinity mask, capped by the cgroup CPU quota
+    (a container can show 256 CPUs and be allowed 8 -- OpenMP teams sized by os.cpu_count() then spin on each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, per = float(f1.read()), float(f2.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+               "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0=None, threads_override=0):
     """The reference's own e_step.hpp (oracle/_ref, built from /root/reference by oracle/Makefile) timed on
     this host, state re-initialised before every call:
       1. threads=1 (the parity reference);
@@ -98,7 +124,9 @@ def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0
     costs `width` times a spike-and-slab one); 3 runs the WHOLE workload (its sweep takes tens of ms)."""
     from oracle import oracle as O
     kind = "reference" if O.have_reference() else "restated"
-    cores = os.cpu_count() or 1
+    cores, host = usable_cpus()
+    if threads_override:
+        cores = int(threads_override)
     # ~0.2-0.5 M SNP-updates/s single-threaded: size the sample for ~budget/4 per single-thread pass
     target_snps = int(min(ld.m, max(2000, 0.08e6 * budget_s / max(1, width))))
     nb = int(np.searchsorted(ld.block_start, target_snps, side="left"))
@@ -168,6 +196,7 @@ def cpu_baseline(ld, inp, budget_s, model="spike_slab", width=1, extra=None, pi0
     return {
         "value": res["all_cores"], "unit": "SNP-updates/s", "cores": mt,
         "best_exact": {"variant": best, "value": exact[best], "threads": 1 if "single" in best else cores},
+        "host": host,
         "kind": "reference" if kind == "reference" else "port",
         "sample": f"first {nb} LD blocks ({m_s} SNPs, {nnz_s} LD entries) of the same workload, model={model}"
                   + (f" width={width}" if model != "spike_slab" else "")
@@ -516,7 +545,8 @@ def main():
         if weak is not None:
             out["weak_scaling"] = weak
         if n_gpus == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds, args.model, width, sw.host_extra, sw.pi0)
+            out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds, args.model, width, sw.host_extra, sw.pi0,
+                                               args.cpu_threads)
         print(json.dumps(out), flush=True)
 
     comm.barrier()

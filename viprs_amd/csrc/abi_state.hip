@@ -537,7 +537,8 @@ static int grid_column_check(viprs_state* S, int g) {
     if (!S) return fail(VIPRS_EINVAL, "null state");
     if (S->model_kind != VIPRS_MODEL_GRID) return fail(VIPRS_EINVAL, "not a grid state");
     if (g < 0 || g >= S->width) return fail(VIPRS_EINVAL, "model index out of range");
-    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    // (an empty plan has no per-SNP sample sizes to set: a rank without LD blocks passes)
+    if (!S->d_n.p && S->plan->m > 0) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
     return VIPRS_OK;
 }
 
