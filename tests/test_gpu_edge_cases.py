@@ -405,7 +405,7 @@ def test_device_resident_entry_points_reject_misuse(gpu):
 
 
 def test_dense_block_beyond_the_lds_limit(gpu):
-    """A dense block whose q does not fit the panel kernels' LDS (> ~29 000 SNPs) is scheduled like a
+    """A dense block whose q does not fit the panel kernels' LDS (> ~13 000 SNPs) is scheduled like a
     windowed component instead of failing: same bits as the oracle."""
     ld, ss, inp = syn.make_problem(sizes=[30500, 70], low_memory=True, ld_dtype=np.int8, seed=17)
     st0 = inp.state_copy()

@@ -146,9 +146,11 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         d.ld_off = 0;
         d.gr_off = 0;
         d.band_left = d.band_right = 0;
-        // the panel kernels keep q of a whole block in LDS: a dense block beyond that (~29 000 SNPs) is
-        // scheduled like a windowed component (band kernel if its ring fits, generic kernel otherwise)
+        // the panel kernels keep q of a whole block in LDS: a dense block beyond that (~13 000 SNPs) is
+        // scheduled like a windowed component (band kernel if its ring fits, generic kernel otherwise).  The binding
+        // case is the upper-triangular form (q and the second-pass sums s, no off-diagonal tile in LDS)
         constexpr int kMaxDenseBlock = (160 * 1024 / 4 - panel_lds_floats(kStrip) - panel_upper_lds_floats(kStrip) - kMixLdsFloats) / 2 / kPanel * kPanel;
+        static_assert(kMaxDenseBlock + kStrip + panel_lds_floats(kStrip, true) + kMixLdsFloats <= 160 * 1024 / 4, "symmetric form fits too");
         const bool dense = panel_ld && (b.kind == VIPRS_BLOCK_DENSE_SYM || b.kind == VIPRS_BLOCK_DENSE_UPPER) &&
                            d.size <= kMaxDenseBlock;
         if (dense) {

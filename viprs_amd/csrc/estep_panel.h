@@ -514,17 +514,25 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     //     off-diagonal tile R[p, p+1] of its next phase it prefetches into registers, one row per step, a whole
     //     phase ahead of its use);
     //   mixture (rolled chain loop): the off-diagonal tiles R[p-1, p] / R[p, p+1], diagonal rows from global memory.
+    constexpr bool kDiagInLds = !MODEL::kLaneParallel;
+    // symmetric form: the off-diagonal tile of the chain's next phase goes through LDS too (below).  The upper-triangular
+    // form keeps the chain's own register prefetch: its updater waves carry the second pass and are the busier side --
+    // staging one more tile per phase, and waiting for the chain's go-ahead to do so, costs them more than the chain wins
+    // (cfg3: 0.74 -> 0.77 ms with the tile in LDS, 0.80 -> 0.72-0.77 ms in the symmetric form)
+    constexpr bool kTileInLds = kDiagInLds && SYM;
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
-    float* lmx = lT + 2 * kPanel * kPanel;              // mixture chain only (kMixLdsFloats)
+    // lane-per-SNP models: the off-diagonal tile R[p, p+1] the chain's NEXT phase starts with (ONE buffer: staged by the
+    // updaters during phase p once the chain has consumed its predecessor -- s_tdone below)
+    float* lTo = lT + 2 * kPanel * kPanel;
+    float* lmx = lTo + (kTileInLds ? kPanel * kPanel : 0);   // mixture chain only (kMixLdsFloats)
     // upper-triangular form: eta_diff of the last two panels and the running second-pass sums s[j] of the block
     // (panel_upper_lds_floats; behind the mixture scratch)
     float* led = lmx + ((MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value) ? kMixLdsFloats : 0);
     float* ls = led + 2 * kPanel;
     // upper-triangular form: one 32-row transposition buffer per updater wave (HalfTileRows::to_rows), behind ls[qcap]
     char* tbuf = reinterpret_cast<char*>(ls + qcap) + (threadIdx.x >> 6 ? (threadIdx.x >> 6) - 1 : 0) * kPanelUpperTransposeBytes;
-    constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     constexpr bool kSecondPassViaLds = !(MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value);
 #ifndef PANEL_TEAM_STRIP_DEPTH
 #define PANEL_TEAM_STRIP_DEPTH kStripRowsInFlight
@@ -532,6 +540,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     // row loads in flight per updater lane: team blocks (the critical path) may take a larger share of the memory system
     constexpr int kDepth = TEAM ? PANEL_TEAM_STRIP_DEPTH : kStripRowsInFlight;
     __shared__ int s_blk;
+    __shared__ int s_tdone;        // phases whose off-diagonal tile the chain has consumed (gate of the single lTo buffer)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -597,6 +606,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 
         for (int i = tid; i < bpad + kStrip; i += NW * 64) lq[i] = (i < b) ? A.q[s0 + i] : 0.0f;
         if (!SYM) for (int i = tid; i < bpad; i += NW * 64) ls[i] = 0.0f;
+        if (tid == 0) s_tdone = 0;
         if (kDiagInLds) {
             // diagonal tile of panel 0 (rows past the end of a short block are clamped: finite values that
             // only ever meet a = 0)
@@ -613,7 +623,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         //      current panel's serial updates so that no HBM latency sits between two panels
         typename MODEL::In nxt_in{};
         float dnext[kChainPrefetch];                    // mixture chain: first diagonal rows of the next panel
-        float tnext[kDiagInLds ? kPanel : 1];           // lane-per-SNP chain: column `lane` of tile R[p, p+1], row by row
+        float tnext[(kDiagInLds && !kTileInLds) ? kPanel : 1];   // register prefetch of tile R[p, p+1]: column `lane`, row by row
         if (wave == 0) {
             const bool live0 = lane < b;
             nxt_in = MODEL::load(A, s0 + (live0 ? lane : 0), live0);
@@ -686,10 +696,20 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     }
                     PPROF(1, true);
                     if (p > 0) {
-                        if (kDiagInLds) {
+                        if (kDiagInLds && !kTileInLds) {
                             // a_{p-1} through tile R[p-1, p], prefetched into registers during the previous phase
 #pragma unroll
                             for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(tnext[k], rl(a_prev, k), qc);
+                        } else if (kTileInLds) {
+                            // a_{p-1} through tile R[p-1, p], staged in LDS by the updaters during the previous phase: the
+                            // chain wave issues NO vector-memory instruction between two panels and none inside one -- a
+                            // global load per step stalls at issue behind the updaters' loads when the chip is loaded
+                            // (chain step 135 ns on an idle chip, 170-230 ns in mid-sweep; in-kernel timeline)
+                            float trow[kPanel];
+#pragma unroll
+                            for (int k = 0; k < kPanel; ++k) trow[k] = lTo[k * kPanel + lane];
+#pragma unroll
+                            for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(trow[k], rl(a_prev, k), qc);
                         } else {
                             // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
                             const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
@@ -698,6 +718,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         }
                     }
 
+                    if (kTileInLds) {
+                        // the tile is consumed: the updaters may stage the next one (LDS executes a wave's operations in
+                        // order, so the reads above precede this store)
+                        if (lane == 0) *reinterpret_cast<volatile int*>(&s_tdone) = p + 1;
+                    }
                     PPROF(2, true);
                     if constexpr (is_wide_mixture<MODEL>::value) {
                         constexpr int KMAX = MODEL::kMax;
@@ -912,19 +937,20 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         //   * skipped steps (|d| < eps, e_step.hpp:410) become a = 0: fma(R, 0, q) == q.
                         //     Lanes past a partial last panel carry all-zero inputs (MODEL::load), which makes
                         //     their d exactly 0: they skip by themselves, no `live` test inside the loop;
-                        //   * the tile row R[p, p+1][jj, lane] the NEXT phase starts with is fetched here,
-                        //     one row per step: by the time it is used the load is a whole phase old.
                         float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
                         const float* __restrict__ Dt = lT + (p & 1) * kPanel * kPanel + lane;
-                        // rows of panel p x columns of panel p+1 (clamped into the block when there is no next panel)
-                        // (rows past a partial last panel run into the slack behind the dense LD buffer: loaded, never used)
+                        // register prefetch (upper-triangular form): rows of panel p x columns of panel p+1, one row per
+                        // step, a whole phase ahead of its use (clamped into the block when there is no next panel; rows
+                        // past a partial last panel run into the slack behind the dense LD buffer: loaded, never used)
                         const U* __restrict__ tptr = base + (int64_t)r0 * stride + min(r0 + kPanel, bpad - kPanel) + lane;
                         unsigned long long lane_bit = 1ull;
                         float qf = qc;
     #pragma unroll
                         for (int jj = 0; jj < kPanel; ++jj) {
-                            tnext[jj] = static_cast<float>(*tptr);
-                            tptr += stride;
+                            if (!kTileInLds) {
+                                tnext[jj] = static_cast<float>(*tptr);
+                                tptr += stride;
+                            }
                             const float dr = Dt[jj * kPanel];
                             const float d = MODEL::template delta<kLookupLane>(in, qf, tab, jj);
                             const float dz = (MODEL::kHasSkip && fabsf(d) < Eps<float>::value) ? 0.0f : d;   // :410
@@ -971,10 +997,29 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         const int row = 4 * min(uw + g * (NW - 1), kPanel / 4 - 1) + trow;
                         v[g] = load4<U>(base + (int64_t)min(row_base + row, b - 1) * stride + (p + 1) * kPanel + tcol);
                     }
+                    float4 w[kTileInLds ? kGroups : 1];
+                    if (kTileInLds) {
+                        // ... and the off-diagonal tile R[p, p+1] its next phase STARTS with (rows of this panel; rows past a
+                        // partial last panel are clamped: they only ever meet a = 0)
+#pragma unroll
+                        for (int g = 0; g < kGroups; ++g) {
+                            const int row = 4 * min(uw + g * (NW - 1), kPanel / 4 - 1) + trow;
+                            w[g] = load4<U>(base + (int64_t)min(p * kPanel + row, b - 1) * stride + (p + 1) * kPanel + tcol);
+                        }
+                    }
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) {
                         const int i = uw + g * (NW - 1);
                         if (i < kPanel / 4) *reinterpret_cast<float4*>(T + (4 * i + trow) * kPanel + tcol) = v[g];
+                    }
+                    if (kTileInLds) {
+                        // the single buffer still holds R[p-1, p] until the chain has applied it (first thing in its phase)
+                        while (*reinterpret_cast<volatile int*>(&s_tdone) < p + 1) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int g = 0; g < kGroups; ++g) {
+                            const int i = uw + g * (NW - 1);
+                            if (i < kPanel / 4) *reinterpret_cast<float4*>(lTo + (4 * i + trow) * kPanel + tcol) = w[g];
+                        }
                     }
                 }
                 PPROF(5, wave == 1);

@@ -10,7 +10,10 @@ constexpr int kStrip = 256;         // padding unit of the per-block q arrays (o
 
 // ---- sizes the host-side schedule shares with the kernel headers ------------------------------------
 // panel kernels (estep_panel.h): LDS carve (floats) q[qcap] | a[2][64] | T[2][64*64]
-__host__ __device__ constexpr int panel_lds_floats(int qcap) { return qcap + 2 * kPanel + 2 * kPanel * kPanel; }
+// (+ To[64*64], the off-diagonal tile of the chain's next phase, for the lane-per-SNP models: `offdiag_tile`)
+__host__ __device__ constexpr int panel_lds_floats(int qcap, bool offdiag_tile = false) {
+    return qcap + 2 * kPanel + 2 * kPanel * kPanel + (offdiag_tile ? kPanel * kPanel : 0);
+}
 // upper-triangular form: eta_diff[2][64] of the last two panels + the running second-pass sums s[qcap]
 constexpr int kPanelUpperTransposeBytes = 32 * 128;         // per updater wave: 32 rows of a half tile (fp32: 128 B per row)
 __host__ __device__ constexpr int panel_upper_lds_floats(int qcap, int n_waves = 4) {
