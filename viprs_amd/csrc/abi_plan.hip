@@ -286,11 +286,19 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
                 const int np = (P->dense_h[i].size + kPanel - 1) / kPanel;
                 for (int T = 0; 2 * T + 1 < np; ++T) low.push_back({(int32_t)i, T});
             }
+            // items of the blocks beyond the batched kernel's resident form first (the only ones it leaves to the lower
+            // pass by default), each group longest first
+            constexpr int kResMax = 6 * 2 * 2 * kPanel;             // = kGridResMaxCols (estep_grid_mfma.h)
             std::stable_sort(low.begin(), low.end(), [&](const EpiItem& x, const EpiItem& y) {
-                const int npx = (P->dense_h[(size_t)x.blk].size + kPanel - 1) / kPanel, npy = (P->dense_h[(size_t)y.blk].size + kPanel - 1) / kPanel;
+                const int bx = P->dense_h[(size_t)x.blk].size, by = P->dense_h[(size_t)y.blk].size;
+                const bool gx = bx > kResMax, gy = by > kResMax;
+                if (gx != gy) return gx;
+                const int npx = (bx + kPanel - 1) / kPanel, npy = (by + kPanel - 1) / kPanel;
                 return npx - 2 * x.row0 > npy - 2 * y.row0;
             });
             P->n_low_items = (int64_t)low.size();
+            P->n_low_items_big = 0;
+            for (const EpiItem& it : low) P->n_low_items_big += P->dense_h[(size_t)it.blk].size > kResMax ? 1 : 0;
             if (!low.empty()) {
                 HIP_TRY(P->d_low_items.alloc(low.size()));
                 HIP_TRY(hipMemcpy(P->d_low_items.p, low.data(), sizeof(EpiItem) * low.size(), hipMemcpyHostToDevice));

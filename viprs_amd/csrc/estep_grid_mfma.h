@@ -215,13 +215,423 @@ __device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)
     }
 }
 
+// ---- the chain wave's work for one panel: 64 serial SNP updates for all models ------------------------------
+template <bool SYM>
+__device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, float* io, float* la, float* dg, float* qx, int p, int b,
+                                                 int64_t s0, int lane, int n_models, float dq, const ExpTab& tab
+#ifdef VIPRS_GRID_PROFILE
+                                                 , int blk, unsigned* prof
+#endif
+                                                 ) {
+    const int cg = lane & 31, ch = lane >> 5;
+    const bool has_model = cg < n_models;
+#ifdef VIPRS_GRID_PROFILE
+    unsigned (*s_prof)[12] = reinterpret_cast<unsigned (*)[12]>(prof);
+#endif
+    const int r0 = p * kPanel;
+    const int nrows = min(kPanel, b - r0);
+    float* iob = io + (p & 1) * kGridIoFloats + cg * kGridIoPitch;
+    float* lap = la + (p & 1) * kGridAFloats + cg;
+    const float* drow = dg + (p & 1) * kGridDiagFloats + 32 * ch;
+    float* qmine = qx + (p & 1) * kGridQxFloats + cg * kGridQxPitch + 32 * ch;
+    // this lane's 32 columns of its model's q
+    // (register pairs: the row application below is v_pk_fma_f32, two columns per instruction)
+    f32x2 qv[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(qmine + 4 * i);
+        qv[2 * i] = has_model ? f32x2{v[0], v[1]} : f32x2{0.0f, 0.0f};
+        qv[2 * i + 1] = has_model ? f32x2{v[2], v[3]} : f32x2{0.0f, 0.0f};
+    }
+    const float betav = A.std_beta[s0 + min(r0 + lane, b - 1)];
+#ifdef VIPRS_GRID_PROFILE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    GPROF(2, true);
+    // row jj of the diagonal tile for this half: register c <-> column 32 h + ((c + 16 g4) & 31)
+    f32x2 rw[16];
+    auto load_row = [&](f32x2 (&dst)[16], int jr, int g4) {
+        const float* rp = drow + jr * kPanel;
+        const int o0 = 16 * (g4 & 1), o1 = 16 * ((g4 + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(rp + o0 + 4 * i);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(rp + o1 + 4 * i);
+            dst[2 * i] = f32x2{x[0], x[1]};
+            dst[2 * i + 1] = f32x2{x[2], x[3]};
+            dst[8 + 2 * i] = f32x2{y[0], y[1]};
+            dst[8 + 2 * i + 1] = f32x2{y[2], y[3]};
+        }
+    };
+    load_row(rw, 0, 0);
+    float mm = iob[0 * kGridIoArr], ulog = iob[1 * kGridIoArr], hvt = iob[2 * kGridIoArr],
+          eta_old = iob[3 * kGridIoArr];
+#pragma unroll 1
+    for (int g4 = 0; g4 < kPanel / 16; ++g4) {
+        const bool hi_owner = g4 >= 2;                                   // columns 32.. belong to half 1
+        const bool owner = (ch == 1) == hi_owner;
+        // (one LDS base per group of 16 SNPs: the SNP index inside the group is an immediate offset)
+        float* const iog = iob + 16 * g4;
+        float* const lag = lap + 16 * g4 * kGridModels;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int jj = 16 * g4 + k;                                  // wave-uniform
+            const bool live = jj < nrows;
+            // next SNP's inputs: in flight while this one is evaluated
+            const int jn = min(jj + 1, kPanel - 1);
+            const int kn = (k < 15) ? k + 1 : ((g4 < kPanel / 16 - 1) ? 16 : 15);   // = jn - 16 g4
+            const float mm_n = iog[0 * kGridIoArr + kn], ulog_n = iog[1 * kGridIoArr + kn],
+                        hvt_n = iog[2 * kGridIoArr + kn], eta_n = iog[3 * kGridIoArr + kn];
+            // the SNP's own q from the half that owns its column
+            const unsigned qbits = __float_as_uint(qv[k >> 1][k & 1]);
+            auto sw = __builtin_amdgcn_permlane32_swap(qbits, qbits, false, false);
+            const float qcur = __uint_as_float(hi_owner ? sw[1] : sw[0]);
+            const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
+            const float mu = mm * (beta - qcur);                         // e_step.hpp:613
+            const float u = ulog + hvt * mu * mu;                        // :616
+            const float gamma = sigmoid_exact<kLookupPerLane>(u, tab);   // :617
+            const float d = gamma * mu - eta_old;                        // :620
+            const float a = (live && has_model) ? dq * d : 0.0f;
+            // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order)
+            __builtin_amdgcn_sched_barrier(0);
+            f32x2 rn[16];
+            load_row(rn, jn, (jj + 1) >> 4);
+            const f32x2 a2 = {a, a};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {                               // :623, one IEEE fma per column
+                qv[c] = __builtin_elementwise_fma(rw[c], a2, qv[c]);
+                asm volatile("" : "+v"(qv[c]));      // apply now (hipcc would sink the chain to its use)
+            }
+            if (SYM) qv[k >> 1][k & 1] -= (live && owner && has_model) ? d : 0.0f;   // :629
+            if (has_model && live && ch == 0) {
+                iog[0 * kGridIoArr + k] = mu;
+                iog[1 * kGridIoArr + k] = gamma;
+                iog[2 * kGridIoArr + k] = d;
+                iog[3 * kGridIoArr + k] = eta_old + d;                    // :633
+            }
+            if (ch == 0) lag[k * kGridModels] = a;
+            mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) rw[c] = rn[c];
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch distance at one SNP
+        }
+        // rotate the q registers by one group of 16 columns
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x2 t = qv[c];
+            qv[c] = qv[8 + c];
+            qv[8 + c] = t;
+        }
+    }
+    GPROF(3, true);
+    if (has_model) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f32x4*>(qmine + 4 * i) = f32x4{qv[2 * i][0], qv[2 * i][1], qv[2 * i + 1][0], qv[2 * i + 1][1]};
+    }
+}
+
 constexpr int kGridWaves = 8;                      // 1 chain wave + 7 updater waves
 constexpr int kGridNU = kGridWaves - 1;
 constexpr int kGridPerWave = (kGridModels + kGridNU - 1) / kGridNU;     // model rows a wave stages / flushes
 constexpr int kGridDiagPerWave = (kPanel + kGridNU - 1) / kGridNU;      // diagonal-tile rows a wave stages
 
+
+// =====================================================================================================================
+// Resident form (blocks of up to kGridResMaxCols SNPs): q of the WHOLE block lives in the accumulator registers of the
+// updater waves for as long as the block is swept -- read from the state once, written once -- and every LD row of the
+// block is read exactly once: the tiles LEFT of the chain (symmetric form) receive the later rows from the same waves,
+// in the same row order, so estep_grid_lower_pass_kernel has nothing left to do for these blocks.
+//
+//   wave 0      chain, as in the streaming form (grid_chain_panel).
+//   wave 1      carry: takes the 64 columns of panel p+1 out of their owner's registers one phase ahead (through LDS,
+//               `cq`), applies a_{p-1} during phase p and a_p between the chain's two panels, hands them to the chain
+//               (qx) -- the accumulators stay in ITS registers across the barriers (own loop over the phases).
+//   waves 2..7  owners: wave w holds the 128-column tiles T = w - 2 and T = w + 4 (32 models x 128 columns = 64
+//               accumulator registers each).  Per phase p they apply the rows of panel p-1 (a_{p-1}) to their tiles --
+//               LD rows in 4 chunks of 8 16-byte loads -- except to the panels that
+//               are "away": p-1 (its own rows are the chain's diagonal tile), p and p+1 (with the carry).  The B operand
+//               of a masked half is 0: fma(a, 0, acc) == acc (q is never -0: it starts at +0 and a sum is -0 only if
+//               both addends are).  A panel comes back from the chain one phase after it was swept (qx).
+// Same arithmetic per (model, column) as the streaming form and as e_step_grid: the rows arrive in ascending order.
+// =====================================================================================================================
+constexpr int kGridResOwners = 6;
+constexpr int kGridResSlots = 2;
+constexpr int kGridResMaxCols = kGridResOwners * kGridResSlots * 2 * kPanel;      // 1536
+
+// rows of panel `pp` x the 128 columns from c0 applied to a resident tile; `on_l` / `on_r`: the left / right 64 columns
+// take the update (a masked half gets B = 0)
+template <typename U>
+__device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __restrict__ base, int stride, int pp, int c0,
+                                               int lane, bool on_l, bool on_r, const float* __restrict__ a_lds) {
+    using V = typename Vec4<U>::type;
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool lane_on = (lane & 16) ? on_r : on_l;
+    int col = c0 + 4 * l31;
+    if (col >= stride) col = c0;                      // right half of the last (odd) tile: masked (on_r == false)
+    const unsigned voff = (unsigned)((half * stride + (col - c0)) * (int)sizeof(U));
+    const char* __restrict__ sb = reinterpret_cast<const char*>(base + (int64_t)pp * kPanel * stride + c0);
+    const size_t step = (size_t)2 * stride * sizeof(U);
+    // 4 chunks of 8 row pairs, ONE chunk in registers at a time (32 VGPRs): the loads of a chunk are not overlapped
+    // with this wave's own MFMAs -- the other owner waves of the SIMD fill the matrix pipe meanwhile, and a deeper ring
+    // (64 VGPRs) next to the 128 accumulator registers pushes loop-invariant addresses into scratch
+    constexpr int CH = 8;
+#pragma unroll
+    for (int c = 0; c < kPanel / 2 / CH; ++c) {
+        V ring[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) ring[i] = *reinterpret_cast<const V*>(sb + (c * CH + i) * step + voff);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const V v = ring[i];
+            const float aop = a_lds[(2 * (c * CH + i) + half) * kGridModels + l31];      // A[model = lane & 31][k = lane >> 5]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bop = lane_on ? static_cast<float>(v[j]) : 0.0f;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc[j], 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <typename U, bool SYM>
-__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A) {
+__device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, float* io, float* la, float* dg, f32x4* cy,
+                                                    float* qx, const int* s_act, const BlockDesc& bd, int wave, int lane,
+                                                    int n_models, float dq, const ExpTab& tab) {
+    constexpr int NU = kGridNU;
+    const int64_t s0 = bd.start;
+    const int b = bd.size, stride = bd.stride;
+    const U* __restrict__ base = static_cast<const U*>(A.ld_dense) + bd.ld_off;
+    const int np = (b + kPanel - 1) / kPanel;
+    float* cq = reinterpret_cast<float*>(cy + 16 * 64);          // [32 models][64 columns]: a panel on its way to the carry
+    const int half = lane >> 5, n = lane & 31;
+
+    // the per-panel input / output staging of the streaming form (waves 1..7; sym: q of a panel is NOT written here)
+    auto stage_inputs = [&](int pp, bool with_q) {
+        float* dst = io + (pp & 1) * kGridIoFloats;
+        const int r0 = pp * kPanel;
+        const int j = r0 + lane;
+        const bool ok = j < b;
+        const unsigned jo = (unsigned)s0 + (ok ? j : 0);
+        float v[kGridPerWave][5];
+#pragma unroll
+        for (int i = 0; i < kGridPerWave; ++i) {
+            const int g = min(wave - 1 + NU * i, kGridModels - 1);
+            const unsigned off = (unsigned)s_act[g] * (unsigned)A.m + jo;
+            v[i][0] = A.mu_mult[off]; v[i][1] = A.u_logs[off]; v[i][2] = A.shvt[off]; v[i][3] = A.eta[off];
+            v[i][4] = with_q ? A.q[off] : 0.0f;
+        }
+        const int nrows = min(kPanel, b - r0);
+        const U* __restrict__ dp = base + (int64_t)r0 * stride + r0 + lane;
+        float dv[kGridDiagPerWave];
+#pragma unroll
+        for (int i = 0; i < kGridDiagPerWave; ++i)
+            dv[i] = static_cast<float>(dp[(int64_t)min(wave - 1 + NU * i, nrows - 1) * stride]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < kGridPerWave; ++i) {
+            const int g = wave - 1 + NU * i;
+            if (g < n_models) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) dst[a * kGridIoArr + g * kGridIoPitch + lane] = ok ? v[i][a] : 0.0f;
+                if (with_q) qx[(pp & 1) * kGridQxFloats + g * kGridQxPitch + lane] = ok ? v[i][4] : 0.0f;
+            }
+        }
+        float* dd = dg + (pp & 1) * kGridDiagFloats;
+#pragma unroll
+        for (int i = 0; i < kGridDiagPerWave; ++i) {
+            const int t = wave - 1 + NU * i;
+            if (t < kPanel) dd[t * kPanel + lane] = dv[i];
+        }
+    };
+    auto flush_outputs = [&](int pp) {
+        const float* src = io + (pp & 1) * kGridIoFloats;
+        const float* qs = qx + (pp & 1) * kGridQxFloats;
+        const int j = pp * kPanel + lane;
+        if (j < b) {
+#pragma unroll
+            for (int i = 0; i < kGridPerWave; ++i) {
+                const int g = wave - 1 + NU * i;
+                if (g < n_models) {
+                    const unsigned off = (unsigned)s_act[g] * (unsigned)A.m + (unsigned)(s0 + j);
+                    A.var_mu[off] = src[0 * kGridIoArr + g * kGridIoPitch + lane];
+                    A.var_gamma[off] = src[1 * kGridIoArr + g * kGridIoPitch + lane];
+                    A.eta_diff[off] = src[2 * kGridIoArr + g * kGridIoPitch + lane];
+                    A.eta[off] = src[3 * kGridIoArr + g * kGridIoPitch + lane];
+                    // upper-triangular form: q of the panel is final (its second pass is the epilogue kernel's); symmetric
+                    // form: the panel goes back to its owner and is stored with the block
+                    if (!SYM) A.q[off] = qs[g * kGridQxPitch + lane];
+                }
+            }
+        }
+    };
+
+    if (wave == 0) {
+        // ================================================= chain =========================================================
+        __syncthreads();                                            // B0: inputs of panel 0 staged
+        for (int p = 0; p <= np; ++p) {
+            __syncthreads();                                        // mid: the carry has put panel p into qx
+            if (p < np)
+                grid_chain_panel<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
+#ifdef VIPRS_GRID_PROFILE
+                                      , 1, nullptr
+#endif
+                                      );
+            __syncthreads();                                        // end
+        }
+    } else if (wave == 1) {
+        // ================================================= carry =========================================================
+        stage_inputs(0, true);
+        __syncthreads();                                            // B0
+        // the carried panel: during phase p it is panel p+1 (taking a_{p-1}), between the chain's panels it is finished
+        // with a_p and handed to the chain; then the next one is picked up (ONE set of 32 accumulators, in registers
+        // across the barriers)
+        f32x16 c0v, c1v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c0v[r] = 0.0f; c1v[r] = 0.0f; }
+        for (int p = 0; p <= np; ++p) {
+            if (p > 0 && p < np) {
+                float R1[kPanel];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const f32x4 v = cy[i * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) R1[4 * i + e] = v[e];
+                }
+                tile_compute(c0v, c1v, R1, la + ((p - 1) & 1) * kGridAFloats, lane);
+                float* qd = qx + (p & 1) * kGridQxFloats + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    qd[g * kGridQxPitch] = c0v[r];
+                    qd[g * kGridQxPitch + 32] = c1v[r];
+                }
+            }
+            if (p + 1 < np) {
+                // panel p+1 as its owner left it at the end of the previous phase (a_0 .. a_{p-2} applied)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    c0v[r] = cq[g * kPanel + n];
+                    c1v[r] = cq[g * kPanel + 32 + n];
+                }
+            }
+            __syncthreads();                                        // mid
+            if (p > 0) flush_outputs(p - 1);
+            if (p + 1 < np) stage_inputs(p + 1, false);
+            if (p + 1 < np) {
+                // one tile of LD rows at a time (this wave has the whole phase for two memory round trips; both tiles in
+                // registers at once, 128 VGPRs, is what pushed loop-invariant addresses of every role into scratch)
+                if (p > 0) {
+                    float R0[kPanel];
+                    tile_load_rows<U>(R0, base, stride, b, p - 1, p + 1, lane);
+                    tile_compute(c0v, c1v, R0, la + ((p - 1) & 1) * kGridAFloats, lane);
+                    asm volatile("" : "+v"(c0v), "+v"(c1v) :: "memory");
+                }
+                float R1[kPanel];
+                tile_load_rows<U>(R1, base, stride, b, p, p + 1, lane);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) cy[i * 64 + lane] = f32x4{R1[4 * i], R1[4 * i + 1], R1[4 * i + 2], R1[4 * i + 3]};
+            }
+            __syncthreads();                                        // end
+        }
+    } else {
+        // ================================================= owners ========================================================
+        const int ow = wave - 2;
+        f32x16 accA[4], accB[4];                                    // tiles T = ow and T = ow + kGridResOwners
+        const int cA = ow * 2 * kPanel, cB = (ow + kGridResOwners) * 2 * kPanel;
+        const bool hasA = cA < b, hasB = cB < b;
+        auto load_tile = [&](f32x16 (&acc)[4], int c0, bool has) {
+            if (!has) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+                return;
+            }
+            const bool lane_ok = (n < 16) || (c0 + kPanel < b);
+            if (c0 + 2 * kPanel <= b) wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+            else wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+        };
+        load_tile(accA, cA, hasA);
+        load_tile(accB, cB, hasB);
+        // the 64 columns of panel `e` out of the tile that holds them -> cq (for the carry); `e` belongs to this wave
+        auto extract = [&](const f32x16 (&acc)[4], int e) {
+            if ((n >= 16) == ((e & 1) != 0)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    *reinterpret_cast<f32x4*>(cq + g * kPanel + 4 * (n & 15)) = f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                }
+            }
+        };
+        // ... and back from the chain (qx of the panel's phase): the final value of the panel's own sweep
+        auto take_back = [&](f32x16 (&acc)[4], int e) {
+            if ((n >= 16) == ((e & 1) != 0)) {
+                const float* qs = qx + (e & 1) * kGridQxFloats;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(qs + g * kGridQxPitch + 4 * (n & 15));
+                    const bool okg = g < n_models;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j][r] = okg ? v[j] : 0.0f;
+                }
+            }
+        };
+        auto tile_of = [&](int panel) { return panel >> 1; };
+        if (np > 1) {
+            if (tile_of(1) == ow) extract(accA, 1);                 // (tile 0 is wave 2's first tile)
+        }
+        stage_inputs(0, true);
+        __syncthreads();                                            // B0
+        for (int p = 0; p <= np; ++p) {
+            __syncthreads();                                        // mid
+            if (p > 0) flush_outputs(p - 1);
+            if (p + 1 < np) stage_inputs(p + 1, false);
+            if (p > 0) {
+                const int pp = p - 1;
+                if (SYM) {
+                    if (tile_of(pp) == ow) take_back(accA, pp);
+                    else if (tile_of(pp) == ow + kGridResOwners) take_back(accB, pp);
+                }
+                const float* a_lds = la + (pp & 1) * kGridAFloats;
+                auto panel_on = [&](int c) {
+                    if (c >= np) return false;
+                    return SYM ? (c < p - 1 || c > p + 1) : (c > p + 1);
+                };
+                if (hasA) {
+                    const bool l = panel_on(2 * ow), r = panel_on(2 * ow + 1);
+                    if (l || r) res_tile_apply<U>(accA, base, stride, pp, cA, lane, l, r, a_lds);
+                }
+                if (hasB) {
+                    const int T = ow + kGridResOwners;
+                    const bool l = panel_on(2 * T), r = panel_on(2 * T + 1);
+                    if (l || r) res_tile_apply<U>(accB, base, stride, pp, cB, lane, l, r, a_lds);
+                }
+            }
+            if (p + 2 < np) {
+                const int e = p + 2;                                // (a_0 .. a_{p-1} applied) -> the carry's next panel
+                if (tile_of(e) == ow) extract(accA, e);
+                else if (tile_of(e) == ow + kGridResOwners) extract(accB, e);
+            }
+            __syncthreads();                                        // end
+        }
+        if (SYM) {
+            auto store_tile = [&](const f32x16 (&acc)[4], int c0) {
+                const bool lane_ok = (n < 16) || (c0 + kPanel < b);
+                if (c0 + 2 * kPanel <= b) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+                else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+            };
+            if (hasA) store_tile(accA, cA);
+            if (hasB) store_tile(accB, cB);
+        }
+    }
+}
+
+template <typename U, bool SYM>
+__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, int resident_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* io = smem;                                   // [2][4][32][65]: mm, ulog, hvt, eta -> mu, gamma, d, eta'
     float* la = smem + 2 * kGridIoFloats;               // [2][64][32] scaled eta_diff of a panel
@@ -252,6 +662,11 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
         __syncthreads();
         if (blk >= A.n_blocks) break;
         const BlockDesc bd = A.blocks[blk];
+        if (bd.size <= resident_max) {
+            // q of the whole block fits the updater waves' accumulator registers: resident form (above)
+            grid_block_resident<U, SYM>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
+            continue;
+        }
         const int64_t s0 = bd.start;
         const int b = bd.size, stride = bd.stride;
         const U* __restrict__ base = ldd + bd.ld_off;
@@ -356,109 +771,12 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
             GPROF(1, wave == 0);
             if (wave == 0) {
                 // ---- (2) chain: 64 serial SNP updates for all models
-                if (p < np) {
-                    const int r0 = p * kPanel;
-                    const int nrows = min(kPanel, b - r0);
-                    float* iob = io + (p & 1) * kGridIoFloats + cg * kGridIoPitch;
-                    float* lap = la + (p & 1) * kGridAFloats + cg;
-                    const float* drow = dg + (p & 1) * kGridDiagFloats + 32 * ch;
-                    float* qmine = qx + (p & 1) * kGridQxFloats + cg * kGridQxPitch + 32 * ch;
-                    // this lane's 32 columns of its model's q
-                    // (register pairs: the row application below is v_pk_fma_f32, two columns per instruction)
-                    f32x2 qv[16];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(qmine + 4 * i);
-                        qv[2 * i] = has_model ? f32x2{v[0], v[1]} : f32x2{0.0f, 0.0f};
-                        qv[2 * i + 1] = has_model ? f32x2{v[2], v[3]} : f32x2{0.0f, 0.0f};
-                    }
-                    const float betav = A.std_beta[s0 + min(r0 + lane, b - 1)];
+                if (p < np)
+                    grid_chain_panel<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
 #ifdef VIPRS_GRID_PROFILE
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                                          , blk, &s_prof[0][0]
 #endif
-                    GPROF(2, true);
-                    // row jj of the diagonal tile for this half: register c <-> column 32 h + ((c + 16 g4) & 31)
-                    f32x2 rw[16];
-                    auto load_row = [&](f32x2 (&dst)[16], int jr, int g4) {
-                        const float* rp = drow + jr * kPanel;
-                        const int o0 = 16 * (g4 & 1), o1 = 16 * ((g4 + 1) & 1);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const f32x4 x = *reinterpret_cast<const f32x4*>(rp + o0 + 4 * i);
-                            const f32x4 y = *reinterpret_cast<const f32x4*>(rp + o1 + 4 * i);
-                            dst[2 * i] = f32x2{x[0], x[1]};
-                            dst[2 * i + 1] = f32x2{x[2], x[3]};
-                            dst[8 + 2 * i] = f32x2{y[0], y[1]};
-                            dst[8 + 2 * i + 1] = f32x2{y[2], y[3]};
-                        }
-                    };
-                    load_row(rw, 0, 0);
-                    float mm = iob[0 * kGridIoArr], ulog = iob[1 * kGridIoArr], hvt = iob[2 * kGridIoArr],
-                          eta_old = iob[3 * kGridIoArr];
-#pragma unroll 1
-                    for (int g4 = 0; g4 < kPanel / 16; ++g4) {
-                        const bool hi_owner = g4 >= 2;                                   // columns 32.. belong to half 1
-                        const bool owner = (ch == 1) == hi_owner;
-                        // (one LDS base per group of 16 SNPs: the SNP index inside the group is an immediate offset)
-                        float* const iog = iob + 16 * g4;
-                        float* const lag = lap + 16 * g4 * kGridModels;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const int jj = 16 * g4 + k;                                  // wave-uniform
-                            const bool live = jj < nrows;
-                            // next SNP's inputs: in flight while this one is evaluated
-                            const int jn = min(jj + 1, kPanel - 1);
-                            const int kn = (k < 15) ? k + 1 : ((g4 < kPanel / 16 - 1) ? 16 : 15);   // = jn - 16 g4
-                            const float mm_n = iog[0 * kGridIoArr + kn], ulog_n = iog[1 * kGridIoArr + kn],
-                                        hvt_n = iog[2 * kGridIoArr + kn], eta_n = iog[3 * kGridIoArr + kn];
-                            // the SNP's own q from the half that owns its column
-                            const unsigned qbits = __float_as_uint(qv[k >> 1][k & 1]);
-                            auto sw = __builtin_amdgcn_permlane32_swap(qbits, qbits, false, false);
-                            const float qcur = __uint_as_float(hi_owner ? sw[1] : sw[0]);
-                            const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
-                            const float mu = mm * (beta - qcur);                         // e_step.hpp:613
-                            const float u = ulog + hvt * mu * mu;                        // :616
-                            const float gamma = sigmoid_exact<kLookupPerLane>(u, tab);   // :617
-                            const float d = gamma * mu - eta_old;                        // :620
-                            const float a = (live && has_model) ? dq * d : 0.0f;
-                            // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order)
-                            __builtin_amdgcn_sched_barrier(0);
-                            f32x2 rn[16];
-                            load_row(rn, jn, (jj + 1) >> 4);
-                            const f32x2 a2 = {a, a};
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) {                               // :623, one IEEE fma per column
-                                qv[c] = __builtin_elementwise_fma(rw[c], a2, qv[c]);
-                                asm volatile("" : "+v"(qv[c]));      // apply now (hipcc would sink the chain to its use)
-                            }
-                            if (SYM) qv[k >> 1][k & 1] -= (live && owner && has_model) ? d : 0.0f;   // :629
-                            if (has_model && live && ch == 0) {
-                                iog[0 * kGridIoArr + k] = mu;
-                                iog[1 * kGridIoArr + k] = gamma;
-                                iog[2 * kGridIoArr + k] = d;
-                                iog[3 * kGridIoArr + k] = eta_old + d;                    // :633
-                            }
-                            if (ch == 0) lag[k * kGridModels] = a;
-                            mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n;
-#pragma unroll
-                            for (int c = 0; c < 16; ++c) rw[c] = rn[c];
-                            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch distance at one SNP
-                        }
-                        // rotate the q registers by one group of 16 columns
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const f32x2 t = qv[c];
-                            qv[c] = qv[8 + c];
-                            qv[8 + c] = t;
-                        }
-                    }
-                    GPROF(3, true);
-                    if (has_model) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            *reinterpret_cast<f32x4*>(qmine + 4 * i) = f32x4{qv[2 * i][0], qv[2 * i][1], qv[2 * i + 1][0], qv[2 * i + 1][1]};
-                    }
-                }
+                                          );
             } else {
                 // ---- (3) waves 1..7, concurrently with the chain: outputs of panel p-1 out of io[(p-1)&1],
                 //      inputs of panel p+1 into the same buffer (each wave flushes and refills its own
