@@ -155,9 +155,11 @@ __device__ __forceinline__ void wtile_load_rows(f32x4 (&R)[kPanel / 2], const U*
 
 // accumulators acc[j][r]: model (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c0 + 4 (lane & 31) + j.
 // FULL: the tile lies inside the block (vector access); otherwise element-wise with column masks.
+// (two halves, so that a tile's accumulators can be in flight while another tile is multiplied: `issue` only loads,
+// `finish` applies the masks)
 template <bool FULL>
-__device__ __forceinline__ void wtile_load_acc(f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act, int64_t s0,
-                                               int b, int c0, bool lane_ok, int n_models, int lane) {
+__device__ __forceinline__ void wtile_load_acc_issue(f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act, int64_t s0,
+                                                     int b, int c0, bool lane_ok, int lane) {
     const int half = lane >> 5, c = c0 + 4 * (lane & 31);
     // raw loads straight into the accumulator registers, masks applied once everything is in flight
 #pragma unroll
@@ -174,6 +176,10 @@ __device__ __forceinline__ void wtile_load_acc(f32x16 (&acc)[4], const EStepArgs
         }
     }
     asm volatile("" ::: "memory");
+}
+template <bool FULL>
+__device__ __forceinline__ void wtile_load_acc_finish(f32x16 (&acc)[4], int b, int c0, bool lane_ok, int n_models, int lane) {
+    const int half = lane >> 5, c = c0 + 4 * (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -181,6 +187,12 @@ __device__ __forceinline__ void wtile_load_acc(f32x16 (&acc)[4], const EStepArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j][r] = (ok && (FULL || c + j < b)) ? acc[j][r] : 0.0f;
     }
+}
+template <bool FULL>
+__device__ __forceinline__ void wtile_load_acc(f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act, int64_t s0,
+                                               int b, int c0, bool lane_ok, int n_models, int lane) {
+    wtile_load_acc_issue<FULL>(acc, A, act, s0, b, c0, lane_ok, lane);
+    wtile_load_acc_finish<FULL>(acc, b, c0, lane_ok, n_models, lane);
 }
 
 template <bool FULL>
@@ -337,6 +349,74 @@ constexpr int kGridPerWave = (kGridModels + kGridNU - 1) / kGridNU;     // model
 constexpr int kGridDiagPerWave = (kPanel + kGridNU - 1) / kGridNU;      // diagonal-tile rows a wave stages
 
 
+// ---- symmetric form, columns left of the chain: one 128-column tile (estep_grid_lower_pass_kernel, see there) ----
+constexpr int kGridLowWaves = 4;
+constexpr int kGridLowEPitch = kGridModels + 1;
+constexpr int kGridLowWaveFloats = 2 * kPanel * kGridLowEPitch;
+
+// one 128-column tile `T` of block `bd`: every row below the tile's own panels, in row order, accumulators in registers
+// (el: this wave's [2][64][33] staging of dq * eta_diff)
+template <typename U>
+__device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const int* s_act, const BlockDesc& bd, int T, float* el,
+                                                int lane, int n_models, float dq) {
+    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
+    const int n = lane & 31;
+    const int b = bd.size, stride = bd.stride;
+    const int64_t s0 = bd.start;
+    const U* __restrict__ base = ldd + bd.ld_off;
+    const int np = (b + kPanel - 1) / kPanel;
+    const int c0 = T * 2 * kPanel;
+    const int p_first = 2 * T + 1;                              // first panel below the tile's left half
+    if (p_first >= np) return;
+    const bool right = 2 * T + 1 < np;                          // the right 64 columns exist
+    const bool lane_ok = (n < 16) || right;
+    const bool full = c0 + 2 * kPanel <= b;
+
+    f32x16 acc[4];
+    if (full) wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+    else wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+
+    // a tile of panel pq into el[buf]: rows pq*64 .. +63 x models
+    auto stage_a = [&](int pq, int buf) {
+        float* e = el + buf * kPanel * kGridLowEPitch;
+        const int row = pq * kPanel + lane;
+        const bool ok = row < b;
+        const unsigned off = (unsigned)s0 + (unsigned)min(row, b - 1);
+        float v[kGridModels];
+#pragma unroll
+        for (int g = 0; g < kGridModels; ++g) v[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < kGridModels; ++g) e[lane * kGridLowEPitch + g] = (ok && g < n_models) ? dq * v[g] : 0.0f;
+    };
+    f32x4 R0[kPanel / 2], R1[kPanel / 2];
+    wtile_load_rows<U>(R0, base, stride, p_first, c0, lane);
+    stage_a(p_first, 0);
+    int buf = 0;
+    for (int pq = p_first; pq < np; pq += 2) {
+        // -- panel pq from R0 / el[buf], panel pq + 1 in flight into R1
+        const int p1 = min(pq + 1, np - 1);
+        wtile_load_rows<U>(R1, base, stride, p1, c0, lane);
+        if (pq == p_first && n >= 16) {
+#pragma unroll
+            for (int i = 0; i < kPanel / 2; ++i) R0[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // right half: its own panel, no update
+        }
+        __builtin_amdgcn_wave_barrier();
+        wtile_compute(acc, R0, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
+        if (pq + 1 >= np) break;
+        stage_a(pq + 1, buf ^ 1);
+        // -- panel pq + 1 from R1, panel pq + 2 in flight into R0
+        const int p2 = min(pq + 2, np - 1);
+        wtile_load_rows<U>(R0, base, stride, p2, c0, lane);
+        __builtin_amdgcn_wave_barrier();
+        wtile_compute(acc, R1, el + (buf ^ 1) * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
+        if (pq + 2 < np) stage_a(pq + 2, buf);
+    }
+    if (full) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+    else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+}
+
+
 // =====================================================================================================================
 // Resident form (blocks of up to kGridResMaxCols SNPs): q of the WHOLE block lives in the accumulator registers of the
 // updater waves for as long as the block is swept -- read from the state once, written once -- and every LD row of the
@@ -359,32 +439,50 @@ constexpr int kGridResOwners = 6;
 constexpr int kGridResSlots = 2;
 constexpr int kGridResMaxCols = kGridResOwners * kGridResSlots * 2 * kPanel;      // 1536
 
-// rows of panel `pp` x the 128 columns from c0 applied to a resident tile; `on_l` / `on_r`: the left / right 64 columns
-// take the update (a masked half gets B = 0)
-template <typename U>
+// rows of panel `pp` x the 128 columns from c0 applied to a tile whose accumulators are in registers; `on_l` / `on_r`: the
+// left / right 64 columns take the update (a masked half gets B = 0).  LD rows in 4 chunks of 8 row pairs (one 16-byte load
+// per lane = rows 2i, 2i+1 x 128 columns = the B operands of four MFMAs) through a register ring of DEPTH chunks:
+//   DEPTH 1 (resident form, 32 VGPRs): a chunk's loads are not overlapped with this wave's own MFMAs -- the other owner
+//           waves of the SIMD fill the matrix pipe meanwhile (a deeper ring next to 128 accumulator registers pushes
+//           loop-invariant addresses into scratch);
+//   DEPTH 2 (streaming form, 64 VGPRs): the next chunk is in flight while the current one is multiplied.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// (`after_first_issue` runs once the first chunk's loads are out and before the first MFMA: the streaming form finishes
+// the tile's accumulator loads there, so that they and the first rows share one memory round trip)
+template <typename U, int DEPTH, typename HOOK = NoHook>
 __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __restrict__ base, int stride, int pp, int c0,
-                                               int lane, bool on_l, bool on_r, const float* __restrict__ a_lds) {
+                                               int lane, bool on_l, bool on_r, const float* __restrict__ a_lds,
+                                               HOOK after_first_issue = HOOK()) {
     using V = typename Vec4<U>::type;
     const int half = lane >> 5, l31 = lane & 31;
     const bool lane_on = (lane & 16) ? on_r : on_l;
     int col = c0 + 4 * l31;
-    if (col >= stride) col = c0;                      // right half of the last (odd) tile: masked (on_r == false)
+    if (col >= stride) col = c0;                      // right half of the last (odd) tile: masked by the caller
     const unsigned voff = (unsigned)((half * stride + (col - c0)) * (int)sizeof(U));
     const char* __restrict__ sb = reinterpret_cast<const char*>(base + (int64_t)pp * kPanel * stride + c0);
     const size_t step = (size_t)2 * stride * sizeof(U);
-    // 4 chunks of 8 row pairs, ONE chunk in registers at a time (32 VGPRs): the loads of a chunk are not overlapped
-    // with this wave's own MFMAs -- the other owner waves of the SIMD fill the matrix pipe meanwhile, and a deeper ring
-    // (64 VGPRs) next to the 128 accumulator registers pushes loop-invariant addresses into scratch
-    constexpr int CH = 8;
+    constexpr int CH = 8, NCH = kPanel / 2 / CH;
+    V ring[DEPTH][CH];
+    if (DEPTH == 2) {
 #pragma unroll
-    for (int c = 0; c < kPanel / 2 / CH; ++c) {
-        V ring[CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i) ring[i] = *reinterpret_cast<const V*>(sb + (c * CH + i) * step + voff);
+        for (int i = 0; i < CH; ++i) ring[0][i] = *reinterpret_cast<const V*>(sb + i * step + voff);
         asm volatile("" ::: "memory");
+        after_first_issue();
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (DEPTH == 1) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) ring[0][i] = *reinterpret_cast<const V*>(sb + (c * CH + i) * step + voff);
+            asm volatile("" ::: "memory");
+        } else if (c + 1 < NCH) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) ring[(c + 1) & 1][i] = *reinterpret_cast<const V*>(sb + ((c + 1) * CH + i) * step + voff);
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const V v = ring[i];
+            const V v = ring[DEPTH == 2 ? (c & 1) : 0][i];
             const float aop = a_lds[(2 * (c * CH + i) + half) * kGridModels + l31];      // A[model = lane & 31][k = lane >> 5]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -603,12 +701,12 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                 };
                 if (hasA) {
                     const bool l = panel_on(2 * ow), r = panel_on(2 * ow + 1);
-                    if (l || r) res_tile_apply<U>(accA, base, stride, pp, cA, lane, l, r, a_lds);
+                    if (l || r) res_tile_apply<U, 1>(accA, base, stride, pp, cA, lane, l, r, a_lds);
                 }
                 if (hasB) {
                     const int T = ow + kGridResOwners;
                     const bool l = panel_on(2 * T), r = panel_on(2 * T + 1);
-                    if (l || r) res_tile_apply<U>(accB, base, stride, pp, cB, lane, l, r, a_lds);
+                    if (l || r) res_tile_apply<U, 1>(accB, base, stride, pp, cB, lane, l, r, a_lds);
                 }
             }
             if (p + 2 < np) {
@@ -796,30 +894,33 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                     const int pp = p - 1;
                     const float* a_lds = la + (pp & 1) * kGridAFloats;
                     const int n_wide = (np + 1) / 2;                         // 128-column tiles of the block
-                    for (int T = (p + 2) / 2 + wave - 1; T < n_wide; T += NU) {
-                        auto active64 = [&](int ct) { return ct < np && ct > p + 1; };
-                        const bool a0 = active64(2 * T), a1 = active64(2 * T + 1);
-                        if (!a0 && !a1) continue;
-                        const bool lane_ok = (lane & 16) ? a1 : a0;          // lanes n < 16: left 64 columns
+                    // Per tile: the accumulator loads and the first chunk of LD rows share one memory round trip, the other
+                    // three chunks stream through a two-chunk register ring under the MFMAs of their predecessors (round 2
+                    // waited for all 48 loads of a tile before its first MFMA and held 128 VGPRs of rows).  (Prefetching the
+                    // NEXT tile's accumulators as well needs 192 VGPRs + and spills: 4.4 instead of 2.7 ms.)
+                    auto active64 = [&](int ct) { return ct < np && ct > p + 1; };
+                    auto next_tile = [&](int T) {
+                        while (T < n_wide && !active64(2 * T) && !active64(2 * T + 1)) T += NU;
+                        return T;
+                    };
+                    auto tile_lane_ok = [&](int T) { return (lane & 16) ? active64(2 * T + 1) : active64(2 * T); };
+                    auto acc_issue = [&](f32x16 (&acc)[4], int T) {
                         const int c0 = T * 2 * kPanel;
-                        f32x4 R[kPanel / 2];
+                        if (c0 + 2 * kPanel <= b) wtile_load_acc_issue<true>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), lane);
+                        else wtile_load_acc_issue<false>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), lane);
+                    };
+                    auto acc_finish = [&](f32x16 (&acc)[4], int T) {
+                        const int c0 = T * 2 * kPanel;
+                        if (c0 + 2 * kPanel <= b) wtile_load_acc_finish<true>(acc, b, c0, tile_lane_ok(T), n_models, lane);
+                        else wtile_load_acc_finish<false>(acc, b, c0, tile_lane_ok(T), n_models, lane);
+                    };
+                    for (int T = next_tile((p + 2) / 2 + wave - 1); T < n_wide; T = next_tile(T + NU)) {
                         f32x16 acc[4];
-                        wtile_load_rows<U>(R, base, stride, pp, c0, lane);
-                        if (c0 + 2 * kPanel <= b) {
-                            wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-#ifdef VIPRS_GRID_PROFILE
-                            if (T < NU) { GPROF(8, wave == 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GPROF(9, wave == 1); }
-#endif
-                            wtile_compute(acc, R, a_lds, lane);
-#ifdef VIPRS_GRID_PROFILE
-                            if (T < NU) { asm volatile("" :: "v"(acc[0]), "v"(acc[3])); GPROF(10, wave == 1); }
-#endif
-                            wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-                        } else {
-                            wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-                            wtile_compute(acc, R, a_lds, lane);
-                            wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-                        }
+                        const int c0 = T * 2 * kPanel;
+                        acc_issue(acc, T);
+                        res_tile_apply<U, 2>(acc, base, stride, pp, c0, lane, true, true, a_lds, [&]() { acc_finish(acc, T); });
+                        if (c0 + 2 * kPanel <= b) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), n_models, lane);
+                        else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), n_models, lane);
                     }
                 }
                 GPROF(11, wave == 1);
@@ -966,10 +1067,6 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
 // registers and streams the rows below the tile's own panels once (LD lower triangle read once, q
 // read and written once), a = dq * eta_diff recomputed from the stored eta_diff exactly as the chain did.
 // ---------------------------------------------------------------------------------------------
-constexpr int kGridLowWaves = 4;
-constexpr int kGridLowEPitch = kGridModels + 1;
-constexpr int kGridLowWaveFloats = 2 * kPanel * kGridLowEPitch;
-
 template <typename U>
 __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kernel(EStepArgs<float> A, const EpiItem* items,
                                                                                    int n_items, int32_t* counter) {
@@ -990,60 +1087,7 @@ __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kern
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
         const EpiItem it = items[item];
-        const BlockDesc bd = A.blocks[it.blk];
-        const int b = bd.size, stride = bd.stride, T = it.row0;     // row0 = index of the 128-column tile
-        const int64_t s0 = bd.start;
-        const U* __restrict__ base = ldd + bd.ld_off;
-        const int np = (b + kPanel - 1) / kPanel;
-        const int c0 = T * 2 * kPanel;
-        const int p_first = 2 * T + 1;                              // first panel below the tile's left half
-        if (p_first >= np) continue;
-        const bool right = 2 * T + 1 < np;                          // the right 64 columns exist
-        const bool lane_ok = (n < 16) || right;
-        const bool full = c0 + 2 * kPanel <= b;
-
-        f32x16 acc[4];
-        if (full) wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-        else wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-
-        // a tile of panel pq into el[buf]: rows pq*64 .. +63 x models
-        auto stage_a = [&](int pq, int buf) {
-            float* e = el + buf * kPanel * kGridLowEPitch;
-            const int row = pq * kPanel + lane;
-            const bool ok = row < b;
-            const unsigned off = (unsigned)s0 + (unsigned)min(row, b - 1);
-            float v[kGridModels];
-#pragma unroll
-            for (int g = 0; g < kGridModels; ++g) v[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int g = 0; g < kGridModels; ++g) e[lane * kGridLowEPitch + g] = (ok && g < n_models) ? dq * v[g] : 0.0f;
-        };
-        f32x4 R0[kPanel / 2], R1[kPanel / 2];
-        wtile_load_rows<U>(R0, base, stride, p_first, c0, lane);
-        stage_a(p_first, 0);
-        int buf = 0;
-        for (int pq = p_first; pq < np; pq += 2) {
-            // -- panel pq from R0 / el[buf], panel pq + 1 in flight into R1
-            const int p1 = min(pq + 1, np - 1);
-            wtile_load_rows<U>(R1, base, stride, p1, c0, lane);
-            if (pq == p_first && n >= 16) {
-#pragma unroll
-                for (int i = 0; i < kPanel / 2; ++i) R0[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // right half: its own panel, no update
-            }
-            __builtin_amdgcn_wave_barrier();
-            wtile_compute(acc, R0, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
-            if (pq + 1 >= np) break;
-            stage_a(pq + 1, buf ^ 1);
-            // -- panel pq + 1 from R1, panel pq + 2 in flight into R0
-            const int p2 = min(pq + 2, np - 1);
-            wtile_load_rows<U>(R0, base, stride, p2, c0, lane);
-            __builtin_amdgcn_wave_barrier();
-            wtile_compute(acc, R1, el + (buf ^ 1) * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
-            if (pq + 2 < np) stage_a(pq + 2, buf);
-        }
-        if (full) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-        else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+        grid_lower_tile<U>(A, s_act, A.blocks[it.blk], it.row0, el, lane, n_models, dq);      // row0 = index of the 128-column tile
     }
 }
 
