@@ -24,9 +24,12 @@ else:
     if model == "grid": active = np.arange(width, dtype=np.int32)
 for _ in range(5): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
 ds.synchronize(); plan.timing_reset()
+import time
+t0 = time.perf_counter()
 for _ in range(30): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
-ds.synchronize(); t = np.array(plan.timing_history(which=1))
-print("%.4f %.4f %.4f" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90)))
+ds.synchronize(); wall = (time.perf_counter() - t0) / 30 * 1e3
+t = np.array(plan.timing_history(which=1))
+print("%.4f %.4f %.4f  wall ms/step %.4f" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90), wall))
 '''
 for rnd in range(3):
     for name, lib in (("A", sys.argv[1]), ("B", sys.argv[2])):

@@ -11,7 +11,7 @@ __global__ void sweep_prologue_kernel(int32_t* counters, int n_counters, unsigne
                                       unsigned long long* granules, int64_t n_granules) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_counters) counters[i] = 0;
-    if (i == 0) *skipped = 0ull;
+    if (i == 0) { skipped[0] = 0ull; skipped[1] = 0ull; }
     for (int64_t k = i; k < n_granules; k += (int64_t)gridDim.x * blockDim.x) granules[k] = 0ull;
 }
 
@@ -88,16 +88,18 @@ int launch_band_u(viprs_plan* P, const EStepArgs<float>& A, int model) {
 int run_spike_slab(viprs_state* S, double dq) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    {
+    // two HIP events per sweep when the dense kernels are all there is (the common case): [2] .. [3] then also
+    // stand for the whole sweep; every event record costs stream time
+    const bool dense_only = S->float_dtype == VIPRS_F32 && !P->dense_h.empty() && P->ragged_h.empty();
+    // (dense blocks only: the panel sweep is the only kernel of the call and keeps its own books -- generation-tagged
+    // hand-off granules, queue heads reset and the skip count published by its last workgroup: no prologue launch)
+    if (!dense_only) {
         const int64_t ng = P->n_granule_rows * kPanel;
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
         sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, kPlanCounters, P->d_skipped.p, P->d_granules.p, ng);
         HIP_TRY(hipGetLastError());
     }
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
-    // two HIP events per sweep when the dense kernels are all there is (the common case): [2] .. [3] then also
-    // stand for the whole sweep; every event record costs stream time
-    const bool dense_only = S->float_dtype == VIPRS_F32 && !P->dense_h.empty() && P->ragged_h.empty();
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = dense_only;
     if (!dense_only) HIP_TRY(hipEventRecord(ev[0], P->stream));
     int rc = VIPRS_OK;
@@ -164,7 +166,10 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
                       const int32_t* h_active) {
     viprs_plan* P = S->plan;
     HIP_TRY(hipSetDevice(P->device));
-    int rc = sweep_prologue(P, model == kGenGrid ? n_active : 1);
+    // (the panel sweep keeps its own books, run_spike_slab: no prologue launch when it is the only kernel of the call)
+    const bool panel_only = S->float_dtype == VIPRS_F32 && !P->dense_h.empty() && P->ragged_h.empty() &&
+                            ((model == kGenMixture && S->width <= kPanelWideMaxK) || (model == kGenGrid && !use_grid_mfma(P, S->width)));
+    int rc = panel_only ? VIPRS_OK : sweep_prologue(P, model == kGenGrid ? n_active : 1);
     if (rc != VIPRS_OK) return rc;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = true;      // [2] .. [3] bracket all kernels of the call
@@ -403,9 +408,9 @@ int viprs_plan_last_skipped(viprs_plan* P, int64_t* n) {
     if (!P || !n) return fail(VIPRS_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(P->device));
     HIP_TRY(hipStreamSynchronize(P->stream));
-    unsigned long long v = 0;
-    HIP_TRY(hipMemcpy(&v, P->d_skipped.p, sizeof(v), hipMemcpyDeviceToHost));
-    *n = (int64_t)v;
+    unsigned long long v[2] = {0, 0};       // [0]: kernels that count in place, [1]: moved there by the panel sweep's last workgroup
+    HIP_TRY(hipMemcpy(v, P->d_skipped.p, sizeof(v), hipMemcpyDeviceToHost));
+    *n = (int64_t)(v[0] + v[1]);
     return VIPRS_OK;
 }
 

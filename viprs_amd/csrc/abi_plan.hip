@@ -201,10 +201,14 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
 
     // ---- upload -------------------------------------------------------------------------------
     HIP_TRY(P->d_counters.alloc(kPlanCounters));
+    // (the panel sweep leaves its queue heads at 0; hipMemset is asynchronous for device memory and the plan's stream does
+    // not wait for the null stream: synchronise here)
+    HIP_TRY(hipMemset(P->d_counters.p, 0, kPlanCounters * sizeof(int32_t)));
+    HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(P->d_error.alloc(1));
     HIP_TRY(hipMemset(P->d_error.p, 0, sizeof(int32_t)));
-    HIP_TRY(P->d_skipped.alloc(1));
-    HIP_TRY(hipMemset(P->d_skipped.p, 0, sizeof(unsigned long long)));
+    HIP_TRY(P->d_skipped.alloc(2));
+    HIP_TRY(hipMemset(P->d_skipped.p, 0, 2 * sizeof(unsigned long long)));
     if (m > 0) {
         HIP_TRY(P->d_lb.alloc((size_t)m));
         HIP_TRY(P->d_ip.alloc((size_t)m + 1));
@@ -251,7 +255,11 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
             HIP_TRY(hipDeviceSynchronize());
         }
     }
-    if (P->n_granule_rows > 0) HIP_TRY(P->d_granules.alloc((size_t)P->n_granule_rows * kPanel));
+    if (P->n_granule_rows > 0) {
+        HIP_TRY(P->d_granules.alloc((size_t)P->n_granule_rows * kPanel));
+        HIP_TRY(hipMemset(P->d_granules.p, 0, sizeof(unsigned long long) * P->d_granules.n));    // tag 0 = no launch
+        HIP_TRY(hipDeviceSynchronize());
+    }
     if (!P->dense_h.empty()) {
         HIP_TRY(P->d_dense.alloc(P->dense_h.size()));
         HIP_TRY(hipMemcpy(P->d_dense.p, P->dense_h.data(), sizeof(BlockDesc) * P->dense_h.size(), hipMemcpyHostToDevice));

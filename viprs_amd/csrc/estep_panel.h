@@ -131,6 +131,12 @@ __device__ __forceinline__ float sel_mask(float a, float b, unsigned long long m
     return r;
 }
 
+// staged outputs of a team block: another member -- possibly on another XCD, behind another L2 -- copies them into place
+// when the block is done, so they are written past the caches (agent scope)
+__device__ __forceinline__ void stage_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -339,7 +345,7 @@ struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
             } else {
                 A.eta_diff[j] = 0.0f;                                     // :412
             }
-            if (TEAM) A.eta_out[j] = skip ? in.eta_old : in.eta_old + d;
+            if (TEAM) stage_store(A.eta_out + j, skip ? in.eta_old : in.eta_old + d);
         }
         skipped = live && skip;
         if (d_out) *d_out = (live && !skip) ? d : 0.0f;
@@ -394,7 +400,7 @@ struct GridColumnModel {
             A.var_mu[j] = mu;
             A.var_gamma[j] = gamma;
             A.eta_diff[j] = d;
-            if (TEAM) A.eta_out[j] = in.eta_old + d; else A.eta[j] = in.eta_old + d;   // :633
+            if (TEAM) stage_store(A.eta_out + j, in.eta_old + d); else A.eta[j] = in.eta_old + d;   // :633
         }
         skipped = false;
         return live ? A.dq * d : 0.0f;
@@ -473,7 +479,7 @@ struct MixtureModel {
                 }
             }
             A.eta_diff[j] = d;
-            if (TEAM) A.eta_out[j] = in.eta_old + d; else A.eta[j] = in.eta_old + d;   // :536
+            if (TEAM) stage_store(A.eta_out + j, in.eta_old + d); else A.eta[j] = in.eta_old + d;   // :536
         }
         skipped = false;
         return live ? A.dq * d : 0.0f;
@@ -685,7 +691,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         for (unsigned spins = 0;; ++spins) {
                             g = __hip_atomic_load(gran + (int64_t)p * kPanel + lane, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
-                            if (__all((unsigned)(g >> 32) == (unsigned)(p + 1))) break;
+                            if (__all((unsigned)(g >> 32) == A.tag_base + (unsigned)(p + 1))) break;
                             if (spins > (1u << 22)) {          // ~seconds: give up loudly, never hang
                                 if (lane == 0) atomicExch(A.error, 1);
                                 break;
@@ -805,7 +811,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[k];
                         if (member == 0 && live) {
                             A.eta_diff[j] = dvec;
-                            if (TEAM) A.eta_out[j] = in.eta_old + dvec; else A.eta[j] = in.eta_old + dvec;   // :536
+                            if (TEAM) stage_store(A.eta_out + j, in.eta_old + dvec); else A.eta[j] = in.eta_old + dvec;   // :536
                         }
                         a_prev = avec;
                         if (!SYM) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
@@ -918,7 +924,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             }
                             if (live) {
                                 A.eta_diff[j] = dvec;
-                                if (TEAM) A.eta_out[j] = in.eta_old + dvec; else A.eta[j] = in.eta_old + dvec;   // :536
+                                if (TEAM) stage_store(A.eta_out + j, in.eta_old + dvec); else A.eta[j] = in.eta_old + dvec;   // :536
                             }
                         }
                         a_prev = avec;
@@ -1060,7 +1066,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             __builtin_amdgcn_wave_barrier();
                             const float v = lq[(p + 1) * kPanel + lane];
                             const unsigned long long g =
-                                ((unsigned long long)(unsigned)(p + 2) << 32) | (unsigned long long)__float_as_uint(v);
+                                ((unsigned long long)(A.tag_base + (unsigned)(p + 2)) << 32) | (unsigned long long)__float_as_uint(v);
                             __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -1134,10 +1140,31 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         }
 #endif
         {   // teams: every member owns the final q of its own strips
-            float* __restrict__ qdst = TEAM ? A.q_out : A.q;
             for (int i = tid; i < b; i += NW * 64)
-                if (!TEAM || ((i / kSW) % TS) == member)
-                    qdst[s0 + i] = SYM ? lq[i] : lq[i] + A.dq * ls[i];      // upper form: q[j] += dq * dot (e_step.hpp:335)
+                if (!TEAM || ((i / kSW) % TS) == member) {
+                    const float v = SYM ? lq[i] : lq[i] + A.dq * ls[i];      // upper form: q[j] += dq * dot (e_step.hpp:335)
+                    if (TEAM) stage_store(A.q_out + s0 + i, v); else A.q[s0 + i] = v;
+                }
+        }
+        if (TEAM) {
+            // eta / q are in-out and other members may still be reading the old values, so team blocks write to staging
+            // buffers; the member that finishes the block LAST copies them into place (every member has then read what it
+            // needed).  The staged values are written and read past the caches (agent-scope atomics: the members of a team
+            // sit on different XCDs, each with its own L2), every wave waits for its own stores to complete before the
+            // barrier, and the arrival is an agent-scope atomic -- no fence (__threadfence() here costs 8 % of the cfg3
+            // sweep: its release writes back the whole L2).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) s_blk = (atomicAdd(A.arrive + item, 1) == TS - 1) ? 1 : 0;
+            __syncthreads();
+            const bool last = s_blk != 0;
+            if (last) {
+                for (int i = tid; i < b; i += NW * 64) {
+                    A.eta[s0 + i] = __hip_atomic_load(A.eta_out + s0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    A.q[s0 + i] = __hip_atomic_load(A.q_out + s0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (tid == 0) atomicExch(A.arrive + item, 0);
+            }
         }
         __syncthreads();
 #ifdef VIPRS_SWEEP_TRACE
@@ -1168,6 +1195,10 @@ struct SweepArgs {
     EStepArgs<float> cls[3];     // per size class: block list, team geometry, queue counters
     int32_t qcap[3];             // LDS floats reserved for q per class (largest block of the class, padded)
     int32_t n_wg[2];             // team workgroups of class 0 / class 1 (0 = class empty)
+    // launch bookkeeping, done by the workgroup that finishes LAST instead of by a prologue launch: the small-block queue
+    // heads go back to 0 for the next sweep and the skip counter moves to `skipped_last` (what the host reads)
+    int32_t* done;               // workgroups that have finished
+    unsigned long long* skipped_last;
 };
 
 template <typename U, typename MODEL, bool SYM, int NW, int CPL>
@@ -1180,15 +1211,14 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(S
         __syncthreads();
     }
     if (S.cls[2].n_blocks > 0) panel_role<U, MODEL, SYM, NW, false, CPL>(S.cls[2], S.qcap[2], smem, wg);
-}
-
-// Copies the team kernels' eta / q outputs into place (runs behind the team kernel on its stream).
-static __global__ void commit_team_kernel(EStepArgs<float> A0) {
-    const EStepArgs<float> A = select_model(A0, blockIdx.y);
-    const BlockDesc bd = A.blocks[blockIdx.x];
-    for (int i = threadIdx.x; i < bd.size; i += blockDim.x) {
-        A.eta[bd.start + i] = A.eta_out[bd.start + i];
-        A.q[bd.start + i] = A.q_out[bd.start + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (this workgroup's skip count and queue claims are atomics at L2, issued before this one)
+        if (atomicAdd(S.done, 1) == (int)gridDim.x - 1) {
+            S.cls[2].counter[0] = 0; S.cls[2].counter[1] = 0; S.cls[2].counter[2] = 0;
+            atomicExch(S.skipped_last, atomicExch(S.cls[2].skipped, 0ull));      // this sweep's count; the running one back to 0
+            atomicExch(S.done, 0);
+        }
     }
 }
 

@@ -53,7 +53,11 @@ struct EStepArgs {
     // bottom_mod - 1 take from the small end: at any time the chip then works on a MIX of bandwidth-bound (large)
     // and chain-bound (small) blocks instead of all workgroups moving from large to small blocks in lockstep.
     int32_t bottom_mod;
-    unsigned long long* granules; // team kernels: {tag, value} hand-off granules (zeroed before every launch)
+    unsigned long long* granules; // team kernels: {tag, value} hand-off granules; tag = tag_base + panel + 1
+    uint32_t tag_base;           //   (tag_base = launch generation << 12: a granule of an earlier launch never matches,
+                                 //    so the buffer needs no zeroing between launches)
+    int32_t* arrive;             // team kernels: one arrival counter per (block, model) item -- the member that arrives
+                                 //   LAST copies the item's staged eta / q into place and resets the counter
     int32_t* error;              // set to non-zero when a bounded spin gives up
     int32_t n_teams;             // team kernels: number of teams in the launch
     int32_t team_size;           // team kernels: workgroups per team
