@@ -525,7 +525,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     // form keeps the chain's own register prefetch: its updater waves carry the second pass and are the busier side --
     // staging one more tile per phase, and waiting for the chain's go-ahead to do so, costs them more than the chain wins
     // (cfg3: 0.74 -> 0.77 ms with the tile in LDS, 0.80 -> 0.72-0.77 ms in the symmetric form)
-    constexpr bool kTileInLds = kDiagInLds && SYM;
+    // The K <= 8 mixture chain (components of one SNP across the lanes) follows the same scheme in the symmetric form:
+    // diagonal tiles staged in LDS, the off-diagonal tile of the next phase in the single gated buffer -- its chain wave
+    // issues no vector-memory instruction inside a panel either (it used to stream the diagonal rows from global memory,
+    // 16 rows ahead).
+    constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value && SYM;
+    constexpr bool kStageDiag = kDiagInLds || kMixLds;          // what the updaters stage into lT: diagonal tiles
+    constexpr bool kTileInLds = (kDiagInLds && SYM) || kMixLds;
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
@@ -613,7 +619,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         for (int i = tid; i < bpad + kStrip; i += NW * 64) lq[i] = (i < b) ? A.q[s0 + i] : 0.0f;
         if (!SYM) for (int i = tid; i < bpad; i += NW * 64) ls[i] = 0.0f;
         if (tid == 0) s_tdone = 0;
-        if (kDiagInLds) {
+        if (kStageDiag) {
             // diagonal tile of panel 0 (rows past the end of a short block are clamped: finite values that
             // only ever meet a = 0)
             for (int i = tid; i < kPanel * kPanel / 4; i += NW * 64) {
@@ -633,7 +639,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         if (wave == 0) {
             const bool live0 = lane < b;
             nxt_in = MODEL::load(A, s0 + (live0 ? lane : 0), live0);
-            if (!kDiagInLds) {
+            if (!kStageDiag) {
 #pragma unroll
                 for (int k = 0; k < kChainPrefetch; ++k)
                     dnext[k] = static_cast<float>(base[(int64_t)min(k, b - 1) * stride + lane]);
@@ -673,8 +679,8 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     // path (a = 0 leaves every q untouched).
                     const int last = nrows - 1;
                     const U* __restrict__ dptr = base + (int64_t)r0 * stride + r0 + lane;
-                    float drow[kDiagInLds ? 1 : kPanel];
-                    if (!kDiagInLds) {
+                    float drow[kStageDiag ? 1 : kPanel];
+                    if (!kStageDiag) {
 #pragma unroll
                         for (int k = 0; k < kChainPrefetch; ++k) drow[k] = dnext[k];
                     }
@@ -846,20 +852,26 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         // earlier into the same register win[k]; the last group loads the first rows of the NEXT
                         // panel's diagonal tile, which are handed over through dnext.
                         static_assert(kChainPrefetch == 16 && kPanel == 64, "window indexing");
-                        float win[kChainPrefetch];
+                        float win[kMixLds ? 1 : kChainPrefetch];
+                        if (!kMixLds) {
 #pragma unroll
-                        for (int k = 0; k < kChainPrefetch; ++k) win[k] = drow[k];
+                            for (int k = 0; k < kChainPrefetch; ++k) win[k] = drow[kMixLds ? 0 : k];
+                        }
+                        const float* __restrict__ Dt = lT + (p & 1) * kPanel * kPanel + lane;     // kMixLds: diagonal tile of the panel
 #pragma unroll 1
                         for (int g = 0; g < kPanel / kChainPrefetch; ++g) {
 #pragma unroll
                         for (int k = 0; k < kChainPrefetch; ++k) {
                             const int jj = kChainPrefetch * g + k;                             // wave-uniform
-                            const float drow_jj = win[k];
-                            {
+                            float drow_jj;
+                            if (kMixLds) {
+                                drow_jj = Dt[jj * kPanel];
+                            } else {
+                                drow_jj = win[kMixLds ? 0 : k];
                                 const U* __restrict__ src = (g < kPanel / kChainPrefetch - 1)
                                     ? dptr + (int64_t)min(jj + kChainPrefetch, last) * stride
                                     : nptr + (int64_t)min(k, b - 1 - rn0) * stride;
-                                win[k] = static_cast<float>(*src);
+                                win[kMixLds ? 0 : k] = static_cast<float>(*src);
                             }
                             const int jn = (jj + 1 < kPanel) ? jj + 1 : jj;
                             const float nmm = Lmm[jn * K + kc], nsv = Lsv[jn * K + kc], nul = Lul[jn * K + kc];
@@ -909,8 +921,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             cmm = nmm; csv = nsv; cul = nul;
                         }
                         }
+                        if (!kMixLds) {
 #pragma unroll
-                        for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[k];
+                            for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[kMixLds ? 0 : k];
+                        }
                         };
                         if (K <= 4) run_panel(std::integral_constant<int, 4>{});
                         else run_panel(std::integral_constant<int, kPanelMaxK>{});
@@ -995,7 +1009,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                 if (p + 1 < np) {
                     float* __restrict__ T = lT + ((p + 1) & 1) * kPanel * kPanel;
                     const int trow = lane >> 4, tcol = (lane & 15) * 4;
-                    const int row_base = (kDiagInLds ? p + 1 : p) * kPanel;
+                    const int row_base = (kStageDiag ? p + 1 : p) * kPanel;
                     constexpr int kGroups = (kPanel / 4 + NW - 2) / (NW - 1);
                     float4 v[kGroups];
 #pragma unroll
