@@ -307,6 +307,14 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
             P->n_low_items = (int64_t)low.size();
             P->n_low_items_big = 0;
             for (const EpiItem& it : low) P->n_low_items_big += P->dense_h[(size_t)it.blk].size > kResMax ? 1 : 0;
+            std::vector<EpiItem> split;
+            for (int64_t i = 0; i < P->n_low_items_big; ++i)
+                for (int jh = 0; jh < 2; ++jh) split.push_back({low[(size_t)i].blk, 2 * low[(size_t)i].row0 + jh});
+            P->n_low_split = (int64_t)split.size();
+            if (!split.empty()) {
+                HIP_TRY(P->d_low_split.alloc(split.size()));
+                HIP_TRY(hipMemcpy(P->d_low_split.p, split.data(), sizeof(EpiItem) * split.size(), hipMemcpyHostToDevice));
+            }
             if (!low.empty()) {
                 HIP_TRY(P->d_low_items.alloc(low.size()));
                 HIP_TRY(hipMemcpy(P->d_low_items.p, low.data(), sizeof(EpiItem) * low.size(), hipMemcpyHostToDevice));

@@ -343,6 +343,33 @@ __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, floa
     }
 }
 
+// the same for two of the four column groups of a 128-column tile (columns c0 + 4n + J0, + J0 + 1): 64 MFMAs
+template <int J0>
+__device__ __forceinline__ void wtile_compute_half(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
+                                                   const float* __restrict__ a_lds, int lane, int a_pitch) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < kPanel / 2; ++i) {
+        const float aop = a_lds[(2 * i + half) * a_pitch + l31];
+        acc[J0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][J0], acc[J0], 0, 0, 0);
+        acc[J0 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][J0 + 1], acc[J0 + 1], 0, 0, 0);
+    }
+}
+template <int J0>
+__device__ __forceinline__ void wtile_store_acc_half(const f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act,
+                                                     int64_t s0, int b, int c0, bool lane_ok, int n_models, int lane) {
+    const int half = lane >> 5, c = c0 + 4 * (lane & 31) + J0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (lane_ok && g < n_models) {
+            const unsigned off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0 + c;
+            if (c < b) A.q[off] = acc[J0][r];
+            if (c + 1 < b) A.q[off + 1] = acc[J0 + 1][r];
+        }
+    }
+}
+
 constexpr int kGridWaves = 8;                      // 1 chain wave + 7 updater waves
 constexpr int kGridNU = kGridWaves - 1;
 constexpr int kGridPerWave = (kGridModels + kGridNU - 1) / kGridNU;     // model rows a wave stages / flushes
@@ -356,7 +383,11 @@ constexpr int kGridLowWaveFloats = 2 * kPanel * kGridLowEPitch;
 
 // one 128-column tile `T` of block `bd`: every row below the tile's own panels, in row order, accumulators in registers
 // (el: this wave's [2][64][33] staging of dq * eta_diff)
-template <typename U>
+// JH >= 0: only the column groups 2 JH, 2 JH + 1 of the tile (64 of its 128 columns, interleaved in pairs): half the
+// MFMAs per row panel.  The lower pass is bound by its longest items (a tile at the left edge of the largest block has
+// every other panel of the block below it), and only the few blocks beyond the resident form are left to it: twice as
+// many items of half the length (0.32 -> 0.2 ms on cfg3).
+template <typename U, int JH>
 __device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const int* s_act, const BlockDesc& bd, int T, float* el,
                                                 int lane, int n_models, float dq) {
     const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
@@ -376,43 +407,56 @@ __device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const
     if (full) wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
     else wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
 
-    // a tile of panel pq into el[buf]: rows pq*64 .. +63 x models
-    auto stage_a = [&](int pq, int buf) {
-        float* e = el + buf * kPanel * kGridLowEPitch;
+    // dq * eta_diff of panel pq (rows pq*64 .. +63 x models): loaded into registers (`issue`) a whole panel ahead of
+    // its use, written to el[buf] (`commit`) once the MFMAs that read the other buffer are out -- the 32 loads per lane
+    // used to sit, exposed, between two panels of every item
+    float av[kGridModels];
+    bool av_ok = false;
+    auto stage_issue = [&](int pq) {
         const int row = pq * kPanel + lane;
-        const bool ok = row < b;
+        av_ok = row < b;
         const unsigned off = (unsigned)s0 + (unsigned)min(row, b - 1);
-        float v[kGridModels];
 #pragma unroll
-        for (int g = 0; g < kGridModels; ++g) v[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
+        for (int g = 0; g < kGridModels; ++g) av[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
         asm volatile("" ::: "memory");
+    };
+    auto stage_commit = [&](int buf) {
+        float* e = el + buf * kPanel * kGridLowEPitch;
 #pragma unroll
-        for (int g = 0; g < kGridModels; ++g) e[lane * kGridLowEPitch + g] = (ok && g < n_models) ? dq * v[g] : 0.0f;
+        for (int g = 0; g < kGridModels; ++g) e[lane * kGridLowEPitch + g] = (av_ok && g < n_models) ? dq * av[g] : 0.0f;
+    };
+    auto compute = [&](const f32x4 (&R)[kPanel / 2], int buf) {
+        if (JH < 0) wtile_compute(acc, R, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
+        else wtile_compute_half<JH < 0 ? 0 : 2 * JH>(acc, R, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
     };
     f32x4 R0[kPanel / 2], R1[kPanel / 2];
     wtile_load_rows<U>(R0, base, stride, p_first, c0, lane);
-    stage_a(p_first, 0);
+    stage_issue(p_first);
+    stage_commit(0);
     int buf = 0;
     for (int pq = p_first; pq < np; pq += 2) {
-        // -- panel pq from R0 / el[buf], panel pq + 1 in flight into R1
+        // -- panel pq from R0 / el[buf]; panel pq + 1 (rows and eta_diff) in flight
         const int p1 = min(pq + 1, np - 1);
         wtile_load_rows<U>(R1, base, stride, p1, c0, lane);
+        stage_issue(p1);
         if (pq == p_first && n >= 16) {
 #pragma unroll
             for (int i = 0; i < kPanel / 2; ++i) R0[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // right half: its own panel, no update
         }
         __builtin_amdgcn_wave_barrier();
-        wtile_compute(acc, R0, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
+        compute(R0, buf);
         if (pq + 1 >= np) break;
-        stage_a(pq + 1, buf ^ 1);
-        // -- panel pq + 1 from R1, panel pq + 2 in flight into R0
+        stage_commit(buf ^ 1);
+        // -- panel pq + 1 from R1 / el[buf ^ 1]; panel pq + 2 in flight
         const int p2 = min(pq + 2, np - 1);
         wtile_load_rows<U>(R0, base, stride, p2, c0, lane);
+        stage_issue(p2);
         __builtin_amdgcn_wave_barrier();
-        wtile_compute(acc, R1, el + (buf ^ 1) * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
-        if (pq + 2 < np) stage_a(pq + 2, buf);
+        compute(R1, buf ^ 1);
+        if (pq + 2 < np) stage_commit(buf);
     }
-    if (full) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+    if (JH >= 0) wtile_store_acc_half<JH < 0 ? 0 : 2 * JH>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
+    else if (full) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
     else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
 }
 
@@ -1069,7 +1113,7 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
 // ---------------------------------------------------------------------------------------------
 template <typename U>
 __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kernel(EStepArgs<float> A, const EpiItem* items,
-                                                                                   int n_items, int32_t* counter) {
+                                                                                   int n_items, int32_t* counter, int split) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_act[kGridModels];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1087,7 +1131,10 @@ __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kern
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
         const EpiItem it = items[item];
-        grid_lower_tile<U>(A, s_act, A.blocks[it.blk], it.row0, el, lane, n_models, dq);      // row0 = index of the 128-column tile
+        // row0 = index of the 128-column tile; split launches: 2 x tile + column-group pair
+        if (!split) grid_lower_tile<U, -1>(A, s_act, A.blocks[it.blk], it.row0, el, lane, n_models, dq);
+        else if (it.row0 & 1) grid_lower_tile<U, 1>(A, s_act, A.blocks[it.blk], it.row0 >> 1, el, lane, n_models, dq);
+        else grid_lower_tile<U, 0>(A, s_act, A.blocks[it.blk], it.row0 >> 1, el, lane, n_models, dq);
     }
 }
 

@@ -100,6 +100,8 @@ struct viprs_plan {
     viprs::DevBuf<viprs::EpiItem> d_low_items;            // symmetric form: (block, 128-column tile) items of the batched grid lower pass
     int64_t n_low_items = 0;
     int64_t n_low_items_big = 0;                          // ... of which belong to blocks beyond the resident form (they come first)
+    viprs::DevBuf<viprs::EpiItem> d_low_split;            // those again, as two half-tile items each: (block, 2 x tile + column-group pair)
+    int64_t n_low_split = 0;
     viprs::DevBuf<int32_t> d_lb;
     viprs::DevBuf<int64_t> d_ip;
     viprs::DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
