@@ -25,6 +25,10 @@ def test_host_vector_collectives(comm):
     comm.barrier()
     big = np.arange(100_000, dtype=np.float64)
     np.testing.assert_array_equal(comm.allreduce_sum(big), big)
+    # bulk exchange (the posterior of every rank's SNPs at the end of a fit): (world, n) rows in rank order
+    g = comm.allgather(big)
+    assert g.shape == (1, big.size)
+    np.testing.assert_array_equal(g[0], big)
 
 
 def test_device_sums_through_the_communicator_equal_local_sums(comm):

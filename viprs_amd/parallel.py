@@ -23,7 +23,7 @@ import numpy as np
 # A rank's sweep time is bounded by its HBM stream (sum of the LD bytes of its blocks), by the serial
 # Gauss-Seidel chains of its blocks spread over the chain slots of the chip, and by the longest single chain.
 HBM_STREAM_BYTES_PER_S = 5.5e12      # what a sweep streams at on one MI355X
-CHAIN_STEP_S = 140e-9                # one serial SNP update of the panel kernels' chain wave, per-phase work included
+CHAIN_STEP_S = 135e-9                # one serial SNP update of the panel kernels' chain wave, per-phase work included
 CHAIN_SLOTS = 512                    # chains resident on one GPU (256 CUs x workgroups per CU)
 
 
