@@ -343,6 +343,110 @@ __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, floa
     }
 }
 
+// ---- the chain wave's work for one panel, row application on the MATRIX CORE (round 3; -DVIPRS_GRID_MFMA_CHAIN) -------
+// BUILT, MEASURED, NOT THE DEFAULT: bit-identical to the VALU chain above on every grid parity test, 81 instead of 97
+// instructions per SNP -- and 9 % SLOWER (1 700 equal blocks of 650 SNPs, purely chain-bound: 1.86 against 1.71 ms; cfg3
+// 2.50 against 2.34 ms), with the carry moved to the wave that shares the chain's SIMD or not.  The two MFMAs per SNP
+// occupy the issuing wave for their 2 x 64 clocks: a wave's own VALU instructions do not run under its own MFMA, so the
+// 16 v_pk_fma_f32 + 8 ds_read_b128 they replace were the cheaper way to spend those clocks.  (A v_mfma_f32_32x32x1_2b
+// variant -- one MFMA per SNP, own column on the VALU -- would save half of that and land where the VALU chain is.)
+// The VALU chain above spends most of its ~1 000 clocks per SNP on things that are not the serial dependency: the 32
+// columns of the diagonal-tile row per lane come in as 8 ds_read_b128 (~27 clk of issue each) and go out as 16
+// v_pk_fma_f32.  Here the panel's q lives in two 32x32 accumulator tiles, C[column i][model n] (lane = (half, model),
+// register r <-> column (r & 3) + 8 (r >> 2) + 4 half), and the row of SNP jj is applied to all 64 columns of all 32
+// models by TWO v_mfma_f32_32x32x2_f32:
+//     k = 0:  A = D[jj][column],          B = a[model]            q = fma(D, a, q)          e_step.hpp:623
+//     k = 1:  A = -1 at column jj, else 0, B = d[model] (SYM)      q[jj] = q[jj] - d         e_step.hpp:629
+// (fma(-1, d, x) rounds as x - d does; fma(0, d, x) == x: q is never -0).  The A operand is ONE ds_read_b32 per lane (the
+// row, lane = column) + one v_permlane32_swap.  The MFMA's ~64 clocks of latency stay off the critical path: the q the
+// NEXT SNP needs (column jj+1) is read from the accumulators before this step's MFMAs are issued -- the previous step's
+// have long completed -- and gets row jj by one VALU fma with D[jj][jj+1] from a v_readlane; the matrix core applies the
+// same fma to the accumulator's copy.  Fully unrolled (the register <-> column map of the accumulators is fixed).
+template <bool SYM>
+__device__ __forceinline__ void grid_chain_panel_mfma(const EStepArgs<float>& A, float* io, float* la, float* dg, float* qx, int p,
+                                                      int b, int64_t s0, int lane, int n_models, float dq, const ExpTab& tab) {
+    const int cg = lane & 31, ch = lane >> 5;
+    const bool has_model = cg < n_models;
+    const int r0 = p * kPanel;
+    const int nrows = min(kPanel, b - r0);
+    float* iob = io + (p & 1) * kGridIoFloats + cg * kGridIoPitch;
+    float* lap = la + (p & 1) * kGridAFloats + cg;
+    const float* drow = dg + (p & 1) * kGridDiagFloats + lane;             // D[jj][lane]
+    float* qm = qx + (p & 1) * kGridQxFloats + cg * kGridQxPitch;          // this model's 64 columns
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(qm + 8 * g + 4 * ch);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(qm + 32 + 8 * g + 4 * ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0[4 * g + e] = has_model ? v[e] : 0.0f;
+            acc1[4 * g + e] = has_model ? w[e] : 0.0f;
+        }
+    }
+    const float betav = A.std_beta[s0 + min(r0 + lane, b - 1)];
+    float mm = iob[0 * kGridIoArr], ulog = iob[1 * kGridIoArr], hvt = iob[2 * kGridIoArr], eta_old = iob[3 * kGridIoArr];
+    float rowv = drow[0];
+    float qcur;
+    {
+        const unsigned x = __float_as_uint(acc0[0]);                      // column 0: half 0, register 0
+        auto sx = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        qcur = __uint_as_float(sx[0]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < kPanel; ++jj) {
+        const bool live = jj < nrows;
+        const int jn = (jj + 1 < kPanel) ? jj + 1 : jj;
+        // next SNP's inputs and diagonal-tile row: in flight while this one is evaluated
+        const float mm_n = iob[0 * kGridIoArr + jn], ulog_n = iob[1 * kGridIoArr + jn], hvt_n = iob[2 * kGridIoArr + jn],
+                    eta_n = iob[3 * kGridIoArr + jn];
+        const float rowv_n = drow[jn * kPanel];
+        const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
+        const float mu = mm * (beta - qcur);                         // e_step.hpp:613
+        const float u = ulog + hvt * mu * mu;                        // :616
+        const float gamma = sigmoid_exact<kLookupPerLane>(u, tab);   // :617
+        const float d = gamma * mu - eta_old;                        // :620
+        const float a = (live && has_model) ? dq * d : 0.0f;
+        const float dsub = (SYM && live && has_model) ? d : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);      // (the accumulator reads below wait for the previous step's MFMAs: keep them here)
+        // A operands: lanes 0..31 the row (k = 0), lanes 32..63 the diagonal selector (k = 1)
+        auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(rowv), __float_as_uint(rowv), false, false);
+        const float row_lo = __uint_as_float(sr[0]), row_hi = __uint_as_float(sr[1]);      // D[jj][lane & 31], D[jj][32 + (lane & 31)]
+        const float A0 = ch ? ((SYM && cg == jj) ? -1.0f : 0.0f) : row_lo;
+        const float A1 = ch ? ((SYM && cg + 32 == jj) ? -1.0f : 0.0f) : row_hi;
+        const float B = ch ? dsub : a;
+        // the next SNP's q: its column out of the accumulators (rows < jj applied) + row jj on the VALU
+        float qnext = 0.0f;
+        if (jj + 1 < kPanel) {
+            constexpr int kDummy = 0; (void)kDummy;
+            const int c1 = jj + 1, i1 = c1 & 31, r1 = (i1 & 3) + 4 * (i1 >> 3), h1 = (i1 >> 2) & 1;
+            const unsigned x = __float_as_uint((c1 >> 5) ? acc1[r1] : acc0[r1]);
+            auto sx = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+            const float xq = __uint_as_float(h1 ? sx[1] : sx[0]);
+            const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rowv), c1));   // D[jj][jj+1]
+            qnext = __builtin_fmaf(dn, a, xq);                       // :623 for column jj+1
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B, acc0, 0, 0, 0);      // :623 (+ :629) for all 64 columns x 32 models
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B, acc1, 0, 0, 0);
+        if (has_model && live && ch == 0) {
+            iob[0 * kGridIoArr + jj] = mu;
+            iob[1 * kGridIoArr + jj] = gamma;
+            iob[2 * kGridIoArr + jj] = d;
+            iob[3 * kGridIoArr + jj] = eta_old + d;                   // :633
+        }
+        if (ch == 0) lap[jj * kGridModels] = a;
+        mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n; rowv = rowv_n; qcur = qnext;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (has_model) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<f32x4*>(qm + 8 * g + 4 * ch) = f32x4{acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(qm + 32 + 8 * g + 4 * ch) = f32x4{acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+        }
+    }
+}
+
 // the same for two of the four column groups of a 128-column tile (columns c0 + 4n + J0, + J0 + 1): 64 MFMAs
 template <int J0>
 __device__ __forceinline__ void wtile_compute_half(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
@@ -468,10 +572,10 @@ __device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const
 // in the same row order, so estep_grid_lower_pass_kernel has nothing left to do for these blocks.
 //
 //   wave 0      chain, as in the streaming form (grid_chain_panel).
-//   wave 1      carry: takes the 64 columns of panel p+1 out of their owner's registers one phase ahead (through LDS,
+//   wave 4      carry: takes the 64 columns of panel p+1 out of their owner's registers one phase ahead (through LDS,
 //               `cq`), applies a_{p-1} during phase p and a_p between the chain's two panels, hands them to the chain
 //               (qx) -- the accumulators stay in ITS registers across the barriers (own loop over the phases).
-//   waves 2..7  owners: wave w holds the 128-column tiles T = w - 2 and T = w + 4 (32 models x 128 columns = 64
+//   the others  owners (waves 1, 2, 3, 5, 6, 7 = owner 0 .. 5): owner o holds the 128-column tiles T = o and T = o + 6 (32 models x 128 columns = 64
 //               accumulator registers each).  Per phase p they apply the rows of panel p-1 (a_{p-1}) to their tiles --
 //               LD rows in 4 chunks of 8 16-byte loads -- except to the panels that
 //               are "away": p-1 (its own rows are the chain's diagonal tile), p and p+1 (with the carry).  The B operand
@@ -479,6 +583,11 @@ __device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const
 //               both addends are).  A panel comes back from the chain one phase after it was swept (qx).
 // Same arithmetic per (model, column) as the streaming form and as e_step_grid: the rows arrive in ascending order.
 // =====================================================================================================================
+// The carry is wave 4: the hardware puts waves w and w + 4 of a workgroup on the same SIMD, i.e. wave 4 shares the chain
+// wave's matrix pipe -- and the chain now issues two MFMAs per SNP.  An owner wave there (128 back-to-back MFMAs per tile)
+// makes each of them queue for up to two MFMA times (64 clocks each); the carry's few MFMAs mostly fall between the
+// chain's panels.
+constexpr int kGridCarryWave = 4;
 constexpr int kGridResOwners = 6;
 constexpr int kGridResSlots = 2;
 constexpr int kGridResMaxCols = kGridResOwners * kGridResSlots * 2 * kPanel;      // 1536
@@ -614,15 +723,20 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
         __syncthreads();                                            // B0: inputs of panel 0 staged
         for (int p = 0; p <= np; ++p) {
             __syncthreads();                                        // mid: the carry has put panel p into qx
-            if (p < np)
+            if (p < np) {
+#ifdef VIPRS_GRID_MFMA_CHAIN
+                grid_chain_panel_mfma<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
+#else
                 grid_chain_panel<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
 #ifdef VIPRS_GRID_PROFILE
                                       , 1, nullptr
 #endif
                                       );
+#endif
+            }
             __syncthreads();                                        // end
         }
-    } else if (wave == 1) {
+    } else if (wave == kGridCarryWave) {
         // ================================================= carry =========================================================
         stage_inputs(0, true);
         __syncthreads();                                            // B0
@@ -680,7 +794,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
         }
     } else {
         // ================================================= owners ========================================================
-        const int ow = wave - 2;
+        const int ow = wave < kGridCarryWave ? wave - 1 : wave - 2;     // waves 1, 2, 3, 5, 6, 7
         f32x16 accA[4], accB[4];                                    // tiles T = ow and T = ow + kGridResOwners
         const int cA = ow * 2 * kPanel, cB = (ow + kGridResOwners) * 2 * kPanel;
         const bool hasA = cA < b, hasB = cB < b;
@@ -913,12 +1027,17 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
             GPROF(1, wave == 0);
             if (wave == 0) {
                 // ---- (2) chain: 64 serial SNP updates for all models
-                if (p < np)
+                if (p < np) {
+#ifdef VIPRS_GRID_MFMA_CHAIN
+                    grid_chain_panel_mfma<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
+#else
                     grid_chain_panel<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
 #ifdef VIPRS_GRID_PROFILE
                                           , blk, &s_prof[0][0]
 #endif
                                           );
+#endif
+                }
             } else {
                 // ---- (3) waves 1..7, concurrently with the chain: outputs of panel p-1 out of io[(p-1)&1],
                 //      inputs of panel p+1 into the same buffer (each wave flushes and refills its own
