@@ -11,12 +11,10 @@ from viprs_amd.utils import synthetic as syn
 upper = "upper" in sys.argv
 dt = np.int8 if "int8" in sys.argv else np.float32
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
-CONFIGS = [dict()]
-for lg, md, t0, t1 in (("1920", "1600", "8", "4"), ("1792", "1600", "8", "4"), ("2048", "1600", "8", "4"), ("1920", "1280", "8", "3"),
-                       ("1920", "1408", "8", "3"), ("1920", "1280", "8", "4"), ("2304", "1280", "8", "3"), ("2304", "1408", "8", "3"),
-                       ("1792", "1280", "8", "3"), ("1920", "1152", "8", "2"), ("1664", "1152", "8", "3"), ("1920", "1600", "6", "4")):
-    CONFIGS.append(dict(VIPRS_LARGE_BLOCK=lg, VIPRS_MEDIUM_BLOCK=md, VIPRS_TEAM0=t0, VIPRS_TEAM1=t1))
-CONFIGS.append(dict())
+CONFIGS = []
+for rep in range(2):
+    for t0, t1 in (("8", "4"), ("12", "4"), ("12", "6"), ("16", "6"), ("16", "4"), ("12", "5")):
+        CONFIGS.append(dict(VIPRS_TEAM0=t0, VIPRS_TEAM1=t1))
 KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK")
 for cfg in CONFIGS:
     for k in KEYS:

@@ -190,6 +190,13 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         while (i < n && P->dense_h[i].size >= sched_config().medium_block) ++i;
         P->class_begin[2] = i;
         P->class_begin[3] = n;
+        // Team size of the largest class: a member's updater waves pull ~16 GB/s under load, so the share of a block's
+        // row panel per member has to stay near 100 KB for the phase to remain chain-bound (~9 us): 4 members per 1 500
+        // SNPs of the largest block, 8..16 (cfg3, 3 619 SNPs: 12 -- 0.70-0.71 ms against 0.72-0.77 with 8 in the same
+        // process; one 6 000-SNP block: 16 -- 1.05 against 1.17 ms).  VIPRS_TEAM0 overrides.
+        // (bytes, not SNPs: int8 LD keeps 8 -- its sweep is bound by the number of chains in flight, 12 costs it 4 %)
+        if (!sched_config().team_env && P->class_begin[1] > 0)
+            P->team0 = std::min(16, std::max(8, 4 * (int)(((int64_t)P->dense_h[0].size * (int64_t)es + 5999) / 6000)));
         // hand-off granules for the blocks served by teams (classes 0 and 1)
         int64_t rows = 0;
         for (int k = 0; k < P->class_begin[2]; ++k) {

@@ -89,6 +89,7 @@ struct viprs_plan {
     // more row loads in flight = a larger share of HBM bandwidth for the larger blocks); class c
     // covers dense_h[class_begin[c] .. class_begin[c+1])
     int class_begin[4] = {0, 0, 0, 0};
+    int team0 = 0;                          // team size of the largest class for this plan's largest block (0: the configured one)
     viprs::DevBuf<viprs::BlockDesc> d_dense, d_ragged;
     viprs::DevBuf<unsigned long long> d_granules;  // team hand-off granules (one row of 64 per panel of a team block)
     int64_t n_granule_rows = 0;
