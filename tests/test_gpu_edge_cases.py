@@ -410,3 +410,14 @@ def test_dense_block_beyond_the_lds_limit(gpu):
     ld, ss, inp = syn.make_problem(sizes=[30500, 70], low_memory=True, ld_dtype=np.int8, seed=17)
     st0 = inp.state_copy()
     H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=1), H.run_oracle(ld, inp, st0, sweeps=1))
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_dense_block_at_the_lds_limit(gpu, low_memory):
+    """The largest block the panel kernels take (13 184 SNPs: q -- and, in the upper-triangular form, the second-pass
+    sums -- of the whole block in LDS next to the tiles, 160 KB, one workgroup per CU) and the first size beyond it
+    (windowed-component schedule): same bits as the oracle on far-field-sensitive LD."""
+    for size in (13184, 13248):
+        ld, ss, inp = syn.make_problem(sizes=[size, 130], low_memory=low_memory, ld_dtype=np.int8, seed=19, kind="longrange")
+        st0 = inp.state_copy()
+        H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=1), H.run_oracle(ld, inp, st0, sweeps=1))

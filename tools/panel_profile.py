@@ -8,12 +8,14 @@ import numpy as np
 from viprs_amd.plan import DeviceState, LDPlan
 from viprs_amd.utils import synthetic as syn
 
-arg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+UPPER = "upper" in sys.argv
+argv = [a for a in sys.argv if a != "upper"]
+arg = argv[1] if len(argv) > 1 else "cfg3"
 if arg == "cfg3":
-    ld, ss, inp = syn.make_problem("cfg3", low_memory=False)
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=UPPER)
 else:
     ld, ss, inp = syn.make_problem(sizes=[int(arg)] * int(sys.argv[2] if len(sys.argv) > 2 else 1), low_memory=False, seed=3)
-plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False)
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, ld.low_memory)
 ds = DeviceState(plan)
 ds.upload("std_beta", inp.std_beta)
 for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"):
