@@ -905,9 +905,6 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
     const float dq = A.dq;
     ExpTab tab;
     tab.init();
-    // chain-wave roles
-    const int cg = lane & 31, ch = lane >> 5;
-    const bool has_model = cg < n_models;
     if (tid < kGridModels) s_act[tid] = A.active[min(tid, n_models - 1)];
     __syncthreads();
 
@@ -1237,12 +1234,10 @@ __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kern
     __shared__ int s_act[kGridModels];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* el = smem + wave * kGridLowWaveFloats;        // [2][64 rows][33]: dq * eta_diff of a panel, [row][model]
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
     const int n_models = A.n_active;
     const float dq = A.dq;
     if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
     __syncthreads();
-    const int n = lane & 31;
 
     for (;;) {
         int item = 0;

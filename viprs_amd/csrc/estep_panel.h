@@ -521,17 +521,22 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     //     phase ahead of its use);
     //   mixture (rolled chain loop): the off-diagonal tiles R[p-1, p] / R[p, p+1], diagonal rows from global memory.
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
-    // symmetric form: the off-diagonal tile of the chain's next phase goes through LDS too (below).  The upper-triangular
-    // form keeps the chain's own register prefetch: its updater waves carry the second pass and are the busier side --
-    // staging one more tile per phase, and waiting for the chain's go-ahead to do so, costs them more than the chain wins
-    // (cfg3: 0.74 -> 0.77 ms with the tile in LDS, 0.80 -> 0.72-0.77 ms in the symmetric form)
+    // The off-diagonal tile of the chain's next phase goes through LDS too (below) in the SYMMETRIC form.  The upper-
+    // triangular form keeps the chain's own register prefetch: measured with nothing else changed (-DPANEL_UPPER_LDS_TILE;
+    // the LDS is there since the team classes keep only their own strips), the tile in LDS makes the cfg3 sweep 5 % SLOWER
+    // (0.792 -> 0.831 ms) although the chain loop itself gets faster -- the upper form's updater waves carry the second pass
+    // and are the busier side: one more tile to stage per phase, and a go-ahead to wait for, cost them more than the chain wins.
     // The K <= 8 mixture chain (components of one SNP across the lanes) follows the same scheme in the symmetric form:
     // diagonal tiles staged in LDS, the off-diagonal tile of the next phase in the single gated buffer -- its chain wave
     // issues no vector-memory instruction inside a panel either (it used to stream the diagonal rows from global memory,
     // 16 rows ahead).
     constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value && SYM;
     constexpr bool kStageDiag = kDiagInLds || kMixLds;          // what the updaters stage into lT: diagonal tiles
+#ifndef PANEL_UPPER_LDS_TILE
     constexpr bool kTileInLds = (kDiagInLds && SYM) || kMixLds;
+#else
+    constexpr bool kTileInLds = kDiagInLds || kMixLds;
+#endif
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
@@ -615,9 +620,22 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         const U* __restrict__ base = ldd + bd.ld_off;
         const int np = (b + kPanel - 1) / kPanel;
         const int bpad = np * kPanel;
+        // A team member keeps in LDS only the q (and, upper-triangular form, the second-pass sums) of ITS OWN strips,
+        // strip after strip (strip st = member + k TS is local strip k): nobody else's columns are ever read from or
+        // written to its LDS -- the chain takes the other members' panels from their hand-off granules (panels 0 and 1,
+        // which precede every hand-off, from the state itself).  LDS of the team classes: qcap / TS instead of qcap.
+        const int nstrips_all = (bpad + kSW - 1) / kSW;
+        const int n_own = TEAM ? (nstrips_all - member + TS - 1) / TS : nstrips_all;       // strips member, member + TS, ...
+        auto own = [&](int c) { return !TEAM || ((c / kSW) % TS) == member; };
+        auto loc = [&](int c) { return TEAM ? ((c / kSW) / TS) * kSW + (c % kSW) : c; };       // own columns only
+        auto glob = [&](int li) { return TEAM ? ((li / kSW) * TS + member) * kSW + (li % kSW) : li; };
 
-        for (int i = tid; i < bpad + kStrip; i += NW * 64) lq[i] = (i < b) ? A.q[s0 + i] : 0.0f;
-        if (!SYM) for (int i = tid; i < bpad; i += NW * 64) ls[i] = 0.0f;
+        for (int li = tid; li < (TEAM ? n_own * kSW : bpad) + kStrip; li += NW * 64) {
+            const int c = glob(li);
+            const bool in = (!TEAM || li < n_own * kSW) && c < b;
+            lq[li] = in ? A.q[s0 + c] : 0.0f;
+            if (!SYM) ls[li] = 0.0f;
+        }
         if (tid == 0) s_tdone = 0;
         if (kStageDiag) {
             // diagonal tile of panel 0 (rows past the end of a short block are clamped: finite values that
@@ -689,7 +707,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     const int rn0 = min(r0 + kPanel, bpad - kPanel);
                     const U* __restrict__ nptr = base + (int64_t)rn0 * stride + rn0 + lane;
 
-                    float qc = lq[r0 + lane];
+                    float qc;
+                    if (own(r0)) qc = lq[loc(r0 + lane)];
+                    else qc = (r0 + lane < b) ? A.q[s0 + r0 + lane] : 0.0f;       // (panels 0 / 1 of another member: no update has reached them yet)
                     if (TEAM && p >= 2 && (((p * kPanel) / kSW) % TS) != member) {
                         // panel p lives in another member's strip: take its q (all trailing updates
                         // a_0 .. a_{p-2} applied) from the owner's granules, tag = p + 1
@@ -992,7 +1012,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         if (!SYM) led[(p & 1) * kPanel + lane] = d_lane;
                     }
                     la[(p & 1) * kPanel + lane] = a_prev;
-                    lq[r0 + lane] = qc;
+                    if (own(r0)) lq[loc(r0 + lane)] = qc;
                     PPROF(4, true);
                 }
             }
@@ -1055,13 +1075,15 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     const int s_pri = ((p + 1) * kPanel) / kSW;
                     const int n_mine = (nstrips - member + TS - 1) / TS;       // strips member, member+TS, ...
                     for (int k = uw; k < n_mine; k += NW - 1) {
-                        int st = member + k * TS;
+                        int st = member + k * TS, kl = k;                     // kl: the strip's index in this member's LDS
                         if (TEAM) {
                             // rotate so that the priority strip (if this member owns it) is slot 0
                             const int k_pri = (s_pri % TS == member) ? (s_pri - member) / TS : 0;
-                            st = member + ((k + k_pri) % n_mine) * TS;
+                            kl = (k + k_pri) % n_mine;
+                            st = member + kl * TS;
                         }
                         const int c = st * kSW + CPL * lane;
+                        float* __restrict__ lq_c = lq + (TEAM ? kl * kSW + CPL * lane : c);
                         const int cp = c >> 6;
                         // symmetric form: every column except the chain's two panels (left of the
                         // chain = SNPs already visited, their q keeps accumulating for the next
@@ -1070,15 +1092,15 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
                         if (any_a && active) {
                             if (last_row == kPanel - 1)
-                                strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
                             else
-                                strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq + c);
+                                strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
                         }
                         if (k == uw) PPROF(6, wave == 1);
                         if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
                             // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
                             __builtin_amdgcn_wave_barrier();
-                            const float v = lq[(p + 1) * kPanel + lane];
+                            const float v = lq[loc((p + 1) * kPanel + lane)];
                             const unsigned long long g =
                                 ((unsigned long long)(A.tag_base + (unsigned)(p + 2)) << 32) | (unsigned long long)__float_as_uint(v);
                             __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
@@ -1118,7 +1140,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                     int rn = r + NW - 1;
                                     while (rn <= pp && !mine(rn)) rn += NW - 1;
                                     if (rn <= pp) fetch(h1, rn);
-                                    float* __restrict__ sl = ls + r * kPanel + lane;
+                                    float* __restrict__ sl = ls + loc(r * kPanel + lane);
                                     if constexpr (kSecondPassViaLds) h0.to_rows(tbuf, lane);
                                     *sl = h0.accumulate(*sl, ed);
                                     r = rn;
@@ -1126,7 +1148,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                     rn = r + NW - 1;
                                     while (rn <= pp && !mine(rn)) rn += NW - 1;
                                     if (rn <= pp) fetch(h0, rn);
-                                    sl = ls + r * kPanel + lane;
+                                    sl = ls + loc(r * kPanel + lane);
                                     if constexpr (kSecondPassViaLds) h1.to_rows(tbuf, lane);
                                     *sl = h1.accumulate(*sl, ed);
                                     r = rn;
@@ -1154,11 +1176,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         }
 #endif
         {   // teams: every member owns the final q of its own strips
-            for (int i = tid; i < b; i += NW * 64)
-                if (!TEAM || ((i / kSW) % TS) == member) {
-                    const float v = SYM ? lq[i] : lq[i] + A.dq * ls[i];      // upper form: q[j] += dq * dot (e_step.hpp:335)
+            for (int li = tid; li < (TEAM ? n_own * kSW : b); li += NW * 64) {
+                const int i = glob(li);
+                if (i < b) {
+                    const float v = SYM ? lq[li] : lq[li] + A.dq * ls[li];   // upper form: q[j] += dq * dot (e_step.hpp:335)
                     if (TEAM) stage_store(A.q_out + s0 + i, v); else A.q[s0 + i] = v;
                 }
+            }
         }
         if (TEAM) {
             // eta / q are in-out and other members may still be reading the old values, so team blocks write to staging
