@@ -202,3 +202,52 @@ def test_reporting_methods_match_their_definitions(name):
     ht = model.to_history_table()
     assert len(ht) == len(model.history["ELBO"]) and "ELBO" in ht.columns
     assert model.get_average_effect_size_variance() > 0
+
+
+_WORKER_EMPTY = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch.distributed as dist
+world = {world}
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=world)
+from oracle import oracle as O
+from viprs_amd.data import ArrayDataLoader
+from viprs_amd.model import VIPRS
+from viprs_amd.parallel import TorchDistComm
+comm = TorchDistComm()
+# two chromosomes with ONE and TWO LD blocks: with three ranks every rank gets one block, with four one rank gets NONE
+gdl = ArrayDataLoader.synthetic({{21: [260], 22: [150, 330]}}, seed=77, kind="longrange")
+theta = {{"pi": 0.02, "sigma_epsilon": 0.85}}
+model = VIPRS(gdl, low_memory=True, comm=comm, e_step_fn=O.cpp_e_step)
+n_local = sum(model.shapes.values())
+tot = comm.allreduce_sum(np.array([float(n_local), 1.0 if n_local == 0 else 0.0]))
+assert int(tot[0]) == 740 and int(tot[1]) == world - 3, (tot, n_local)
+model.fit(max_iter=25, theta_0=dict(theta))
+if comm.rank == 0:
+    ref = VIPRS(gdl, low_memory=True, e_step_fn=O.cpp_e_step).fit(max_iter=25, theta_0=dict(theta))
+    np.testing.assert_allclose(model.history["ELBO"], ref.history["ELBO"], rtol=2e-7, atol=0.05)
+    assert model.optim_result.nit == ref.optim_result.nit
+    for c in (21, 22):
+        np.testing.assert_allclose(model.pip[c], ref.pip[c], rtol=2e-3, atol=2e-6)
+        np.testing.assert_allclose(model.post_mean_beta[c], ref.post_mean_beta[c], rtol=2e-3, atol=2e-7)
+        np.testing.assert_allclose(model.q_full[c], ref.q[c], rtol=2e-3, atol=2e-6)
+        assert model.pip[c].shape == (gdl.shapes[c],)
+dist.barrier(); dist.destroy_process_group()
+print("RANK_OK", sys.argv[1])
+"""
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_more_ranks_than_blocks_per_chromosome_and_an_empty_rank(tmp_path, world):
+    """Three LD blocks on three / four ranks (gloo on CPU): a rank may hold blocks of one chromosome only, or NO block at
+    all -- it still takes part in every exchange (the partial sums of each EM iteration, the posterior all-gather at the
+    end) and ends up with the posterior of all SNPs; the fit equals the single-process fit."""
+    script = tmp_path / "worker.py"
+    port = 29500 + ((os.getpid() * 11 + world * 197) % 2000)
+    script.write_text(_WORKER_EMPTY.format(root=ROOT, port=port, world=world))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-3000:]

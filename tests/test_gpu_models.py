@@ -143,3 +143,21 @@ def test_very_large_blocks_all_models(gpu, low_memory, monkeypatch):
     g, gst0 = _grid_inputs(ld, ss, 8)
     active = np.arange(8, dtype=np.int32)
     H.assert_state_equal(_run_grid(S, ld, inp, g, gst0, active, sweeps=1), _run_grid(O, ld, inp, g, gst0, active, sweeps=1))
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_grid_resident_form_equals_streaming_form(gpu, low_memory, monkeypatch):
+    """The batched grid kernel keeps q of blocks up to 1 536 SNPs in accumulator registers for the whole block (resident
+    form) and streams it per panel for larger ones; VIPRS_GRID_RESIDENT=0 forces the streaming form (+ the lower-pass
+    kernel) for every block.  Same bits either way, and the oracle's -- on blocks on both sides of the limit."""
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    ld, ss, inp = syn.make_problem(sizes=[1536, 1537, 640, 65, 1], low_memory=low_memory, seed=71, kind=KIND)
+    g, st0 = _grid_inputs(ld, ss, 32)
+    active = np.array([0, 31, 6, 17, 23], dtype=np.int32)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("VIPRS_GRID_RESIDENT", mode)
+        out[mode] = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
+    H.assert_state_equal(out["1"], out["0"])
+    H.assert_state_equal(out["1"], _run_grid(O, ld, inp, g, st0, active, sweeps=2))

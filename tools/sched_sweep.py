@@ -11,10 +11,10 @@ from viprs_amd.utils import synthetic as syn
 upper = "upper" in sys.argv
 dt = np.int8 if "int8" in sys.argv else np.float32
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
-CONFIGS = []
-for rep in range(2):
-    for t0, t1 in (("8", "4"), ("12", "4"), ("12", "6"), ("16", "6"), ("16", "4"), ("12", "5")):
-        CONFIGS.append(dict(VIPRS_TEAM0=t0, VIPRS_TEAM1=t1))
+CONFIGS = [dict()]
+for md, t1 in (("1024", "2"), ("1024", "3"), ("1024", "4"), ("960", "2"), ("896", "2"), ("1024", "1")):
+    CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK=md, VIPRS_TEAM1=t1, VIPRS_TEAM0="12"))
+CONFIGS.append(dict())
 KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK")
 for cfg in CONFIGS:
     for k in KEYS:
