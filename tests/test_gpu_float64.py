@@ -1,0 +1,140 @@
+"""GPU: float64 state (float_precision='float64', VIPRS.py:72) -- the panel-walking kernels of estep_tile.h against
+the oracle run in double.  A float64 state is NOT a bit-for-bit contract (the device's double exp is ocml's, the
+reference's is glibc's; the second pass of the upper form sums in lane order): the tolerance is 1e-10 relative, which
+BASELINE.json's north_star states for float64."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+from tests.test_band import banded_ld
+from tests.test_oracle_vs_ref import _grid_inputs
+from viprs_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+RTOL_F64 = 1e-10
+T = np.float64
+
+
+def assert_state_close_f64(got, ref, rtol=RTOL_F64):
+    """1e-10 relative, entries below 1e-4 of a vector's largest magnitude held to that floor: var_mu = mu_mult (beta -
+    q) and eta_diff = gamma mu - eta are differences of O(scale) quantities, their small entries carry the absolute
+    rounding noise of q (a 2 500-term fma chain seeded by an exp that is not glibc's) -- ~1e-15 absolute here."""
+    assert H.branch_flips(got, ref) == 0
+    for k in H.STATE:
+        assert_close_f64(got[k], ref[k], k, rtol)
+
+
+def assert_close_f64(got, ref, what, rtol=RTOL_F64):
+    scale = float(np.max(np.abs(ref)))
+    tol = rtol * np.maximum(np.abs(ref), 1e-4 * scale)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.size} beyond {rtol}; worst {np.max(np.abs(got - ref))}"
+
+
+@pytest.mark.parametrize("ld_dtype", [np.int8, np.int16, np.float32, np.float64, np.int32])
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_float64_spike_slab_matches_oracle_on_far_field_ld(gpu, low_memory, ld_dtype):
+    """Blocks of 1 .. 40 panels (ragged last panels, more than 1 024 columns: several column passes per panel) on
+    long-range LD; every stored entry matters (the probe with the far field cut away must differ)."""
+    ld, ss, inp = syn.make_problem(sizes=[70, 1400, 333, 2500, 64, 1], low_memory=low_memory, ld_dtype=ld_dtype, seed=41,
+                                   kind="longrange", float_precision=T)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=3)
+    got = H.run_hip(ld, inp, st0, sweeps=3)
+    assert got["q"].dtype == np.float64
+    assert_state_close_f64(got, ref)
+    cut = H.run_oracle(H.cut_far_field(ld), inp, st0, sweeps=3)
+    assert np.max(np.abs(cut["q"] - ref["q"])) > 1e-4 * np.max(np.abs(ref["q"]))
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_float64_tile_kernel_equals_row_by_row_kernel(gpu, low_memory, monkeypatch):
+    ld, ss, inp = syn.make_problem(sizes=[700, 130, 1100], low_memory=low_memory, ld_dtype=np.int8, seed=42,
+                                   kind="longrange", float_precision=T)
+    st0 = inp.state_copy()
+    tile = H.run_hip(ld, inp, st0, sweeps=2)
+    monkeypatch.setenv("VIPRS_F64_ROW_BY_ROW", "1")
+    rows = H.run_hip(ld, inp, st0, sweeps=2)
+    assert_state_close_f64(tile, rows)
+
+
+@pytest.mark.parametrize("ld_dtype", [np.float32, np.int8])
+@pytest.mark.parametrize("low_memory", [False, True])
+@pytest.mark.parametrize("m, wl, wr, jitter", [(700, 23, 23, 0), (1500, 130, 70, 40), (64, 5, 9, 3), (333, 400, 400, 0)])
+def test_float64_windowed_components(gpu, m, wl, wr, jitter, low_memory, ld_dtype):
+    ld = banded_ld(m, wl, wr, low_memory, ld_dtype, seed=m, jitter=jitter)
+    rng = np.random.default_rng(1)
+    beta = rng.standard_normal(m) * 0.004
+    beta[rng.integers(0, m, max(1, m // 50))] += 0.05
+    ss = syn.SyntheticSumstats(beta.astype(T), np.full(m, 1e5), np.zeros(m, T), 1e5)
+    inp = syn.make_inputs(ss, float_precision=T)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=2)
+    got = H.run_hip(ld, inp, st0, sweeps=2)
+    assert_state_close_f64(got, ref)
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_float64_grid_matches_oracle(gpu, low_memory):
+    from viprs_amd.vi import e_step_hip as S
+    ld, ss, inp = syn.make_problem(sizes=[130, 1300, 64], low_memory=low_memory, seed=33, kind="longrange", float_precision=T)
+    g, st0 = _grid_inputs(ld, ss, 12, T=T)
+    active = np.array([11, 0, 7, 8, 3], dtype=np.int32)
+    out = {}
+    for name, mod in (("ref", O), ("hip", S)):
+        st = {k: v.copy(order="F") for k, v in st0.items()}
+        for _ in range(2):
+            mod.cpp_e_step_grid(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, inp.std_beta, st["var_gamma"], st["var_mu"],
+                                st["eta"], st["q"], st["eta_diff"], g["u_logs"], g["hvt"], g["mu_mult"], ld.dq_scale,
+                                active, 1, low_memory)
+        out[name] = st
+    assert_state_close_f64(out["hip"], out["ref"])
+    untouched = [c for c in range(12) if c not in active]
+    assert np.all(out["hip"]["eta"][:, untouched] == 0)
+
+
+def test_float64_skip_branch_counts(gpu):
+    """Ten sweeps in, about half of the SNPs take the skip branch (|eta_diff| < 1e-8, e_step.hpp:410): they keep
+    var_mu / var_gamma / eta and get eta_diff = 0, the same SNPs as in the oracle."""
+    ld, ss, inp = syn.make_problem(sizes=[300, 90], low_memory=False, seed=43, kind="longrange", float_precision=T)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=10)
+    got = H.run_hip(ld, inp, st0, sweeps=10)
+    skipped = ref["eta_diff"] == 0
+    assert 0.3 < np.mean(skipped) < 0.9                    # both branches are exercised
+    assert np.array_equal(got["eta_diff"] == 0, skipped)
+    for k in ("eta", "q", "var_gamma", "var_mu"):
+        assert_close_f64(got[k], ref[k], k)
+    # eta_diff = gamma * mu - eta cancels to ~1e-8 here: absolute tolerance (a few ulp of eta)
+    np.testing.assert_allclose(got["eta_diff"], ref["eta_diff"], rtol=0, atol=1e-15)
+
+
+def test_float64_chain_sigmoid_against_an_80_bit_reference(gpu):
+    """The chain's own exp / divide (estep_tile.h: 64-entry table, degree-6 polynomial, v_rcp_f64 + one Newton step +
+    residual correction): 1-SNP blocks with mu_mult = std_beta = 1, sqrt_half_var_tau = 0 make var_gamma =
+    sigmoid(u_logs) and eta_diff = var_gamma -- compared with numpy's long double over the whole argument range."""
+    if np.finfo(np.longdouble).eps > 1e-18:
+        pytest.skip("no extended-precision long double on this host")
+    rng = np.random.default_rng(9)
+    x = np.concatenate([np.linspace(-760, 760, 40001), rng.standard_normal(40000) * 30, rng.standard_normal(20000),
+                        [0.0, -0.0, 1e-300, -1e-300, 708.0, -708.0, -708.5, 709.0, -745.2, 1e6, -1e6]])
+    m = x.size
+    ld = syn.SyntheticLD(np.arange(m, dtype=np.int32), np.arange(m + 1, dtype=np.int64), np.ones(m, np.float32),
+                         np.arange(m + 1), np.zeros(m), False, 1.0)
+    ss = syn.SyntheticSumstats(np.ones(m), np.full(m, 1e5), np.zeros(m), 1e5)
+    inp = syn.make_inputs(ss, float_precision=T)
+    inp.mu_mult[:] = 1.0
+    inp.sqrt_half_var_tau[:] = 0.0
+    inp.u_logs[:] = x
+    got = H.run_hip(ld, inp, inp.state_copy(), sweeps=1)
+    xl = x.astype(np.longdouble)
+    e = np.exp(-np.abs(xl))
+    ref = np.where(xl < 0, e, np.longdouble(1)) / (1 + e)
+    applied = got["eta_diff"] != 0
+    assert np.array_equal(applied, np.abs(ref.astype(T)) >= 1e-8)          # the skip branch (|eta_diff| < 1e-8)
+    g = got["var_gamma"][applied].astype(np.longdouble)
+    err = np.abs(g - ref[applied]) / ref[applied]
+    assert float(err.max()) < 4 * np.finfo(T).eps, float(err.max())
+    np.testing.assert_array_equal(got["eta_diff"][applied], got["var_gamma"][applied])
+    assert np.all(got["var_mu"][applied] == 1.0) and np.all(got["q"] == 0)

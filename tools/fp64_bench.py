@@ -1,6 +1,6 @@
 """float_precision='float64' (VIPRS.py:72): the state is double, every block takes the row-by-row generic kernels
 (estep_generic.h).  Sweep time and SNP-updates/s on cfg2 / cfg3 through the device-resident state API.
-    python tools/fp64_bench.py [cfg2|cfg3] [int8|float32|float64]"""
+    python tools/fp64_bench.py [cfg2|cfg3] [int8|float32|float64] [upper|sym]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,11 +9,13 @@ from viprs_amd.utils import synthetic as syn
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 dt = np.dtype(sys.argv[2] if len(sys.argv) > 2 else "int8")
-ld, ss, inp = syn.make_problem(cfg, low_memory=True, ld_dtype=dt, kind="longrange", float_precision=np.float64)
-plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)
+upper = not (len(sys.argv) > 3 and sys.argv[3] == "sym")
+form = "upper-triangular" if upper else "symmetric"
+ld, ss, inp = syn.make_problem(cfg, low_memory=upper, ld_dtype=dt, kind="longrange", float_precision=np.float64)
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper)
 for prec in ("float64", "float32"):
     if prec == "float32":
-        ld32, ss32, inp = syn.make_problem(cfg, low_memory=True, ld_dtype=dt, kind="longrange")
+        ld32, ss32, inp = syn.make_problem(cfg, low_memory=upper, ld_dtype=dt, kind="longrange")
     ds = DeviceState(plan, prec, "spike_slab", 1)
     for k in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
         ds.upload(k, getattr(inp, k))
@@ -26,5 +28,5 @@ for prec in ("float64", "float32"):
         ds.reset(inp.pi); ds.e_step(ld.dq_scale, sync=False)
     ds.synchronize()
     dt_s = (time.perf_counter() - t0) / n
-    print(f"{cfg} LD {dt.name} upper-triangular, state {prec}: {dt_s * 1e3:.2f} ms per sweep = {ld.m / dt_s / 1e6:.1f} M SNP-updates/s", flush=True)
+    print(f"{cfg} LD {dt.name} {form}, state {prec}: {dt_s * 1e3:.2f} ms per sweep = {ld.m / dt_s / 1e6:.1f} M SNP-updates/s", flush=True)
     ds.close()

@@ -60,6 +60,19 @@ int launch_generic_u(viprs_plan* P, const EStepArgs<T>& A, int model, bool dense
     }
 }
 
+int launch_tile_f64_u(viprs_plan* P, const EStepArgs<double>& A, int model, bool dense) {
+    if (getenv("VIPRS_F64_ROW_BY_ROW")) return launch_generic_u<double>(P, A, model, dense);      // experiments / A-B
+    switch (P->ld_dtype) {
+        case VIPRS_LD_I8: return launch_tile_f64<int8_t>(P, A, model, dense);
+        case VIPRS_LD_I16: return launch_tile_f64<int16_t>(P, A, model, dense);
+        case VIPRS_LD_I32: return launch_tile_f64<int32_t>(P, A, model, dense);
+        case VIPRS_LD_I64: return launch_tile_f64<int64_t>(P, A, model, dense);
+        case VIPRS_LD_F32: return launch_tile_f64<float>(P, A, model, dense);
+        case VIPRS_LD_F64: return launch_tile_f64<double>(P, A, model, dense);
+        default: return fail(VIPRS_EINVAL, "bad LD dtype");
+    }
+}
+
 int launch_panel_u(viprs_plan* P, const EStepArgs<float>& A, int model) {
     switch (P->ld_dtype) {
         case VIPRS_LD_F32: return launch_panel<float>(P, A, model);
@@ -119,10 +132,10 @@ int run_spike_slab(viprs_state* S, double dq) {
         if (use_band(P)) rc = launch_band_u(P, A, kBandSpikeSlab);
         else if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A, kGenSpikeSlab, false);
     } else {
-        // float64 state: the panel kernels specialise float; every block takes the generic kernel
+        // float64 state: the panel kernels specialise float; every block takes the panel-walking kernel of estep_tile.h
         EStepArgs<double> A = make_args<double>(S, dq);
-        rc = launch_generic_u<double>(P, A, kGenSpikeSlab, true);
-        if (rc == VIPRS_OK) rc = launch_generic_u<double>(P, A, kGenSpikeSlab, false);
+        rc = launch_tile_f64_u(P, A, kGenSpikeSlab, true);
+        if (rc == VIPRS_OK) rc = launch_tile_f64_u(P, A, kGenSpikeSlab, false);
     }
     if (rc != VIPRS_OK) return rc;
     if (!dense_only) HIP_TRY(hipEventRecord(ev[1], P->stream));
@@ -206,8 +219,8 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         EStepArgs<double> A = make_args<double>(S, dq);
         A.active = d_active;
         A.n_active = n_active;
-        rc = launch_generic_u<double>(P, A, model, true);
-        if (rc == VIPRS_OK) rc = launch_generic_u<double>(P, A, model, false);
+        rc = launch_tile_f64_u(P, A, model, true);
+        if (rc == VIPRS_OK) rc = launch_tile_f64_u(P, A, model, false);
     }
     if (rc != VIPRS_OK) return rc;
     HIP_TRY(hipEventRecord(ev[3], P->stream));

@@ -1,0 +1,453 @@
+// float64 state (float_precision='float64', VIPRS.py:72): the E-step walked in 64-SNP panels by one workgroup per LD
+// block -- the panel scheme of estep_panel.h in its plainest form (no teams, no hand-off), for the state type the panel
+// kernels do not specialise.  Per panel p:
+//   1. its 64 x 64 diagonal tile and the off-diagonal tile (rows of panel p - 1, columns of panel p) go into LDS;
+//   2. wave 0 applies the rows of panel p - 1 to its 64 columns (64 fma per lane), then runs the 64 sequential updates
+//      (e_step.hpp:401-431) with q of the panel in its lanes' registers -- the in-panel part of every row's axpy
+//      (e_step.hpp:421) is one fma per step -- and leaves a_j = dq * eta_diff_j in LDS;
+//   3. meanwhile waves 1..3 apply the rows of panel p - 1 to the columns outside panels p - 1 and p,
+//      q[c] = fma(R[j,c], a_j, q[c]) for j in panel order: every q[c] sees its rows in the order the reference applies
+//      them (symmetric form: the same fma sequence per element).
+// The second pass of the upper-triangular form (update_q_factor, e_step.hpp:331-337) is its own launch over the rows of
+// all blocks, one wave per row with the lanes across the row's columns (coalesced); the dot is summed in lane-partial
+// order there, NOT in the reference's index order.  A float64 state is compared to the reference within 1e-10, never
+// bit for bit (the chain's exp is not glibc's, see below).  The row-by-row kernels of estep_generic.h remain for what
+// this file does not cover: the mixture with a float64 state, blocks whose q does not fit the LDS.
+#pragma once
+#include "device_math.h"
+#include "estep_generic.h"
+#include "kernels_common.h"
+
+namespace viprs {
+
+constexpr int kTileThreads = 256;
+// step 3: a thread owns CPT adjacent columns (16 bytes of a row: one vector load; at least 4 columns), and the loads
+// of RIF rows are in flight at a time (64 VGPRs of row data)
+template <typename U> constexpr int tile_cpt() { return sizeof(U) >= 4 ? 4 : 16 / (int)sizeof(U); }
+template <typename U> constexpr int tile_rif() { return 256 / (tile_cpt<U>() * (int)sizeof(U)); }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The chain's sigmoid.  A float64 operation costs a wave ~20 clocks of dependent latency on gfx950, so the serial step
+// is priced in dependent operations: ocml's exp (no table, degree-11 polynomial, ldexp) and the IEEE divide sequence
+// make it 42; the versions below 27.
+//   exp(t), t <= 0: k = rint(t * 64/ln2), r = t - k ln2/64 (two-term Cody-Waite, |r| <= ln2/128), 2^(k/64) from a
+//   64-entry table held across the lanes (lane l: 2^(l/64); the argument is wave-uniform on the chain, so the lookup is
+//   two v_readlane), exp(r) - 1 by a degree-6 polynomial in Estrin form, the power of two added into the exponent
+//   field.  Error < 2 ulp (table entry 0.5 + polynomial 0.1 + roundings); arguments below -708 give 0.
+//   num / den, den in [1, 2]: v_rcp_f64, one Newton step, quotient and one residual correction.
+// Neither is bit-identical to glibc's exp / an IEEE divide -- nor is ocml's exp: the float64 state is compared to the
+// reference within 1e-10 (see the header); tests/test_gpu_float64.py checks the sigmoid against an 80-bit reference.
+// ---------------------------------------------------------------------------------------------------------------
+struct ExpTab64 {
+    double t;                                                // lane l: 2^((l & 63) / 64)
+    __device__ __forceinline__ void init() { t = exp2((double)(threadIdx.x & 63) * 0.015625); }
+};
+
+__device__ __forceinline__ double exp_nonpos_f64_uniform(double t, const ExpTab64& tab) {
+    const double InvLn2N = 0x1.71547652b82fep+6;             // 64 / ln2
+    const double NegLn2hiN = -0x1.62e42fefa0000p-7;          // -ln2/64, high part (kd * hi is exact for |kd| < 2^17)
+    const double NegLn2loN = -0x1.cf79abc9e3b3ap-46;
+    const double kd = rint(t * InvLn2N);
+    double r = __builtin_fma(kd, NegLn2hiN, t);
+    r = __builtin_fma(kd, NegLn2loN, r);
+    // 2^(k/64): table entry of k mod 64, k div 64 added to its exponent (t >= -708: the result stays normal)
+    const int k = __builtin_amdgcn_readfirstlane((int)kd);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(tab.t), k & 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(tab.t), k & 63) + ((k >> 6) << 20);
+    const double scale = __hiloint2double(hi, lo);
+    const double r2 = r * r;
+    const double A = __builtin_fma(r, 0x1.5555555555555p-3, 0.5);                       // 1/2 + r/6
+    double B = __builtin_fma(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);            // 1/24 + r/120
+    const double r4 = r2 * r2;
+    B = __builtin_fma(r2, 0x1.6c16c16c16c17p-10, B);                                    // + r^2/720
+    const double p = __builtin_fma(r4, B, __builtin_fma(r2, A, r));                     // exp(r) - 1
+    const double e = __builtin_fma(scale, p, scale);
+    return t < -708.0 ? 0.0 : e;
+}
+
+__device__ __forceinline__ double sigmoid_f64_uniform(double x, const ExpTab64& tab) {
+    const double e = exp_nonpos_f64_uniform(-fabs(x), tab);
+    const double num = (x < 0.0) ? e : 1.0;
+    const double den = 1.0 + e;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    const double q0 = num * r;
+    return __builtin_fma(__builtin_fma(-den, q0, num), r, q0);
+}
+
+// spike-and-slab (e_step.hpp:401-413) / one model of the grid (e_step.hpp:613-620: no skip branch, half_var_tau, no fma)
+struct TileSpikeSlab {
+    static constexpr bool kSkip = true;
+    __device__ static __forceinline__ void update(double mm, double beta, double s, double ulog, double eta_old, double qj,
+                                                  const ExpTab64& tab, double& mu, double& gamma, double& d) {
+        const double p = mm * qj;
+        mu = __builtin_fma(mm, beta, -p);
+        const double u = s * mu;
+        gamma = sigmoid_f64_uniform(__builtin_fma(u, u, ulog), tab);
+        d = __builtin_fma(gamma, mu, -eta_old);
+    }
+};
+struct TileGridColumn {
+    static constexpr bool kSkip = false;
+    __device__ static __forceinline__ void update(double mm, double beta, double hvt, double ulog, double eta_old, double qj,
+                                                  const ExpTab64& tab, double& mu, double& gamma, double& d) {
+        mu = mm * (beta - qj);
+        const double uj = ulog + hvt * mu * mu;
+        gamma = sigmoid_f64_uniform(uj, tab);
+        d = gamma * mu - eta_old;
+    }
+};
+
+template <typename U, int N> struct alignas(sizeof(U) * N) UVec { U v[N]; };
+
+// LDS: q[qcap] (doubles) | diagonal tile [64][64] | off-diagonal tile [64][64] (LD elements) | per panel parity:
+// a[64] (doubles), rowbase[64] (int64), ws[64], we[64] (ints) | window masks of the two tiles [2][64] (uint64)
+__host__ __device__ constexpr size_t tile_lds_bytes(int qcap, size_t ld_elem) {
+    return (size_t)qcap * 8 + 2 * kPanel * kPanel * ld_elem + 2 * (kPanel * 8 + kPanel * 8 + 2 * kPanel * 4) + 2 * kPanel * 8;
+}
+
+// window of one LD row, block-local columns [ws, we), and the element offset of (row, block column 0)
+struct TileWindow { int ws, we; int64_t base; };
+
+// Panel p's chain (wave 0) runs side by side with the rows of panel p - 1 going onto the columns outside panels
+// p - 1 and p (waves 1..3): before its chain, wave 0 itself applies those rows to ITS 64 columns from the off-diagonal
+// tile in LDS (64 fma per lane).  Everything a panel needs from global memory -- its inputs, its two tiles, the windows
+// of its rows (those two panels ahead: the tiles' addresses come from them) -- is fetched one panel ahead into
+// registers while the chain of the panel before runs.
+template <typename U, typename MODEL, bool DENSE>
+__global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<double> A0, int qcap) {
+    using T = double;
+    constexpr int kWaves = kTileThreads / 64;
+    constexpr int kRowsPerWave = kPanel / kWaves;              // rows of a tile a wave stages: w, w + 4, ...
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* const qv = reinterpret_cast<T*>(smem_raw);
+    U* const tile_d = reinterpret_cast<U*>(qv + qcap);         // rows of panel p, columns of panel p
+    U* const tile_o = tile_d + kPanel * kPanel;                // rows of panel p - 1, columns of panel p
+    T* const s_a = reinterpret_cast<T*>(tile_o + kPanel * kPanel);         // [2][64]: a_j = dq * eta_diff_j
+    int64_t* const s_base = reinterpret_cast<int64_t*>(s_a + 2 * kPanel);  // [2][64]
+    int* const s_ws = reinterpret_cast<int*>(s_base + 2 * kPanel);         // [2][64]
+    int* const s_we = s_ws + 2 * kPanel;                                   // [2][64]
+    unsigned long long* const s_in_d = reinterpret_cast<unsigned long long*>(s_we + 2 * kPanel);   // window masks of tile_d's rows
+    unsigned long long* const s_in_o = s_in_d + kPanel;                                             // ... of tile_o's rows
+    __shared__ int s_item;
+    __shared__ int s_cmin[2], s_cmax[2];                                   // union of the panel's row windows
+    __shared__ unsigned long long s_applied[2];                            // rows of the panel that were not skipped
+
+    ExpTab64 tab;
+    tab.init();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n_models = max(1, A0.n_active);
+    const int64_t n_items = (int64_t)A0.n_blocks * n_models;
+    const U* __restrict__ ld = static_cast<const U*>(DENSE ? A0.ld_dense : A0.ld_rows);
+    const T eps = Eps<T>::value;
+    unsigned long long my_skipped = 0;
+
+    for (;;) {
+        if (tid == 0) s_item = atomicAdd(A0.counter, 1);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();
+        if (item >= n_items) break;
+        const BlockDesc bd = A0.blocks[item / n_models];
+        const EStepArgs<T> A = select_model(A0, item % n_models);
+        const int64_t s0 = bd.start;
+        const int n = bd.size;
+
+        auto load_window = [&](int p0) {                       // lane l: row p0 + l
+            TileWindow w{0, 0, 0};
+            if (p0 + lane < n) {
+                const int64_t j = s0 + p0 + lane;
+                w.ws = A.lb[j] - (int)s0;
+                w.we = w.ws + A.rowlen[j];
+                w.base = DENSE ? bd.ld_off + (int64_t)(p0 + lane) * bd.stride : A.rowstart[j] - w.ws;
+            }
+            return w;
+        };
+        auto row_window = [&](const TileWindow& w, int jj) {   // row jj's window out of the lanes' registers (jj uniform)
+            TileWindow r;
+            r.ws = __builtin_amdgcn_readlane(w.ws, jj);
+            r.we = __builtin_amdgcn_readlane(w.we, jj);
+            const int lo = __builtin_amdgcn_readlane((int)(uint32_t)w.base, jj);
+            const int hi = __builtin_amdgcn_readlane((int)(w.base >> 32), jj);
+            r.base = ((int64_t)hi << 32) | (uint32_t)lo;
+            return r;
+        };
+        // a 64 x 64 tile: rows of the panel whose windows are `w`, columns c0 + lane; this wave's rows (w, w + 4, ...)
+        auto load_tile = [&](U (&t)[kRowsPerWave], const TileWindow& w, int c0) {
+            const int c = c0 + lane;
+#pragma unroll
+            for (int k = 0; k < kRowsPerWave; ++k) {
+                const TileWindow r = row_window(w, wave + kWaves * k);
+                t[k] = (c >= r.ws && c < r.we) ? ld[r.base + c] : (U)0;          // (rows beyond the block: ws == we)
+            }
+        };
+        auto store_tile = [&](const U (&t)[kRowsPerWave], const TileWindow& w, int c0, U* tile, unsigned long long* mask) {
+            const int c = c0 + lane;
+#pragma unroll
+            for (int k = 0; k < kRowsPerWave; ++k) {
+                const int jj = wave + kWaves * k;
+                const TileWindow r = row_window(w, jj);
+                tile[jj * kPanel + lane] = t[k];
+                const unsigned long long m = __ballot(c >= r.ws && c < r.we);
+                if (lane == 0) mask[jj] = m;
+            }
+        };
+        T in_mm = 0, in_sb = 0, in_sh = 0, in_ul = 0, in_eta = 0;
+        auto load_inputs = [&](int p0) {
+            if (wave == 0 && p0 < n) {
+                const int64_t jl = s0 + min(p0 + lane, n - 1);
+                in_mm = A.mu_mult[jl]; in_sb = A.std_beta[jl]; in_sh = A.shvt[jl]; in_ul = A.u_logs[jl]; in_eta = A.eta[jl];
+            }
+        };
+        // rows of the panel at r0 (parity `par`) onto the columns outside [x0, x1), by threads u of nu: a thread owns 4
+        // adjacent columns; the loads of RIF rows are in flight at a time.  Dense blocks: every row of the panel reaches
+        // every column outside it (symmetric form) / to the right of it (upper form) -- no per-element window test;
+        // windowed rows: element loads and tests.
+        auto rows_onto_columns = [&](int par, int x0, int x1, int u, int nu) {
+            constexpr int CPT = 4;
+            constexpr int RIF = DENSE ? (sizeof(U) <= 2 ? 32 : 64 / (int)sizeof(U)) : 8;
+            const unsigned long long applied = s_applied[par];
+            if (applied == 0) return;
+            const T* const pa = s_a + par * kPanel;
+            const int64_t* const pbase = s_base + par * kPanel;
+            const int* const pws = s_ws + par * kPanel;
+            const int* const pwe = s_we + par * kPanel;
+            const int cmin = s_cmin[par] & ~(CPT - 1), cmax = s_cmax[par];
+            for (int cb = cmin + CPT * u; cb < cmax; cb += CPT * nu) {
+                if (cb >= x0 && cb < x1) continue;                               // (panels start at multiples of 64)
+                T v[CPT];
+#pragma unroll
+                for (int x = 0; x < CPT; ++x) v[x] = cb + x < n ? qv[cb + x] : (T)0;
+                for (int j0 = 0; j0 < kPanel; j0 += RIF) {
+                    UVec<U, CPT> r[RIF];
+#pragma unroll
+                    for (int k = 0; k < RIF; ++k) {
+                        const int jj = j0 + k;
+                        if (DENSE) {
+                            r[k] = *reinterpret_cast<const UVec<U, CPT>*>(ld + pbase[jj] + cb);   // (rows are padded to 64)
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < CPT; ++x) {
+                                const int c = cb + x;
+                                r[k].v[x] = (c >= pws[jj] && c < pwe[jj]) ? ld[pbase[jj] + c] : (U)0;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < RIF; ++k) {
+                        const int jj = j0 + k;
+                        if (!((applied >> jj) & 1ull)) continue;
+                        const T a = pa[jj];
+                        if (DENSE) {
+#pragma unroll
+                            for (int x = 0; x < CPT; ++x) v[x] = __builtin_fma(static_cast<T>(r[k].v[x]), a, v[x]);
+                        } else {
+                            const int ws = pws[jj], we = pwe[jj];
+#pragma unroll
+                            for (int x = 0; x < CPT; ++x) {
+                                const int c = cb + x;
+                                const T w = __builtin_fma(static_cast<T>(r[k].v[x]), a, v[x]);
+                                v[x] = (c >= ws && c < we) ? w : v[x];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < CPT; ++x)
+                    if (cb + x < n) qv[cb + x] = v[x];
+            }
+        };
+
+        for (int i = tid; i < n; i += kTileThreads) qv[i] = A.q[s0 + i];
+        TileWindow w_prev{0, 0, 0}, w_cur = load_window(0), w_nxt = load_window(kPanel);
+        U t_d[kRowsPerWave], t_o[kRowsPerWave];
+        load_tile(t_d, w_cur, 0);
+#pragma unroll
+        for (int k = 0; k < kRowsPerWave; ++k) t_o[k] = (U)0;
+        load_inputs(0);
+        T prev_a = 0;                                          // wave 0, lane jj: a_jj of the panel before
+        unsigned long long prev_applied = 0;
+
+        for (int p0 = 0; p0 < n; p0 += kPanel) {
+            const int np = min(kPanel, n - p0);
+            const int par = (p0 >> 6) & 1;
+            // ---- 1. the prefetched panel into LDS (the chain before is done with the tiles: barrier at the loop's end) --
+            if (wave == 0) {
+                s_ws[par * kPanel + lane] = w_cur.ws;
+                s_we[par * kPanel + lane] = w_cur.we;
+                s_base[par * kPanel + lane] = w_cur.base;
+                int cmin = w_cur.we > w_cur.ws ? w_cur.ws : n, cmax = w_cur.we > w_cur.ws ? w_cur.we : 0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    cmin = min(cmin, __shfl_xor(cmin, off));
+                    cmax = max(cmax, __shfl_xor(cmax, off));
+                }
+                if (lane == 0) { s_cmin[par] = cmin; s_cmax[par] = cmax; }
+            }
+            store_tile(t_d, w_cur, p0, tile_d, s_in_d);
+            if (p0 > 0) store_tile(t_o, w_prev, p0, tile_o, s_in_o);
+            const T c_mm = in_mm, c_sb = in_sb, c_sh = in_sh, c_ul = in_ul, c_eta = in_eta;
+            __syncthreads();
+            // ---- prefetch for the panel after this one (in flight during the chain) ----------------------------------
+            const TileWindow w_nn = load_window(p0 + 2 * kPanel);
+            load_tile(t_d, w_nxt, p0 + kPanel);
+            load_tile(t_o, w_cur, p0 + kPanel);
+            load_inputs(p0 + kPanel);
+
+            if (wave == 0) {
+                // ---- 2. the chain: lane l carries q of SNP p0 + l ---------------------------------------------------
+                T ql = qv[p0 + min(lane, np - 1)];
+                // the rows of the panel before onto these 64 columns first (e_step.hpp:421 for j in that panel)
+                for (int jj = 0; jj < kPanel; ++jj) {
+                    if (!((prev_applied >> jj) & 1ull)) continue;
+                    const T a = readlane_f64(prev_a, jj);
+                    const T v = __builtin_fma(static_cast<T>(tile_o[jj * kPanel + lane]), a, ql);
+                    ql = ((s_in_o[jj] >> lane) & 1ull) ? v : ql;
+                }
+                T o_mu = 0, o_gam = 0, o_eta = 0, o_ed = 0, o_a = 0;
+                unsigned long long applied = 0;
+                for (int jj = 0; jj < np; ++jj) {
+                    const T qj = readlane_f64(ql, jj);
+                    const T eta_old = readlane_f64(c_eta, jj);
+                    T mu, gam, d;
+                    MODEL::update(readlane_f64(c_mm, jj), readlane_f64(c_sb, jj), readlane_f64(c_sh, jj),
+                                  readlane_f64(c_ul, jj), eta_old, qj, tab, mu, gam, d);
+                    // (all lanes computed the same numbers from lane jj's inputs: wave-uniform)
+                    const bool skip = MODEL::kSkip && fabs(readlane_f64(d, 0)) < eps;          // e_step.hpp:410
+                    if (skip) continue;                                                       // :412 (o_ed stays 0)
+                    const T a = A.dq * d;
+                    const T r = static_cast<T>(tile_d[jj * kPanel + lane]);
+                    const bool inw = (s_in_d[jj] >> lane) & 1ull;
+                    const T v = __builtin_fma(r, a, ql);                                      // :421, in-panel columns
+                    ql = inw ? v : ql;
+                    if (lane == jj) {
+                        if (!A.low_memory) ql -= d;                                           // :427
+                        o_mu = mu; o_gam = gam; o_eta = eta_old + d; o_ed = d; o_a = a;       // :416-418, :431
+                    }
+                    applied |= 1ull << jj;
+                }
+                if (lane < np) {
+                    const int64_t j = s0 + p0 + lane;
+                    qv[p0 + lane] = ql;
+                    A.eta_diff[j] = o_ed;
+                    if ((applied >> lane) & 1ull) {
+                        A.var_mu[j] = o_mu;
+                        A.var_gamma[j] = o_gam;
+                        A.eta[j] = o_eta;
+                    }
+                }
+                s_a[par * kPanel + lane] = o_a;
+                if (lane == 0) {
+                    s_applied[par] = applied;
+                    my_skipped += (unsigned long long)(np - __popcll(applied));
+                }
+                prev_a = o_a;
+                prev_applied = applied;
+            } else if (p0 > 0) {
+                // ---- 3. meanwhile: the rows of the panel before onto the columns outside that panel and this one -------
+                rows_onto_columns(par ^ 1, p0 - kPanel, p0 + kPanel, tid - 64, kTileThreads - 64);
+            }
+            __syncthreads();
+            w_prev = w_cur;
+            w_cur = w_nxt;
+            w_nxt = w_nn;
+        }
+        // the rows of the last panel onto the columns outside it (a partial last panel has no skipped-row bits beyond np)
+        {
+            const int last = (n - 1) / kPanel * kPanel;
+            rows_onto_columns((last >> 6) & 1, last, last + kPanel, tid, kTileThreads);
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += kTileThreads) A.q[s0 + i] = qv[i];
+        __syncthreads();
+    }
+    if (tid == 0 && my_skipped) atomicAdd(A0.skipped, my_skipped);
+}
+
+// Second pass of the upper-triangular form, update_q_factor (e_step.hpp:331-337): q[j] += dq * dot(eta_diff[win(j)],
+// row(j)).  One wave per group of kTileGroupRows consecutive rows of a block, the lanes across the columns (coalesced):
+// a lane loads eta_diff of its columns ONCE for the rows of the group (int8 LD: the float64 eta_diff is 8 x the bytes
+// of the LD elements it multiplies -- per row it, not the LD, would be the traffic).  The groups of ALL blocks of the
+// list are dealt round-robin to the waves of the launch (`groups`: (index of the block in the list) << 32 | first row).
+// The dot is summed per lane and then across the lanes -- not in the reference's index order (see the header).
+constexpr int kTileGroupRows = 8;
+
+template <typename U, bool DENSE>
+__global__ __launch_bounds__(kTileThreads) void tile_f64_second_pass_kernel(EStepArgs<double> A0, const int64_t* __restrict__ groups,
+                                                                            int64_t n_groups) {
+    using T = double;
+    constexpr int CPT = DENSE ? tile_cpt<U>() : 4;
+    constexpr int R = kTileGroupRows;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kTileThreads + threadIdx.x) >> 6;
+    const int64_t n_waves = (int64_t)gridDim.x * kTileThreads / 64;
+    const int n_models = max(1, A0.n_active);
+    const U* __restrict__ ld = static_cast<const U*>(DENSE ? A0.ld_dense : A0.ld_rows);
+    for (int64_t item = wave; item < n_groups * n_models; item += n_waves) {
+        const int64_t g = groups[item % n_groups];
+        const BlockDesc bd = A0.blocks[(int)(g >> 32)];
+        const EStepArgs<T> A = select_model(A0, (int)(item / n_groups));
+        const int row0 = (int)(uint32_t)g;
+        const int nr = min(R, bd.size - row0);
+        const int64_t s0 = bd.start;
+        int ws[R], we[R];
+        int64_t base[R];
+        int cmin = bd.size, cmax = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int jj = row0 + min(k, nr - 1);
+            const int64_t j = s0 + jj;
+            ws[k] = A.lb[j] - (int)s0;
+            we[k] = k < nr ? ws[k] + A.rowlen[j] : ws[k];                          // (rows beyond the group: empty window)
+            base[k] = DENSE ? bd.ld_off + (int64_t)jj * bd.stride : A.rowstart[j] - ws[k];
+            if (we[k] > ws[k]) { cmin = min(cmin, ws[k]); cmax = max(cmax, we[k]); }
+        }
+        const T* __restrict__ ed = A.eta_diff + s0;
+        T s[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) s[k] = 0;
+        for (int cb = (cmin & ~(CPT - 1)) + CPT * lane; cb < cmax; cb += CPT * 64) {
+            T e[CPT];
+#pragma unroll
+            for (int x = 0; x < CPT; ++x) e[x] = cb + x < cmax ? ed[cb + x] : (T)0;
+            UVec<U, CPT> r[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (DENSE) {
+                    r[k] = *reinterpret_cast<const UVec<U, CPT>*>(ld + base[k] + cb);    // (rows are padded to 64)
+                } else {
+#pragma unroll
+                    for (int x = 0; x < CPT; ++x) {
+                        const int c = cb + x;
+                        r[k].v[x] = (c >= ws[k] && c < we[k]) ? ld[base[k] + c] : (U)0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+#pragma unroll
+                for (int x = 0; x < CPT; ++x) {
+                    const int c = cb + x;
+                    const T w = __builtin_fma(static_cast<T>(r[k].v[x]), e[x], s[k]);
+                    s[k] = (c >= ws[k] && c < we[k]) ? w : s[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+            if (lane == 0 && k < nr) A.q[s0 + row0 + k] += A.dq * s[k];
+        }
+    }
+}
+
+}  // namespace viprs

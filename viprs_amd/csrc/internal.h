@@ -106,6 +106,7 @@ struct viprs_plan {
     viprs::DevBuf<int32_t> d_lb;
     viprs::DevBuf<int64_t> d_ip;
     viprs::DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]
+    viprs::DevBuf<int64_t> d_rowlist_dense, d_rowlist_ragged;   // float64 second pass (estep_tile.h): (block of the list) << 32 | first row, per group of 8 rows
     viprs::DevBuf<int64_t> d_rowstart_dense;       // row starts inside the repacked dense buffer (generic kernels)
     viprs::DevBuf<char> d_ld_raw;                  // kept only when ragged blocks exist
     viprs::DevBuf<char> d_ld_dense;
@@ -179,6 +180,9 @@ enum { kBandSpikeSlab = 0, kBandGridColumn = 1, kBandMixture = 2 };
 
 // generic kernels over one block list: `dense` = the repacked dense blocks, otherwise the ragged blocks
 template <typename T, typename U> int launch_generic(viprs_plan* P, EStepArgs<T> A, int model, bool dense);
+// float64 state: the panel-walking kernels (estep_tile.h) over one block list; falls back to launch_generic for the
+// mixture and for blocks whose q does not fit the LDS
+template <typename U> int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense);
 // panel kernels of the three size classes on their own streams, joined into the plan's stream
 template <typename U> int launch_panel(viprs_plan* P, EStepArgs<float> A, int model);
 // band kernel for the windowed components
