@@ -1,5 +1,6 @@
-"""float_precision='float64' (VIPRS.py:72): the state is double, every block takes the row-by-row generic kernels
-(estep_generic.h).  Sweep time and SNP-updates/s on cfg2 / cfg3 through the device-resident state API.
+"""float_precision='float64' (VIPRS.py:72): the state is double, every block takes the panel-walking kernels of
+estep_tile.h (VIPRS_F64_ROW_BY_ROW=1: the row-by-row generic kernels).  Sweep time and SNP-updates/s on cfg2 / cfg3
+through the device-resident state API, next to the fp32 state on the same plan.
     python tools/fp64_bench.py [cfg2|cfg3] [int8|float32|float64] [upper|sym]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
