@@ -142,6 +142,11 @@ def main():
          dict(ld_kind="longrange", ld_dtype=np.int8)),
         ("fit_mix_k4_lr_int8_sym", VIPRSMix, {22: [380, 150, 330]}, dict(low_memory=False, K=4, dequantize_on_the_fly=True),
          dict(ld_kind="longrange", ld_dtype=np.int8)),
+        # float_precision='float64' (VIPRS.py:72): the double state end to end, both LD forms
+        ("fit_ss_f64_lr_int8_upper", VIPRS, {22: [420, 300, 180]},
+         dict(low_memory=True, dequantize_on_the_fly=True, float_precision="float64"), dict(ld_kind="longrange", ld_dtype=np.int8)),
+        ("fit_ss_f64_lr_int8_sym", VIPRS, {21: [260, 330], 22: [150, 200]},
+         dict(low_memory=False, dequantize_on_the_fly=True, float_precision="float64"), dict(ld_kind="longrange", ld_dtype=np.int8)),
     ]
     for name, cls, chrom_sizes, kw, ld_kw in cases:
         if ONLY and name not in ONLY:
@@ -157,6 +162,7 @@ def main():
         model.validation_std_beta = {c: inputs[c][2].validation_std_beta for c in chrom_sizes}
         out = dict(pseudo_r2=np.float64(model.pseudo_validate()),        # BayesPRSModel.py:397-410
                    ld_kind=ld_kind, dequantize_on_the_fly=bool(kw.get("dequantize_on_the_fly", False)),
+                   float_precision=str(kw.get("float_precision", "float32")),
                    theta0_pi=0.01, theta0_sigma_epsilon=0.8, n=gdl.n, low_memory=kw.get("low_memory", True),
                    K=kw.get("K", 0), theta0_pis=np.asarray(theta_0.get("pis", [])), fix_sigma_epsilon=kw.get("fix_params", {}).get("sigma_epsilon", np.nan),
                    chroms=np.array(sorted(chrom_sizes)),

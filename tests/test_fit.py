@@ -48,7 +48,8 @@ def build_model(fx, comm=None, e_step="oracle"):
     from viprs_amd.model import VIPRS, VIPRSMix
     K = int(fx["K"])
     kw = dict(low_memory=bool(fx["low_memory"]), comm=comm,
-              dequantize_on_the_fly=bool(fx["dequantize_on_the_fly"]) if "dequantize_on_the_fly" in fx else False)
+              dequantize_on_the_fly=bool(fx["dequantize_on_the_fly"]) if "dequantize_on_the_fly" in fx else False,
+              float_precision=str(fx["float_precision"]) if "float_precision" in fx else "float32")
     if not np.isnan(float(fx["fix_sigma_epsilon"])):
         kw["fix_params"] = {"sigma_epsilon": float(fx["fix_sigma_epsilon"])}
     if e_step == "oracle":
@@ -87,7 +88,7 @@ def check_against_fixture(model, fx, local_only=False, pi_rtol=2e-4):
 
 
 def test_fit_fixtures_present():
-    assert len(FIT) >= 7
+    assert len(FIT) >= 9
 
 
 @pytest.mark.parametrize("path", FIT, ids=[os.path.basename(p)[:-4] for p in FIT])
