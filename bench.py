@@ -266,21 +266,22 @@ class Sweep:
     """Device-resident plan + state of one workload (share) and the timed step.  `plan`: an existing plan of the same
     LD to put another model's state on (the LD is uploaded once)."""
 
-    def __init__(self, args, ld, ss, inp, device, model, width, low_memory, plan=None):
+    def __init__(self, args, ld, ss, inp, device, model, width, low_memory, plan=None, precision="float32"):
         from viprs_amd.plan import DeviceState, LDPlan
         from viprs_amd.utils import synthetic as syn
         self.ld = ld
         self.own_plan = plan is None
         self.plan = plan if plan is not None else \
             LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory, device=device, math_mode=args.math)
-        self.state = DeviceState(self.plan, "float32", model, width)
+        self.state = DeviceState(self.plan, precision, model, width)
         self.model, self.width = model, width
+        self.state_itemsize = np.dtype(precision).itemsize
         self.active = None
         self.host_extra = None
         self.pi0 = inp.pi
         if model == "spike_slab":
             for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
-                self.state.upload(name, getattr(inp, name))
+                self.state.upload(name, getattr(inp, name).astype(precision, copy=False))
         else:
             extra = syn.make_mixture_inputs(ss, width) if model == "mixture" else syn.make_grid_inputs(ss, width)
             self.pi0 = extra.pop("pi")
@@ -315,6 +316,8 @@ class Sweep:
         nnz = int(ld.ld_indptr[-1]) * (2 if ld.low_memory else 1)
         per_snp = {"spike_slab": STATE_BYTES_PER_SNP, "mixture": 12 + 4 + 4 * (3 * w + 1) + 8 * (2 * w + 3),
                    "grid": 12 + 4 + 36 * w}[self.model]
+        if self.model == "spike_slab" and self.state_itemsize != 4:          # 12 index bytes + 14 state / input words
+            per_snp = 12 + 14 * self.state_itemsize
         return ld.ld_data.dtype.itemsize * nnz + per_snp * ld.m
 
     def close(self):
@@ -450,6 +453,13 @@ def main():
                 ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, dt2)
                 sw_u = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True)
                 secondary.append(measure_secondary(nm, sw_u, half, barrier))
+                if dt2.itemsize == 1:
+                    # float_precision='float64' (VIPRS.py:72) on the same plan: the panel-walking kernels of estep_tile.h
+                    sw_d = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan, precision="float64")
+                    secondary.append(measure_secondary("float64 state (float_precision='float64'), upper-triangular int8 LD, spike-and-slab",
+                                                       sw_d, half, barrier))
+                    secondary[-1]["dtype"] = "f64"
+                    sw_d.close()
                 sw_u.close()
                 del ld_u, sw_u
         if strong:

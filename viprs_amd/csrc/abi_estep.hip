@@ -134,7 +134,9 @@ int run_spike_slab(viprs_state* S, double dq) {
     } else {
         // float64 state: the panel kernels specialise float; every block takes the panel-walking kernel of estep_tile.h
         EStepArgs<double> A = make_args<double>(S, dq);
+        if (!P->dense_h.empty()) HIP_TRY(hipEventRecord(ev[2], P->stream));
         rc = launch_tile_f64_u(P, A, kGenSpikeSlab, true);
+        if (rc == VIPRS_OK && !P->dense_h.empty()) HIP_TRY(hipEventRecord(ev[3], P->stream));
         if (rc == VIPRS_OK) rc = launch_tile_f64_u(P, A, kGenSpikeSlab, false);
     }
     if (rc != VIPRS_OK) return rc;
