@@ -48,6 +48,8 @@ def parse_args():
                     help="cfg3max = cfg3 with its largest block replaced by a 6 000-SNP one (BASELINE's clip limit)")
     ap.add_argument("--low-memory", action="store_true", help="upper-triangular LD (reference default)")
     ap.add_argument("--ld-dtype", default="float32", choices=["float32", "int8", "int16"])
+    ap.add_argument("--precision", default="float32", choices=["float32", "float64"],
+                    help="state type (the reference's float_precision, VIPRS.py:72); float64: spike_slab only, no CPU leg")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = ONE workload sharded by LD block (BASELINE's config); weak = one workload per rank")
@@ -401,6 +403,8 @@ def main():
     ld_dtype = np.dtype(args.ld_dtype)
     sizes_all = config_sizes(args.config, args.seed)
     width = args.width or {"spike_slab": 1, "mixture": 4, "grid": 32}[args.model]
+    if args.precision != "float32" and args.model != "spike_slab":
+        raise SystemExit("--precision float64 is measured for the spike-and-slab model only")
 
     # ---- primary measurement -----------------------------------------------------------------------------
     strong = world > 1 and args.scaling == "strong"
@@ -413,7 +417,7 @@ def main():
         seed = args.seed + 1000 * rank                 # weak: every rank its own genome-scale workload
         ld, ss, inp, _ = build_workload(args, sizes_all, None, seed, args.low_memory, ld_dtype)
         total_snps = float(comm.allreduce_sum(np.array([float(ld.m)]))[0])
-    sw = Sweep(args, ld, ss, inp, device, args.model, width, args.low_memory)
+    sw = Sweep(args, ld, ss, inp, device, args.model, width, args.low_memory, precision=args.precision)
     my_elapsed = sw.run(args.steps, args.warmup, barrier)
     elapsed = float(comm.allreduce_max(np.array([my_elapsed]))[0])
     skipped = sw.plan.last_skipped()
@@ -437,7 +441,7 @@ def main():
     # ---- secondary measurements -----------------------------------------------------------------------------
     secondary = []
     weak = None
-    if not args.no_secondary and args.model == "spike_slab":
+    if not args.no_secondary and args.model == "spike_slab" and args.precision == "float32":
         half = max(5, args.steps // 2)
         if world == 1 and not args.low_memory and args.ld_dtype == "float32" and args.config != "cfg1":
             # configs[3] / configs[4] on the LD plan that is already resident (symmetric fp32)
@@ -484,6 +488,8 @@ def main():
                 key = f"{args.config}_{args.ld_dtype}_{'upper' if args.low_memory else 'sym'}"
                 if args.model != "spike_slab":
                     key += f"_{args.model}{width}"
+                if args.precision != "float32":
+                    key += "_f64"
                 traffic = json.load(open(prof)).get(key)
                 traffic_src = ("profiles/pmc_traffic.json: (2 FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 "
                                "--pmc passes of this command (a constant of the kernel, not measured in this run)")
@@ -500,7 +506,7 @@ def main():
             # the series over N is ONE fixed workload sharded by LD block unless --scaling weak was asked for
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "float32" else "f64",
             "data": "synthetic",
             "config": {
                 "workload": {"cfg1": "configs[0]: single LD block, 500 SNPs",
@@ -554,7 +560,7 @@ def main():
             }
         if weak is not None:
             out["weak_scaling"] = weak
-        if n_gpus == 1 and args.cpu_seconds > 0:
+        if n_gpus == 1 and args.cpu_seconds > 0 and args.precision == "float32":
             out["cpu_baseline"] = cpu_baseline(ld, inp, args.cpu_seconds, args.model, width, sw.host_extra, sw.pi0,
                                                args.cpu_threads)
         print(json.dumps(out), flush=True)

@@ -21,7 +21,7 @@ def counters(d, name):
     f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == name and "viprs::estep" in r["Kernel_Name"]:
+        if r["Counter_Name"] == name and ("viprs::estep" in r["Kernel_Name"] or "viprs::tile_f64" in r["Kernel_Name"]):
             agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return agg
 

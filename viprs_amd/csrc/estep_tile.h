@@ -381,8 +381,8 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
 constexpr int kTileGroupRows = 8;
 
 template <typename U, bool DENSE>
-__global__ __launch_bounds__(kTileThreads) void tile_f64_second_pass_kernel(EStepArgs<double> A0, const int64_t* __restrict__ groups,
-                                                                            int64_t n_groups) {
+__global__ __launch_bounds__(kTileThreads, 3) void tile_f64_second_pass_kernel(EStepArgs<double> A0, const int64_t* __restrict__ groups,
+                                                                               int64_t n_groups) {
     using T = double;
     constexpr int CPT = DENSE ? tile_cpt<U>() : 4;
     constexpr int R = kTileGroupRows;
@@ -390,10 +390,16 @@ __global__ __launch_bounds__(kTileThreads) void tile_f64_second_pass_kernel(ESte
     const int64_t wave = ((int64_t)blockIdx.x * kTileThreads + threadIdx.x) >> 6;
     const int64_t n_waves = (int64_t)gridDim.x * kTileThreads / 64;
     const int n_models = max(1, A0.n_active);
+    const int64_t n_items = n_groups * n_models;
     const U* __restrict__ ld = static_cast<const U*>(DENSE ? A0.ld_dense : A0.ld_rows);
-    for (int64_t item = wave; item < n_groups * n_models; item += n_waves) {
-        const int64_t g = groups[item % n_groups];
-        const BlockDesc bd = A0.blocks[(int)(g >> 32)];
+    // a group costs one round trip to memory and about as much arithmetic: the group record two items ahead and the
+    // block descriptor one item ahead are already on their way
+    auto group_of = [&](int64_t item) { return item < n_items ? groups[item % n_groups] : (int64_t)0; };
+    int64_t g = group_of(wave), g_n = group_of(wave + n_waves);
+    BlockDesc bd = A0.blocks[(int)(g >> 32)];
+    for (int64_t item = wave; item < n_items; item += n_waves) {
+        const int64_t g_nn = group_of(item + 2 * n_waves);
+        const BlockDesc bd_n = A0.blocks[(int)(g_n >> 32)];
         const EStepArgs<T> A = select_model(A0, (int)(item / n_groups));
         const int row0 = (int)(uint32_t)g;
         const int nr = min(R, bd.size - row0);
@@ -405,8 +411,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_f64_second_pass_kernel(ESte
         for (int k = 0; k < R; ++k) {
             const int jj = row0 + min(k, nr - 1);
             const int64_t j = s0 + jj;
-            ws[k] = A.lb[j] - (int)s0;
-            we[k] = k < nr ? ws[k] + A.rowlen[j] : ws[k];                          // (rows beyond the group: empty window)
+            // dense blocks of the upper form: row jj holds columns jj + 1 .. size - 1 (no index loads)
+            ws[k] = DENSE ? jj + 1 : A.lb[j] - (int)s0;
+            we[k] = k < nr ? (DENSE ? bd.size : ws[k] + A.rowlen[j]) : ws[k];       // (rows beyond the group: empty window)
             base[k] = DENSE ? bd.ld_off + (int64_t)jj * bd.stride : A.rowstart[j] - ws[k];
             if (we[k] > ws[k]) { cmin = min(cmin, ws[k]); cmax = max(cmax, we[k]); }
         }
@@ -435,9 +442,16 @@ __global__ __launch_bounds__(kTileThreads) void tile_f64_second_pass_kernel(ESte
             for (int k = 0; k < R; ++k) {
 #pragma unroll
                 for (int x = 0; x < CPT; ++x) {
-                    const int c = cb + x;
-                    const T w = __builtin_fma(static_cast<T>(r[k].v[x]), e[x], s[k]);
-                    s[k] = (c >= ws[k] && c < we[k]) ? w : s[k];
+                    if (DENSE) {
+                        // no window test: the repacked block holds exact zeros on and left of the diagonal and in the
+                        // padding (abi_plan.hip: repack_dense_kernel on a zeroed buffer), e is 0 beyond the block, and
+                        // the rows of the group beyond the block are never stored
+                        s[k] = __builtin_fma(static_cast<T>(r[k].v[x]), e[x], s[k]);
+                    } else {
+                        const int c = cb + x;
+                        const T w = __builtin_fma(static_cast<T>(r[k].v[x]), e[x], s[k]);
+                        s[k] = (c >= ws[k] && c < we[k]) ? w : s[k];
+                    }
                 }
             }
         }
@@ -447,6 +461,9 @@ __global__ __launch_bounds__(kTileThreads) void tile_f64_second_pass_kernel(ESte
             for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
             if (lane == 0 && k < nr) A.q[s0 + row0 + k] += A.dq * s[k];
         }
+        g = g_n;
+        g_n = g_nn;
+        bd = bd_n;
     }
 }
 
