@@ -138,3 +138,44 @@ def test_float64_chain_sigmoid_against_an_80_bit_reference(gpu):
     assert float(err.max()) < 4 * np.finfo(T).eps, float(err.max())
     np.testing.assert_array_equal(got["eta_diff"][applied], got["var_gamma"][applied])
     assert np.all(got["var_mu"][applied] == 1.0) and np.all(got["q"] == 0)
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+def test_float64_cfg3_full_size(gpu, low_memory):
+    """BASELINE configs[2] (1.1 M SNPs, 1 700 blocks, int8 long-range LD) with a float64 state: the two block classes of
+    the launch (8-wave workgroups for the largest blocks beside 4-wave ones, two streams) leave a state that is
+    reproducible bit for bit from run to run, whose skip count agrees with it, and that equals the oracle run in double on
+    a sample of blocks from both classes (largest, smallest, around the class limit, the median)."""
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld, ss, inp = syn.make_problem("cfg3", low_memory=low_memory, ld_dtype=np.int8, kind="longrange", float_precision=T)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory)
+    state = DeviceState(plan, "float64", "spike_slab", 1)
+    for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+        state.upload(name, getattr(inp, name))
+    outs = []
+    for _ in range(2):
+        state.reset(inp.pi)
+        state.e_step(ld.dq_scale)
+        state.e_step(ld.dq_scale)                       # two sweeps: the second starts from a state with history
+        outs.append({k: state.download(k) for k in H.STATE})
+    H.assert_state_equal(outs[0], outs[1])
+    got = outs[0]
+    assert plan.last_skipped() == int((got["eta_diff"] == 0).sum())
+    sizes = np.diff(ld.block_start)
+    order = np.argsort(sizes)
+    limit = int(np.searchsorted(sizes[order], 1792))
+    sample = list(order[:2]) + list(order[-2:]) + list(order[limit - 2:limit + 2]) + [order[len(order) // 2]]
+    for bi in sample:
+        s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+        b = e - s
+        lo, hi = int(ld.ld_indptr[s]), int(ld.ld_indptr[e])
+        sub = syn.SyntheticLD(ld.ld_left_bound[s:e] - s, ld.ld_indptr[s:e + 1] - lo, ld.ld_data[lo:hi], np.array([0, b]),
+                              np.zeros(1), low_memory, ld.dq_scale)
+        st = {k: v[s:e].copy() for k, v in inp.state_copy().items()}
+        for _ in range(2):
+            O.cpp_e_step(sub.ld_left_bound, sub.ld_indptr, sub.ld_data, inp.std_beta[s:e].copy(), st["var_gamma"],
+                         st["var_mu"], st["eta"], st["q"], st["eta_diff"], inp.u_logs[s:e].copy(),
+                         inp.sqrt_half_var_tau[s:e].copy(), inp.mu_mult[s:e].copy(), ld.dq_scale, 1, low_memory)
+        assert_state_close_f64({k: got[k][s:e] for k in H.STATE}, st)
+    state.close()
+    plan.close()

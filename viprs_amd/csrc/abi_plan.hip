@@ -75,6 +75,9 @@ static hipError_t launch_expand(const void* up, const int64_t* ipu, const int32_
 viprs_plan::~viprs_plan() {
     delete scratch;
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

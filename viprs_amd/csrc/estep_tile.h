@@ -1,18 +1,19 @@
 // float64 state (float_precision='float64', VIPRS.py:72): the E-step walked in 64-SNP panels by one workgroup per LD
 // block -- the panel scheme of estep_panel.h in its plainest form (no teams, no hand-off), for the state type the panel
 // kernels do not specialise.  Per panel p:
-//   1. its 64 x 64 diagonal tile and the off-diagonal tile (rows of panel p - 1, columns of panel p) go into LDS;
+//   1. its 64 x 64 diagonal tile and the off-diagonal tile (rows of panel p - 1, columns of panel p) go into LDS, 0
+//      outside a row's window (fetched one panel ahead by waves 1 .. NW - 1);
 //   2. wave 0 applies the rows of panel p - 1 to its 64 columns (64 fma per lane), then runs the 64 sequential updates
 //      (e_step.hpp:401-431) with q of the panel in its lanes' registers -- the in-panel part of every row's axpy
-//      (e_step.hpp:421) is one fma per step -- and leaves a_j = dq * eta_diff_j in LDS;
-//   3. meanwhile waves 1..3 apply the rows of panel p - 1 to the columns outside panels p - 1 and p,
+//      (e_step.hpp:421) is one fma per step, the skip branch a select -- and leaves a_j = dq * eta_diff_j in LDS;
+//   3. meanwhile waves 1 .. NW - 1 apply the rows of panel p - 1 to the columns outside panels p - 1 and p,
 //      q[c] = fma(R[j,c], a_j, q[c]) for j in panel order: every q[c] sees its rows in the order the reference applies
 //      them (symmetric form: the same fma sequence per element).
 // The second pass of the upper-triangular form (update_q_factor, e_step.hpp:331-337) is its own launch over the rows of
-// all blocks, one wave per row with the lanes across the row's columns (coalesced); the dot is summed in lane-partial
-// order there, NOT in the reference's index order.  A float64 state is compared to the reference within 1e-10, never
-// bit for bit (the chain's exp is not glibc's, see below).  The row-by-row kernels of estep_generic.h remain for what
-// this file does not cover: the mixture with a float64 state, blocks whose q does not fit the LDS.
+// all blocks, one wave per group of 8 rows with the lanes across the columns (coalesced); the dot is summed in
+// lane-partial order there, NOT in the reference's index order.  A float64 state is compared to the reference within
+// 1e-10, never bit for bit (the chain's exp is not glibc's, see below).  The row-by-row kernels of estep_generic.h remain
+// for what this file does not cover: the mixture with a float64 state, blocks whose q does not fit the LDS.
 #pragma once
 #include "device_math.h"
 #include "estep_generic.h"
@@ -106,10 +107,10 @@ struct TileGridColumn {
 
 template <typename U, int N> struct alignas(sizeof(U) * N) UVec { U v[N]; };
 
-// LDS: q[qcap] (doubles) | diagonal tile [64][64] | off-diagonal tile [64][64] (LD elements) | per panel parity:
-// a[64] (doubles), rowbase[64] (int64), ws[64], we[64] (ints) | window masks of the two tiles [2][64] (uint64)
+// LDS: q[qcap] (doubles) | diagonal tile [64][64] | off-diagonal tile [64][64] (LD elements, 0 outside a row's window) |
+// per panel parity: a[64] (doubles), rowbase[64] (int64), ws[64], we[64] (ints)
 __host__ __device__ constexpr size_t tile_lds_bytes(int qcap, size_t ld_elem) {
-    return (size_t)qcap * 8 + 2 * kPanel * kPanel * ld_elem + 2 * (kPanel * 8 + kPanel * 8 + 2 * kPanel * 4) + 2 * kPanel * 8;
+    return (size_t)qcap * 8 + 2 * kPanel * kPanel * ld_elem + 2 * (kPanel * 8 + kPanel * 8 + 2 * kPanel * 4);
 }
 
 // window of one LD row, block-local columns [ws, we), and the element offset of (row, block column 0)
@@ -120,11 +121,24 @@ struct TileWindow { int ws, we; int64_t base; };
 // tile in LDS (64 fma per lane).  Everything a panel needs from global memory -- its inputs, its two tiles, the windows
 // of its rows (those two panels ahead: the tiles' addresses come from them) -- is fetched one panel ahead into
 // registers while the chain of the panel before runs.
-template <typename U, typename MODEL, bool DENSE>
-__global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<double> A0, int qcap) {
+#ifdef VIPRS_TILE_PROFILE
+#define TPROF(i) do { if (wave == 0 && lane == 0 && blockIdx.x == 0 && (p0 >> 6) < 24) s_tp[p0 >> 6][i] = wall_clock64(); } while (0)
+#else
+#define TPROF(i) do { } while (0)
+#endif
+
+template <typename U, typename MODEL, bool DENSE, int NW>
+__global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<double> A0, int qcap) {
     using T = double;
-    constexpr int kWaves = kTileThreads / 64;
-    constexpr int kRowsPerWave = kPanel / kWaves;              // rows of a tile a wave stages: w, w + 4, ...
+    constexpr int NT = NW * 64;                                // 1 chain wave + NW - 1 waves for the tiles and the row pass
+#ifdef VIPRS_TILE_PROFILE
+    __shared__ unsigned long long s_tp[24][8];
+#endif
+    // Waves 1 .. NW - 1 fetch and stage the tiles (rows w - 1, w - 1 + (NW - 1), ...): the chain wave issues no vector-memory
+    // instruction but the loads of its own 5 inputs per panel -- under the row pass's load its issue stalls for
+    // microseconds (measured: 16 tile-row loads 1.6 us in a quiet workgroup, 4 us next to a 3 648-column row pass).
+    constexpr int kWaves = NW;
+    constexpr int kRowsPerWave = (kPanel + kWaves - 2) / (kWaves - 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* const qv = reinterpret_cast<T*>(smem_raw);
     U* const tile_d = reinterpret_cast<U*>(qv + qcap);         // rows of panel p, columns of panel p
@@ -133,8 +147,6 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
     int64_t* const s_base = reinterpret_cast<int64_t*>(s_a + 2 * kPanel);  // [2][64]
     int* const s_ws = reinterpret_cast<int*>(s_base + 2 * kPanel);         // [2][64]
     int* const s_we = s_ws + 2 * kPanel;                                   // [2][64]
-    unsigned long long* const s_in_d = reinterpret_cast<unsigned long long*>(s_we + 2 * kPanel);   // window masks of tile_d's rows
-    unsigned long long* const s_in_o = s_in_d + kPanel;                                             // ... of tile_o's rows
     __shared__ int s_item;
     __shared__ int s_cmin[2], s_cmax[2];                                   // union of the panel's row windows
     __shared__ unsigned long long s_applied[2];                            // rows of the panel that were not skipped
@@ -161,17 +173,29 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
         const int64_t s0 = bd.start;
         const int n = bd.size;
 
+        // window of row `row` of a dense block: no index loads (symmetric form: the whole block; upper form: right of the
+        // diagonal; rows beyond the block: empty)
+        auto dense_row = [&](int row) {
+            TileWindow w;
+            w.ws = A.low_memory ? row + 1 : 0;
+            w.we = row < n ? n : w.ws;
+            w.base = bd.ld_off + (int64_t)row * bd.stride;
+            return w;
+        };
         auto load_window = [&](int p0) {                       // lane l: row p0 + l
+            if (DENSE) return dense_row(p0 + lane);
             TileWindow w{0, 0, 0};
             if (p0 + lane < n) {
                 const int64_t j = s0 + p0 + lane;
                 w.ws = A.lb[j] - (int)s0;
                 w.we = w.ws + A.rowlen[j];
-                w.base = DENSE ? bd.ld_off + (int64_t)(p0 + lane) * bd.stride : A.rowstart[j] - w.ws;
+                w.base = A.rowstart[j] - w.ws;
             }
             return w;
         };
-        auto row_window = [&](const TileWindow& w, int jj) {   // row jj's window out of the lanes' registers (jj uniform)
+        // window of row r0 + jj (jj uniform): arithmetic for dense blocks, out of the lanes' registers otherwise
+        auto row_window = [&](const TileWindow& w, int r0, int jj) {
+            if (DENSE) return dense_row(r0 + jj);
             TileWindow r;
             r.ws = __builtin_amdgcn_readlane(w.ws, jj);
             r.we = __builtin_amdgcn_readlane(w.we, jj);
@@ -180,24 +204,28 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
             r.base = ((int64_t)hi << 32) | (uint32_t)lo;
             return r;
         };
-        // a 64 x 64 tile: rows of the panel whose windows are `w`, columns c0 + lane; this wave's rows (w, w + 4, ...)
-        auto load_tile = [&](U (&t)[kRowsPerWave], const TileWindow& w, int c0) {
+        // a 64 x 64 tile: rows r0 .. r0 + 63 (windows `w`), columns c0 + lane; this wave's rows of it
+        // Entries outside a row's window are staged as 0: the chain applies every row to all its 64 lanes without a
+        // window test (fma(0, a, q) == q).
+        constexpr int n_stagers = kWaves - 1;
+        const int stager = wave - 1;                                   // -1: the chain wave sits out
+        auto load_tile = [&](U (&t)[kRowsPerWave], const TileWindow& w, int r0, int c0) {
+            if (stager < 0) return;
             const int c = c0 + lane;
 #pragma unroll
             for (int k = 0; k < kRowsPerWave; ++k) {
-                const TileWindow r = row_window(w, wave + kWaves * k);
+                const int jj = stager + n_stagers * k;
+                if (jj >= kPanel) break;
+                const TileWindow r = row_window(w, r0, jj);
                 t[k] = (c >= r.ws && c < r.we) ? ld[r.base + c] : (U)0;          // (rows beyond the block: ws == we)
             }
         };
-        auto store_tile = [&](const U (&t)[kRowsPerWave], const TileWindow& w, int c0, U* tile, unsigned long long* mask) {
-            const int c = c0 + lane;
+        auto store_tile = [&](const U (&t)[kRowsPerWave], U* tile) {
+            if (stager < 0) return;
 #pragma unroll
             for (int k = 0; k < kRowsPerWave; ++k) {
-                const int jj = wave + kWaves * k;
-                const TileWindow r = row_window(w, jj);
-                tile[jj * kPanel + lane] = t[k];
-                const unsigned long long m = __ballot(c >= r.ws && c < r.we);
-                if (lane == 0) mask[jj] = m;
+                const int jj = stager + n_stagers * k;
+                if (jj < kPanel) tile[jj * kPanel + lane] = t[k];
             }
         };
         T in_mm = 0, in_sb = 0, in_sh = 0, in_ul = 0, in_eta = 0;
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
         // windowed rows: element loads and tests.
         auto rows_onto_columns = [&](int par, int x0, int x1, int u, int nu) {
             constexpr int CPT = 4;
-            constexpr int RIF = DENSE ? (sizeof(U) <= 2 ? 32 : 64 / (int)sizeof(U)) : 8;
+            constexpr int RIF = DENSE ? 64 / (int)sizeof(U) : 8;        // 64 VGPRs of row data in flight per lane
             const unsigned long long applied = s_applied[par];
             if (applied == 0) return;
             const T* const pa = s_a + par * kPanel;
@@ -221,119 +249,158 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
             const int* const pws = s_ws + par * kPanel;
             const int* const pwe = s_we + par * kPanel;
             const int cmin = s_cmin[par] & ~(CPT - 1), cmax = s_cmax[par];
-            for (int cb = cmin + CPT * u; cb < cmax; cb += CPT * nu) {
-                if (cb >= x0 && cb < x1) continue;                               // (panels start at multiples of 64)
-                T v[CPT];
+            if constexpr (DENSE) {
+                for (int cb = cmin + CPT * u; cb < cmax; cb += CPT * nu) {
+                    if (cb >= x0 && cb < x1) continue;                           // (panels start at multiples of 64)
+                    T v[CPT];
 #pragma unroll
-                for (int x = 0; x < CPT; ++x) v[x] = cb + x < n ? qv[cb + x] : (T)0;
-                for (int j0 = 0; j0 < kPanel; j0 += RIF) {
-                    UVec<U, CPT> r[RIF];
+                    for (int x = 0; x < CPT; ++x) v[x] = cb + x < n ? qv[cb + x] : (T)0;
+                    for (int j0 = 0; j0 < kPanel; j0 += RIF) {
+                        UVec<U, CPT> r[RIF];
 #pragma unroll
-                    for (int k = 0; k < RIF; ++k) {
-                        const int jj = j0 + k;
-                        if (DENSE) {
-                            r[k] = *reinterpret_cast<const UVec<U, CPT>*>(ld + pbase[jj] + cb);   // (rows are padded to 64)
-                        } else {
+                        for (int k = 0; k < RIF; ++k) r[k] = *reinterpret_cast<const UVec<U, CPT>*>(ld + pbase[j0 + k] + cb);   // (rows are padded to 64)
 #pragma unroll
-                            for (int x = 0; x < CPT; ++x) {
-                                const int c = cb + x;
-                                r[k].v[x] = (c >= pws[jj] && c < pwe[jj]) ? ld[pbase[jj] + c] : (U)0;
-                            }
+                        for (int k = 0; k < RIF; ++k) {
+                            if (!((applied >> (j0 + k)) & 1ull)) continue;
+                            const T a = pa[j0 + k];
+#pragma unroll
+                            for (int x = 0; x < CPT; ++x) v[x] = __builtin_fma(static_cast<T>(r[k].v[x]), a, v[x]);
                         }
                     }
 #pragma unroll
-                    for (int k = 0; k < RIF; ++k) {
-                        const int jj = j0 + k;
-                        if (!((applied >> jj) & 1ull)) continue;
-                        const T a = pa[jj];
-                        if (DENSE) {
+                    for (int x = 0; x < CPT; ++x)
+                        if (cb + x < n) qv[cb + x] = v[x];
+                }
+            } else {
+                for (int cb = cmin + CPT * u; cb < cmax; cb += CPT * nu) {
+                    if (cb >= x0 && cb < x1) continue;                           // (panels start at multiples of 64)
+                    T v[CPT];
 #pragma unroll
-                            for (int x = 0; x < CPT; ++x) v[x] = __builtin_fma(static_cast<T>(r[k].v[x]), a, v[x]);
-                        } else {
+                    for (int x = 0; x < CPT; ++x) v[x] = cb + x < n ? qv[cb + x] : (T)0;
+                    for (int j0 = 0; j0 < kPanel; j0 += RIF) {
+                        U r[RIF][CPT];
+#pragma unroll
+                        for (int k = 0; k < RIF; ++k) {
+#pragma unroll
+                            for (int x = 0; x < CPT; ++x) {
+                                const int c = cb + x;
+                                r[k][x] = (c >= pws[j0 + k] && c < pwe[j0 + k]) ? ld[pbase[j0 + k] + c] : (U)0;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < RIF; ++k) {
+                            const int jj = j0 + k;
+                            if (!((applied >> jj) & 1ull)) continue;
+                            const T a = pa[jj];
                             const int ws = pws[jj], we = pwe[jj];
 #pragma unroll
                             for (int x = 0; x < CPT; ++x) {
                                 const int c = cb + x;
-                                const T w = __builtin_fma(static_cast<T>(r[k].v[x]), a, v[x]);
+                                const T w = __builtin_fma(static_cast<T>(r[k][x]), a, v[x]);
                                 v[x] = (c >= ws && c < we) ? w : v[x];
                             }
                         }
                     }
-                }
 #pragma unroll
-                for (int x = 0; x < CPT; ++x)
-                    if (cb + x < n) qv[cb + x] = v[x];
+                    for (int x = 0; x < CPT; ++x)
+                        if (cb + x < n) qv[cb + x] = v[x];
+                }
             }
         };
 
-        for (int i = tid; i < n; i += kTileThreads) qv[i] = A.q[s0 + i];
+        for (int i = tid; i < n; i += NT) qv[i] = A.q[s0 + i];
         TileWindow w_prev{0, 0, 0}, w_cur = load_window(0), w_nxt = load_window(kPanel);
         U t_d[kRowsPerWave], t_o[kRowsPerWave];
-        load_tile(t_d, w_cur, 0);
+        load_tile(t_d, w_cur, 0, 0);
 #pragma unroll
         for (int k = 0; k < kRowsPerWave; ++k) t_o[k] = (U)0;
         load_inputs(0);
-        T prev_a = 0;                                          // wave 0, lane jj: a_jj of the panel before
-        unsigned long long prev_applied = 0;
+        T prev_a = 0;                                          // wave 0, lane jj: a_jj of the panel before (0: skipped)
 
         for (int p0 = 0; p0 < n; p0 += kPanel) {
             const int np = min(kPanel, n - p0);
             const int par = (p0 >> 6) & 1;
+            TPROF(0);
             // ---- 1. the prefetched panel into LDS (the chain before is done with the tiles: barrier at the loop's end) --
             if (wave == 0) {
                 s_ws[par * kPanel + lane] = w_cur.ws;
                 s_we[par * kPanel + lane] = w_cur.we;
                 s_base[par * kPanel + lane] = w_cur.base;
-                int cmin = w_cur.we > w_cur.ws ? w_cur.ws : n, cmax = w_cur.we > w_cur.ws ? w_cur.we : 0;
+                int cmin, cmax;
+                if (DENSE) {
+                    cmin = A.low_memory ? p0 + 1 : 0;
+                    cmax = n;
+                } else {
+                    cmin = w_cur.we > w_cur.ws ? w_cur.ws : n;
+                    cmax = w_cur.we > w_cur.ws ? w_cur.we : 0;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    cmin = min(cmin, __shfl_xor(cmin, off));
-                    cmax = max(cmax, __shfl_xor(cmax, off));
+                    for (int off = 32; off > 0; off >>= 1) {
+                        cmin = min(cmin, __shfl_xor(cmin, off));
+                        cmax = max(cmax, __shfl_xor(cmax, off));
+                    }
                 }
                 if (lane == 0) { s_cmin[par] = cmin; s_cmax[par] = cmax; }
             }
-            store_tile(t_d, w_cur, p0, tile_d, s_in_d);
-            if (p0 > 0) store_tile(t_o, w_prev, p0, tile_o, s_in_o);
+            store_tile(t_d, tile_d);
+            if (p0 > 0) store_tile(t_o, tile_o);
             const T c_mm = in_mm, c_sb = in_sb, c_sh = in_sh, c_ul = in_ul, c_eta = in_eta;
+            TPROF(1);
             __syncthreads();
+            TPROF(2);
             // ---- prefetch for the panel after this one (in flight during the chain) ----------------------------------
             const TileWindow w_nn = load_window(p0 + 2 * kPanel);
-            load_tile(t_d, w_nxt, p0 + kPanel);
-            load_tile(t_o, w_cur, p0 + kPanel);
+            load_tile(t_d, w_nxt, p0 + kPanel, p0 + kPanel);
+            load_tile(t_o, w_cur, p0, p0 + kPanel);
             load_inputs(p0 + kPanel);
+            TPROF(3);
 
             if (wave == 0) {
                 // ---- 2. the chain: lane l carries q of SNP p0 + l ---------------------------------------------------
                 T ql = qv[p0 + min(lane, np - 1)];
-                // the rows of the panel before onto these 64 columns first (e_step.hpp:421 for j in that panel)
-                for (int jj = 0; jj < kPanel; ++jj) {
-                    if (!((prev_applied >> jj) & 1ull)) continue;
-                    const T a = readlane_f64(prev_a, jj);
-                    const T v = __builtin_fma(static_cast<T>(tile_o[jj * kPanel + lane]), a, ql);
-                    ql = ((s_in_o[jj] >> lane) & 1ull) ? v : ql;
+                // the rows of the panel before onto these 64 columns first (e_step.hpp:421 for j in that panel; a skipped
+                // row carries a = 0: fma(r, 0, q) == q); 8 rows' LDS reads in flight at a time
+                if (p0 > 0) {
+                    for (int j0 = 0; j0 < kPanel; j0 += 8) {
+                        T rr[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) rr[k] = static_cast<T>(tile_o[(j0 + k) * kPanel + lane]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ql = __builtin_fma(rr[k], readlane_f64(prev_a, j0 + k), ql);
+                    }
                 }
+                TPROF(4);
                 T o_mu = 0, o_gam = 0, o_eta = 0, o_ed = 0, o_a = 0;
-                unsigned long long applied = 0;
+                unsigned long long applied_v = 0;              // (the same value in every lane)
+                // The step has no branch and no memory operation between q_j and the new q: the tile row of step jj + 1 is
+                // read from LDS while step jj computes, the skip branch (e_step.hpp:410-413) is a select -- a skipped SNP
+                // applies a = 0 (fma(r, 0, q) == q) and keeps its outputs.
+                T r_nxt = static_cast<T>(tile_d[lane]);
                 for (int jj = 0; jj < np; ++jj) {
+                    const T r = r_nxt;
+                    r_nxt = static_cast<T>(tile_d[min(jj + 1, kPanel - 1) * kPanel + lane]);
                     const T qj = readlane_f64(ql, jj);
                     const T eta_old = readlane_f64(c_eta, jj);
                     T mu, gam, d;
                     MODEL::update(readlane_f64(c_mm, jj), readlane_f64(c_sb, jj), readlane_f64(c_sh, jj),
                                   readlane_f64(c_ul, jj), eta_old, qj, tab, mu, gam, d);
                     // (all lanes computed the same numbers from lane jj's inputs: wave-uniform)
-                    const bool skip = MODEL::kSkip && fabs(readlane_f64(d, 0)) < eps;          // e_step.hpp:410
-                    if (skip) continue;                                                       // :412 (o_ed stays 0)
-                    const T a = A.dq * d;
-                    const T r = static_cast<T>(tile_d[jj * kPanel + lane]);
-                    const bool inw = (s_in_d[jj] >> lane) & 1ull;
+                    const bool skip = MODEL::kSkip && fabs(d) < eps;                          // e_step.hpp:410
+                    const T de = skip ? (T)0 : d;                                             // :412
+                    const T a = A.dq * de;
                     const T v = __builtin_fma(r, a, ql);                                      // :421, in-panel columns
-                    ql = inw ? v : ql;
-                    if (lane == jj) {
-                        if (!A.low_memory) ql -= d;                                           // :427
-                        o_mu = mu; o_gam = gam; o_eta = eta_old + d; o_ed = d; o_a = a;       // :416-418, :431
-                    }
-                    applied |= 1ull << jj;
+                    const bool own = lane == jj;
+                    ql = (own && !A.low_memory) ? v - de : v;                                 // :427
+                    const bool take = own && !skip;                                           // :416-418, :431
+                    o_mu = take ? mu : o_mu;
+                    o_gam = take ? gam : o_gam;
+                    o_eta = take ? eta_old + d : o_eta;
+                    o_ed = take ? d : o_ed;
+                    o_a = take ? a : o_a;
+                    applied_v |= skip ? 0ull : (1ull << jj);
                 }
+                TPROF(5);
+                const unsigned long long applied = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(applied_v >> 32)) << 32) |
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)applied_v);
                 if (lane < np) {
                     const int64_t j = s0 + p0 + lane;
                     qv[p0 + lane] = ql;
@@ -350,23 +417,34 @@ __global__ __launch_bounds__(kTileThreads) void estep_tile_f64_kernel(EStepArgs<
                     my_skipped += (unsigned long long)(np - __popcll(applied));
                 }
                 prev_a = o_a;
-                prev_applied = applied;
+                TPROF(6);
             } else if (p0 > 0) {
                 // ---- 3. meanwhile: the rows of the panel before onto the columns outside that panel and this one -------
-                rows_onto_columns(par ^ 1, p0 - kPanel, p0 + kPanel, tid - 64, kTileThreads - 64);
+                rows_onto_columns(par ^ 1, p0 - kPanel, p0 + kPanel, tid - 64, NT - 64);
             }
             __syncthreads();
+            TPROF(7);
             w_prev = w_cur;
             w_cur = w_nxt;
             w_nxt = w_nn;
         }
+#ifdef VIPRS_TILE_PROFILE
+        if (tid == 0 && blockIdx.x == 0 && n >= 640) {
+            for (int p = 0; p < min(24, (n + 63) / 64); ++p) {
+                const unsigned long long t = s_tp[p][0];
+                printf("panel %2d @%7llu: staged %4d barrier %4d prefetch-issued %4d priority %4d chain %5d stores %5d end %5d (x10ns)\n", p,
+                       t - s_tp[0][0], (int)(s_tp[p][1] - t), (int)(s_tp[p][2] - t), (int)(s_tp[p][3] - t), (int)(s_tp[p][4] - t),
+                       (int)(s_tp[p][5] - t), (int)(s_tp[p][6] - t), (int)(s_tp[p][7] - t));
+            }
+        }
+#endif
         // the rows of the last panel onto the columns outside it (a partial last panel has no skipped-row bits beyond np)
         {
             const int last = (n - 1) / kPanel * kPanel;
-            rows_onto_columns((last >> 6) & 1, last, last + kPanel, tid, kTileThreads);
+            rows_onto_columns((last >> 6) & 1, last, last + kPanel, tid, NT);
         }
         __syncthreads();
-        for (int i = tid; i < n; i += kTileThreads) A.q[s0 + i] = qv[i];
+        for (int i = tid; i < n; i += NT) A.q[s0 + i] = qv[i];
         __syncthreads();
     }
     if (tid == 0 && my_skipped) atomicAdd(A0.skipped, my_skipped);

@@ -83,6 +83,8 @@ struct viprs_plan {
     int n_cu = 0;
     int math_mode = VIPRS_MATH_EXACT;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;             // float64 state: the big-block class of estep_tile.h runs beside the rest
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<viprs::Block> blocks;              // SNP order
     std::vector<viprs::BlockDesc> dense_h, ragged_h;  // schedule order (descending cost)
     // dense blocks are served by panel kernels of three workgroup sizes (more updater waves =

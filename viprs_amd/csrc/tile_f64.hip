@@ -5,34 +5,84 @@
 
 namespace viprs {
 
+// One launch of the panel-walking kernel over blocks [first, first + count) of a list, NW waves per workgroup.
+template <typename U, int NW>
+static int launch_tile_class(viprs_plan* P, EStepArgs<double> A, int model, bool dense, const BlockDesc* d_blocks, int count,
+                             int max_b, int32_t* counter, hipStream_t stream, int cus) {
+    if (count == 0) return VIPRS_OK;
+    const int qcap = (max_b + 3) / 4 * 4;
+    const size_t shmem = tile_lds_bytes(qcap, sizeof(U));
+    A.blocks = d_blocks;
+    A.n_blocks = count;
+    A.counter = counter;
+    const void* kfn = nullptr;
+    if (model == kGenGrid) kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileGridColumn, true, NW>
+                                       : (const void*)estep_tile_f64_kernel<U, TileGridColumn, false, NW>;
+    else kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileSpikeSlab, true, NW>
+                     : (const void*)estep_tile_f64_kernel<U, TileSpikeSlab, false, NW>;
+    if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, NW * 64, shmem));
+    per_cu = std::max(1, per_cu);
+    const int64_t n_items = (int64_t)count * std::max(1, A.n_active);
+    const int grid = (int)std::min<int64_t>(n_items, (int64_t)cus * per_cu);      // persistent workgroups on `cus` CUs
+    int qc = qcap;
+    void* params[] = {(void*)&A, (void*)&qc};
+    HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(NW * 64), params, shmem, stream));
+    return VIPRS_OK;
+}
+
+// Blocks at least this large take 8-wave workgroups (1 chain + 7 waves for the row pass): with 3 row-pass waves the
+// conversion + fma of 64 x n LD elements per panel outlasts the chain's 64 steps from ~1 800 columns on
+// (tools/fp64_block_bench.py).  The two classes run side by side on two streams.
+constexpr int kTileBigBlock = 1792;
+
 template <typename U>
 int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
     const std::vector<BlockDesc>& list = dense ? P->dense_h : P->ragged_h;
     if (list.empty()) return VIPRS_OK;
     const int max_b = dense ? P->max_dense : P->max_ragged;
-    const int qcap = (max_b + 3) / 4 * 4;
-    const size_t shmem = tile_lds_bytes(qcap, sizeof(U));
     // q of a block lives in LDS; blocks beyond that (and the mixture) keep the row-by-row kernels
-    if (shmem > 150 * 1024 || model == kGenMixture) return launch_generic<double, U>(P, A, model, dense);
-    A.blocks = dense ? P->d_dense.p : P->d_ragged.p;
-    A.n_blocks = (int)list.size();
-    A.counter = P->d_counters.p + (dense ? 2 : 1);
-    const void* kfn = nullptr;
-    if (model == kGenGrid) kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileGridColumn, true>
-                                       : (const void*)estep_tile_f64_kernel<U, TileGridColumn, false>;
-    else kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileSpikeSlab, true>
-                     : (const void*)estep_tile_f64_kernel<U, TileSpikeSlab, false>;
-    if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kTileThreads, shmem));
-    per_cu = std::max(1, per_cu);
-    const int64_t n_items = (int64_t)A.n_blocks * std::max(1, A.n_active);
-    const int grid = (int)std::min<int64_t>(n_items, (int64_t)P->n_cu * per_cu);
-    int qc = qcap;
-    void* params[] = {(void*)&A, (void*)&qc};
-    HIP_TRY(hipLaunchKernel(kfn, dim3(grid), dim3(kTileThreads), params, shmem, P->stream));
+    if (tile_lds_bytes((max_b + 3) / 4 * 4, sizeof(U)) > 150 * 1024 || model == kGenMixture)
+        return launch_generic<double, U>(P, A, model, dense);
+    const BlockDesc* d_blocks = dense ? P->d_dense.p : P->d_ragged.p;
+    // the lists are in descending order of size: the big class is a prefix
+    int n_big = 0;
+    while (n_big < (int)list.size() && list[(size_t)n_big].size >= kTileBigBlock) ++n_big;
+    const int n_small = (int)list.size() - n_big;
+    int32_t* counter = P->d_counters.p + (dense ? 2 : 1);
+    if (n_big > 0 && n_small > 0) {
+        if (!P->side_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&P->side_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(P->ev_fork, P->stream));
+        HIP_TRY(hipStreamWaitEvent(P->side_stream, P->ev_fork, 0));
+        // an 8-wave workgroup fills a CU; the persistent workgroups of the other class leave those CUs alone (they would
+        // not drain before their queue is empty)
+        const int64_t big_items = (int64_t)n_big * std::max(1, A.n_active);
+        const int big_cus = (int)std::min<int64_t>(big_items, P->n_cu / 2);
+        // the big class goes FIRST and on the plan's own stream (it starts the moment the work before it ends; the other
+        // class has to come through the fork event and finds those CUs taken)
+        int rc = launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, P->d_counters.p + (dense ? 20 : 21), P->stream, big_cus);
+        if (rc != VIPRS_OK) return rc;
+        rc = launch_tile_class<U, 4>(P, A, model, dense, d_blocks + n_big, n_small, list[(size_t)n_big].size, counter, P->side_stream,
+                                     P->n_cu - big_cus);
+        if (rc != VIPRS_OK) return rc;
+        HIP_TRY(hipEventRecord(P->ev_join, P->side_stream));
+        HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join, 0));
+    } else if (n_big > 0) {
+        int rc = launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, counter, P->stream, P->n_cu);
+        if (rc != VIPRS_OK) return rc;
+    } else {
+        int rc = launch_tile_class<U, 4>(P, A, model, dense, d_blocks, n_small, max_b, counter, P->stream, P->n_cu);
+        if (rc != VIPRS_OK) return rc;
+    }
     if (P->low_memory) {
         // second pass: the rows of all blocks of the list over the whole device
+        A.blocks = d_blocks;
+        A.n_blocks = (int)list.size();
         DevBuf<int64_t>& rows = dense ? P->d_rowlist_dense : P->d_rowlist_ragged;      // groups of kTileGroupRows rows
         if (rows.n == 0) {
             std::vector<int64_t> h;
