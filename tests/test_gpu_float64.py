@@ -179,3 +179,21 @@ def test_float64_cfg3_full_size(gpu, low_memory):
         assert_state_close_f64({k: got[k][s:e] for k in H.STATE}, st)
     state.close()
     plan.close()
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+@pytest.mark.parametrize("K", [1, 3, 4, 6])         # <= 4: the panel-walking kernel (estep_tile.h); 6: row by row
+def test_float64_mixture_matches_oracle(gpu, K, low_memory):
+    from tests.test_gpu_models import _run_mix
+    from tests.test_oracle_vs_ref import _mixture_inputs
+    from viprs_amd.vi import e_step_hip as S
+    ld, ss, inp = syn.make_problem(sizes=[70, 1400, 333, 2000], low_memory=low_memory, ld_dtype=np.int8, seed=31,
+                                   kind="longrange", float_precision=T)
+    mix, st0 = _mixture_inputs(ld, ss, K, T=T)
+    ref = _run_mix(O, ld, inp, mix, st0, 2)
+    got = _run_mix(S, ld, inp, mix, st0, 2)
+    assert got["var_gamma"].dtype == np.float64 and got["var_gamma"].shape == (ld.m, K)
+    for k in H.STATE:
+        assert_close_f64(got[k], ref[k], k)
+    cut = _run_mix(O, H.cut_far_field(ld), inp, mix, st0, 2)
+    assert np.max(np.abs(cut["q"] - ref["q"])) > 1e-4 * np.max(np.abs(ref["q"]))

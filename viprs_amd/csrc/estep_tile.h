@@ -12,8 +12,9 @@
 // The second pass of the upper-triangular form (update_q_factor, e_step.hpp:331-337) is its own launch over the rows of
 // all blocks, one wave per group of 8 rows with the lanes across the columns (coalesced); the dot is summed in
 // lane-partial order there, NOT in the reference's index order.  A float64 state is compared to the reference within
-// 1e-10, never bit for bit (the chain's exp is not glibc's, see below).  The row-by-row kernels of estep_generic.h remain
-// for what this file does not cover: the mixture with a float64 state, blocks whose q does not fit the LDS.
+// 1e-10, never bit for bit (the chain's exp is not glibc's, see below).  Models: spike-and-slab, the columns of a grid, the
+// sparse mixture with up to 4 components.  The row-by-row kernels of estep_generic.h remain for what this file does not
+// cover: mixtures of more than 4 components with a float64 state, blocks whose q does not fit the LDS.
 #pragma once
 #include "device_math.h"
 #include "estep_generic.h"
@@ -83,8 +84,11 @@ __device__ __forceinline__ double sigmoid_f64_uniform(double x, const ExpTab64& 
 }
 
 // spike-and-slab (e_step.hpp:401-413) / one model of the grid (e_step.hpp:613-620: no skip branch, half_var_tau, no fma)
+constexpr int kTileMixK = 4;       // sparse mixture on this kernel: up to 4 components (more: estep_generic.h)
+
 struct TileSpikeSlab {
     static constexpr bool kSkip = true;
+    static constexpr bool kMixture = false;
     __device__ static __forceinline__ void update(double mm, double beta, double s, double ulog, double eta_old, double qj,
                                                   const ExpTab64& tab, double& mu, double& gamma, double& d) {
         const double p = mm * qj;
@@ -96,6 +100,7 @@ struct TileSpikeSlab {
 };
 struct TileGridColumn {
     static constexpr bool kSkip = false;
+    static constexpr bool kMixture = false;
     __device__ static __forceinline__ void update(double mm, double beta, double hvt, double ulog, double eta_old, double qj,
                                                   const ExpTab64& tab, double& mu, double& gamma, double& d) {
         mu = mm * (beta - qj);
@@ -103,6 +108,14 @@ struct TileGridColumn {
         gamma = sigmoid_f64_uniform(uj, tab);
         d = gamma * mu - eta_old;
     }
+};
+
+// e_step_mixture (e_step.hpp:447-551) with K <= kTileMixK components: the chain wave evaluates the K components of the
+// step's SNP as wave-uniform scalars (every lane the same numbers -- no cross-lane reduction; the K exponentials and the
+// K divides are independent of each other and overlap), lane l keeps the K inputs / outputs of SNP l of the panel.
+struct TileMixture {
+    static constexpr bool kSkip = false;
+    static constexpr bool kMixture = true;
 };
 
 template <typename U, int N> struct alignas(sizeof(U) * N) UVec { U v[N]; };
@@ -228,11 +241,24 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                 if (jj < kPanel) tile[jj * kPanel + lane] = t[k];
             }
         };
-        T in_mm = 0, in_sb = 0, in_sh = 0, in_ul = 0, in_eta = 0;
+        constexpr int KM = MODEL::kMixture ? kTileMixK : 1;    // per-SNP input slots (mixture: one per component)
+        const int K = MODEL::kMixture ? A.width : 1;
+        T in_mm[KM], in_sh[KM], in_ul[KM], in_sb = 0, in_eta = 0, in_lnp = 0;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) in_mm[k] = in_sh[k] = in_ul[k] = 0;
         auto load_inputs = [&](int p0) {
             if (wave == 0 && p0 < n) {
                 const int64_t jl = s0 + min(p0 + lane, n - 1);
-                in_mm = A.mu_mult[jl]; in_sb = A.std_beta[jl]; in_sh = A.shvt[jl]; in_ul = A.u_logs[jl]; in_eta = A.eta[jl];
+                if constexpr (MODEL::kMixture) {
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        if (k < K) { in_mm[k] = A.mu_mult[jl * K + k]; in_sh[k] = A.shvt[jl * K + k]; in_ul[k] = A.u_logs[jl * K + k]; }
+                    }
+                    in_lnp = A.log_null_pi[jl];
+                } else {
+                    in_mm[0] = A.mu_mult[jl]; in_sh[0] = A.shvt[jl]; in_ul[0] = A.u_logs[jl];
+                }
+                in_sb = A.std_beta[jl]; in_eta = A.eta[jl];
             }
         };
         // rows of the panel at r0 (parity `par`) onto the columns outside [x0, x1), by threads u of nu: a thread owns 4
@@ -343,7 +369,10 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
             }
             store_tile(t_d, tile_d);
             if (p0 > 0) store_tile(t_o, tile_o);
-            const T c_mm = in_mm, c_sb = in_sb, c_sh = in_sh, c_ul = in_ul, c_eta = in_eta;
+            T c_mm[KM], c_sh[KM], c_ul[KM];
+#pragma unroll
+            for (int k = 0; k < KM; ++k) { c_mm[k] = in_mm[k]; c_sh[k] = in_sh[k]; c_ul[k] = in_ul[k]; }
+            const T c_sb = in_sb, c_eta = in_eta, c_lnp = in_lnp;
             TPROF(1);
             __syncthreads();
             TPROF(2);
@@ -369,7 +398,9 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                     }
                 }
                 TPROF(4);
-                T o_mu = 0, o_gam = 0, o_eta = 0, o_ed = 0, o_a = 0;
+                T o_mu[KM], o_gam[KM], o_eta = 0, o_ed = 0, o_a = 0;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) o_mu[k] = o_gam[k] = 0;
                 unsigned long long applied_v = 0;              // (the same value in every lane)
                 // The step has no branch and no memory operation between q_j and the new q: the tile row of step jj + 1 is
                 // read from LDS while step jj computes, the skip branch (e_step.hpp:410-413) is a select -- a skipped SNP
@@ -380,10 +411,41 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                     r_nxt = static_cast<T>(tile_d[min(jj + 1, kPanel - 1) * kPanel + lane]);
                     const T qj = readlane_f64(ql, jj);
                     const T eta_old = readlane_f64(c_eta, jj);
-                    T mu, gam, d;
-                    MODEL::update(readlane_f64(c_mm, jj), readlane_f64(c_sb, jj), readlane_f64(c_sh, jj),
-                                  readlane_f64(c_ul, jj), eta_old, qj, tab, mu, gam, d);
-                    // (all lanes computed the same numbers from lane jj's inputs: wave-uniform)
+                    T mu[KM], gam[KM], d;
+                    // (all lanes compute the same numbers from lane jj's inputs: wave-uniform)
+                    if constexpr (MODEL::kMixture) {
+                        const T rq = readlane_f64(c_sb, jj) - qj;                             // e_step.hpp:505
+                        const T lnp = readlane_f64(c_lnp, jj);
+                        T u[KM], mx = lnp;
+#pragma unroll
+                        for (int k = 0; k < KM; ++k) {
+                            mu[k] = readlane_f64(c_mm[k], jj) * rq;                           // :509
+                            const T t = readlane_f64(c_sh[k], jj) * mu[k];
+                            u[k] = __builtin_fma(t, t, readlane_f64(c_ul[k], jj));            // :511
+                            if (k < K) mx = fmax(mx, u[k]);                                   // c_max, :58-71
+                        }
+                        T ssum = 0;                                                           // softmax, :231-240: k = 0 .. K in order
+#pragma unroll
+                        for (int k = 0; k < KM; ++k) {
+                            if (k < K) {
+                                u[k] = exp_nonpos_f64_uniform(u[k] - mx, tab);
+                                ssum += u[k];
+                            }
+                        }
+                        ssum += exp_nonpos_f64_uniform(lnp - mx, tab);
+                        d = -eta_old;                                                         // :519
+#pragma unroll
+                        for (int k = 0; k < KM; ++k) {
+                            gam[k] = 0;
+                            if (k < K) {
+                                gam[k] = u[k] / ssum;                                         // :239
+                                d = __builtin_fma(gam[k], mu[k], d);                          // :523
+                            }
+                        }
+                    } else {
+                        MODEL::update(readlane_f64(c_mm[0], jj), readlane_f64(c_sb, jj), readlane_f64(c_sh[0], jj),
+                                      readlane_f64(c_ul[0], jj), eta_old, qj, tab, mu[0], gam[0], d);
+                    }
                     const bool skip = MODEL::kSkip && fabs(d) < eps;                          // e_step.hpp:410
                     const T de = skip ? (T)0 : d;                                             // :412
                     const T a = A.dq * de;
@@ -391,8 +453,11 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                     const bool own = lane == jj;
                     ql = (own && !A.low_memory) ? v - de : v;                                 // :427
                     const bool take = own && !skip;                                           // :416-418, :431
-                    o_mu = take ? mu : o_mu;
-                    o_gam = take ? gam : o_gam;
+#pragma unroll
+                    for (int k = 0; k < KM; ++k) {
+                        o_mu[k] = take ? mu[k] : o_mu[k];
+                        o_gam[k] = take ? gam[k] : o_gam[k];
+                    }
                     o_eta = take ? eta_old + d : o_eta;
                     o_ed = take ? d : o_ed;
                     o_a = take ? a : o_a;
@@ -406,8 +471,13 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                     qv[p0 + lane] = ql;
                     A.eta_diff[j] = o_ed;
                     if ((applied >> lane) & 1ull) {
-                        A.var_mu[j] = o_mu;
-                        A.var_gamma[j] = o_gam;
+#pragma unroll
+                        for (int k = 0; k < KM; ++k) {
+                            if (k < K) {
+                                A.var_mu[j * K + k] = o_mu[k];
+                                A.var_gamma[j * K + k] = o_gam[k];
+                            }
+                        }
                         A.eta[j] = o_eta;
                     }
                 }
