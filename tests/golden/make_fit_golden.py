@@ -147,6 +147,8 @@ def main():
          dict(low_memory=True, dequantize_on_the_fly=True, float_precision="float64"), dict(ld_kind="longrange", ld_dtype=np.int8)),
         ("fit_ss_f64_lr_int8_sym", VIPRS, {21: [260, 330], 22: [150, 200]},
          dict(low_memory=False, dequantize_on_the_fly=True, float_precision="float64"), dict(ld_kind="longrange", ld_dtype=np.int8)),
+        ("fit_mix_k4_f64_lr_int8_upper", VIPRSMix, {22: [380, 150, 330]},
+         dict(low_memory=True, K=4, dequantize_on_the_fly=True, float_precision="float64"), dict(ld_kind="longrange", ld_dtype=np.int8)),
     ]
     for name, cls, chrom_sizes, kw, ld_kw in cases:
         if ONLY and name not in ONLY:

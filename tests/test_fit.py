@@ -88,7 +88,7 @@ def check_against_fixture(model, fx, local_only=False, pi_rtol=2e-4):
 
 
 def test_fit_fixtures_present():
-    assert len(FIT) >= 9
+    assert len(FIT) >= 10
 
 
 @pytest.mark.parametrize("path", FIT, ids=[os.path.basename(p)[:-4] for p in FIT])
