@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
     __shared__ unsigned long long s_tp[24][8];
 #endif
     // Waves 1 .. NW - 1 fetch and stage the tiles (rows w - 1, w - 1 + (NW - 1), ...): the chain wave issues no vector-memory
-    // instruction but the loads of its own 5 inputs per panel -- under the row pass's load its issue stalls for
+    // instruction but the loads of its own per-SNP inputs, one panel ahead -- under the row pass's load its issue stalls for
     // microseconds (measured: 16 tile-row loads 1.6 us in a quiet workgroup, 4 us next to a 3 648-column row pass).
     constexpr int kWaves = NW;
     constexpr int kRowsPerWave = (kPanel + kWaves - 2) / (kWaves - 1);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
         };
 
         for (int i = tid; i < n; i += NT) qv[i] = A.q[s0 + i];
-        TileWindow w_prev{0, 0, 0}, w_cur = load_window(0), w_nxt = load_window(kPanel);
+        TileWindow w_cur = load_window(0), w_nxt = load_window(kPanel);
         U t_d[kRowsPerWave], t_o[kRowsPerWave];
         load_tile(t_d, w_cur, 0, 0);
 #pragma unroll
@@ -494,7 +494,6 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
             }
             __syncthreads();
             TPROF(7);
-            w_prev = w_cur;
             w_cur = w_nxt;
             w_nxt = w_nn;
         }
