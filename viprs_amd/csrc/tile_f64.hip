@@ -53,6 +53,34 @@ int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
     while (n_big < (int)list.size() && list[(size_t)n_big].size >= kTileBigBlock) ++n_big;
     const int n_small = (int)list.size() - n_big;
     int32_t* counter = P->d_counters.p + (dense ? 2 : 1);
+
+    // second pass of the upper form (update_q_factor): groups of kTileGroupRows rows in list order -- the big class's
+    // groups first -- over the whole device
+    DevBuf<int64_t>& groups = dense ? P->d_rowlist_dense : P->d_rowlist_ragged;
+    int64_t n_groups_big = 0;
+    for (int i = 0; i < n_big; ++i) n_groups_big += (list[(size_t)i].size + kTileGroupRows - 1) / kTileGroupRows;
+    if (P->low_memory && groups.n == 0) {
+        std::vector<int64_t> h;
+        for (size_t i = 0; i < list.size(); ++i)
+            for (int r = 0; r < list[i].size; r += kTileGroupRows) h.push_back((int64_t)i << 32 | (int64_t)r);
+        HIP_TRY(groups.alloc(h.size()));
+        HIP_TRY(hipMemcpy(groups.p, h.data(), sizeof(int64_t) * h.size(), hipMemcpyHostToDevice));
+    }
+    auto second_pass = [&](int64_t first, int64_t count, hipStream_t stream, int cus) -> int {
+        if (!P->low_memory || count == 0) return VIPRS_OK;
+        EStepArgs<double> A2 = A;
+        A2.blocks = d_blocks;
+        A2.n_blocks = (int)list.size();
+        const int64_t* pp = groups.p + first;
+        void* params2[] = {(void*)&A2, (void*)&pp, (void*)&count};
+        const void* k2 = dense ? (const void*)tile_f64_second_pass_kernel<U, true> : (const void*)tile_f64_second_pass_kernel<U, false>;
+        const int64_t n_items = count * std::max(1, A.n_active);
+        const int grid = (int)std::min<int64_t>((n_items + kTileThreads / 64 - 1) / (kTileThreads / 64), (int64_t)cus * 8);
+        HIP_TRY(hipLaunchKernel(k2, dim3(grid), dim3(kTileThreads), params2, 0, stream));
+        return VIPRS_OK;
+    };
+    const int64_t n_groups = P->low_memory ? (int64_t)groups.n : 0;
+
     if (n_big > 0 && n_small > 0) {
         if (!P->side_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&P->side_stream, hipStreamNonBlocking));
@@ -72,32 +100,20 @@ int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
         rc = launch_tile_class<U, 4>(P, A, model, dense, d_blocks + n_big, n_small, list[(size_t)n_big].size, counter, P->side_stream,
                                      P->n_cu - big_cus);
         if (rc != VIPRS_OK) return rc;
+        // each class's second pass behind its own sweep: the small class's runs while the largest blocks are still
+        // walking their panels
+        rc = second_pass(n_groups_big, n_groups - n_groups_big, P->side_stream, P->n_cu - big_cus);
+        if (rc != VIPRS_OK) return rc;
         HIP_TRY(hipEventRecord(P->ev_join, P->side_stream));
+        rc = second_pass(0, n_groups_big, P->stream, P->n_cu);
+        if (rc != VIPRS_OK) return rc;
         HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join, 0));
-    } else if (n_big > 0) {
-        int rc = launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, counter, P->stream, P->n_cu);
-        if (rc != VIPRS_OK) return rc;
     } else {
-        int rc = launch_tile_class<U, 4>(P, A, model, dense, d_blocks, n_small, max_b, counter, P->stream, P->n_cu);
+        int rc = n_big > 0 ? launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, counter, P->stream, P->n_cu)
+                           : launch_tile_class<U, 4>(P, A, model, dense, d_blocks, n_small, max_b, counter, P->stream, P->n_cu);
         if (rc != VIPRS_OK) return rc;
-    }
-    if (P->low_memory) {
-        // second pass: the rows of all blocks of the list over the whole device
-        A.blocks = d_blocks;
-        A.n_blocks = (int)list.size();
-        DevBuf<int64_t>& rows = dense ? P->d_rowlist_dense : P->d_rowlist_ragged;      // groups of kTileGroupRows rows
-        if (rows.n == 0) {
-            std::vector<int64_t> h;
-            for (size_t i = 0; i < list.size(); ++i)
-                for (int r = 0; r < list[i].size; r += kTileGroupRows) h.push_back((int64_t)i << 32 | (int64_t)r);
-            HIP_TRY(rows.alloc(h.size()));
-            HIP_TRY(hipMemcpy(rows.p, h.data(), sizeof(int64_t) * h.size(), hipMemcpyHostToDevice));
-        }
-        const int64_t* pp = rows.p;
-        int64_t n_rows = (int64_t)rows.n;
-        void* params2[] = {(void*)&A, (void*)&pp, (void*)&n_rows};
-        const void* k2 = dense ? (const void*)tile_f64_second_pass_kernel<U, true> : (const void*)tile_f64_second_pass_kernel<U, false>;
-        HIP_TRY(hipLaunchKernel(k2, dim3(P->n_cu * 8), dim3(kTileThreads), params2, 0, P->stream));
+        rc = second_pass(0, n_groups, P->stream, P->n_cu);
+        if (rc != VIPRS_OK) return rc;
     }
     return VIPRS_OK;
 }
