@@ -1,5 +1,5 @@
 """A/B of two builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
-    python tools/ab_bench.py LIB_A LIB_B [upper] [int8] [grid|mix] [uniform]   (each library runs in its own subprocess, 3 rounds)"""
+    python tools/ab_bench.py LIB_A LIB_B [upper] [int8|int16] [grid|mix] [uniform]   (each library runs in its own subprocess, 3 rounds)"""
 import os, subprocess, sys
 args = [a for a in sys.argv[3:]]
 code = r'''
@@ -7,7 +7,7 @@ import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 from viprs_amd.plan import DeviceState, LDPlan
 from viprs_amd.utils import synthetic as syn
-upper = "upper" in sys.argv; dt = np.int8 if "int8" in sys.argv else np.float32
+upper = "upper" in sys.argv; dt = np.int8 if "int8" in sys.argv else np.int16 if "int16" in sys.argv else np.float32
 sizes = np.full(1700, 650) if "uniform" in sys.argv else None      # uniform: 1700 blocks of 650 SNPs (no large-block tail)
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt, sizes=sizes)
 model = "grid" if "grid" in sys.argv else "mixture" if "mix" in sys.argv else "spike_slab"

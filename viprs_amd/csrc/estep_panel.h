@@ -522,21 +522,19 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     //   mixture (rolled chain loop): the off-diagonal tiles R[p-1, p] / R[p, p+1], diagonal rows from global memory.
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     // The off-diagonal tile of the chain's next phase goes through LDS too (below) in the SYMMETRIC form.  The upper-
-    // triangular form keeps the chain's own register prefetch: measured with nothing else changed (-DPANEL_UPPER_LDS_TILE;
-    // the LDS is there since the team classes keep only their own strips), the tile in LDS makes the cfg3 sweep 5 % SLOWER
-    // (0.792 -> 0.831 ms) although the chain loop itself gets faster -- the upper form's updater waves carry the second pass
-    // and are the busier side: one more tile to stage per phase, and a go-ahead to wait for, cost them more than the chain wins.
+    // triangular form keeps the chain's own register prefetch for fp32 / int16 LD: measured with nothing else changed
+    // (-DPANEL_UPPER_LDS_TILE; the LDS is there since the team classes keep only their own strips), the tile in LDS makes the
+    // cfg3 sweep 5 % SLOWER (0.792 -> 0.831 ms) although the chain loop itself gets faster -- the upper form's updater waves
+    // carry the second pass and are the busier side: one more tile to stage per phase, and a go-ahead to wait for, cost them
+    // more than the chain wins.  With int8 LD (a quarter of the bytes, a chain-bound sweep) it is the other way round
+    // (panel_upper_tile_in_lds, kernels_common.h).
     // The K <= 8 mixture chain (components of one SNP across the lanes) follows the same scheme in the symmetric form:
     // diagonal tiles staged in LDS, the off-diagonal tile of the next phase in the single gated buffer -- its chain wave
     // issues no vector-memory instruction inside a panel either (it used to stream the diagonal rows from global memory,
     // 16 rows ahead).
     constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value && SYM;
     constexpr bool kStageDiag = kDiagInLds || kMixLds;          // what the updaters stage into lT: diagonal tiles
-#ifndef PANEL_UPPER_LDS_TILE
-    constexpr bool kTileInLds = (kDiagInLds && SYM) || kMixLds;
-#else
-    constexpr bool kTileInLds = kDiagInLds || kMixLds;
-#endif
+    constexpr bool kTileInLds = (kDiagInLds && (SYM || panel_upper_tile_in_lds<U>())) || kMixLds;
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;

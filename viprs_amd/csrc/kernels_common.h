@@ -14,6 +14,18 @@ constexpr int kStrip = 256;         // padding unit of the per-block q arrays (o
 __host__ __device__ constexpr int panel_lds_floats(int qcap, bool offdiag_tile = false) {
     return qcap + 2 * kPanel + 2 * kPanel * kPanel + (offdiag_tile ? kPanel * kPanel : 0);
 }
+// Upper-triangular form of the lane-per-SNP models: does the chain's off-diagonal tile go through LDS (as it always does
+// in the symmetric form) or through the chain wave's own register prefetch?  fp32 LD: registers (the updater waves carry
+// the second pass and are the busier side; the tile in LDS makes the cfg3 sweep 5 % slower); int8 LD streams a quarter of
+// the bytes (int16: half), its sweep is bound by the chain: the tile in LDS makes it 8 % faster (int8 0.570 -> 0.522 ms, int16
+// 0.61 -> 0.56 ms; tools/ab_bench.py).
+template <typename U> __host__ __device__ constexpr bool panel_upper_tile_in_lds() {
+#ifdef PANEL_UPPER_LDS_TILE
+    return true;
+#else
+    return sizeof(U) <= 2;
+#endif
+}
 // upper-triangular form: eta_diff[2][64] of the last two panels + the running second-pass sums s[qcap]
 constexpr int kPanelUpperTransposeBytes = 32 * 128;         // per updater wave: 32 rows of a half tile (fp32: 128 B per row)
 __host__ __device__ constexpr int panel_upper_lds_floats(int qcap, int n_waves = 4) {
