@@ -12,8 +12,13 @@ upper = "upper" in sys.argv
 dt = np.int8 if "int8" in sys.argv else np.float32
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
 CONFIGS = [dict()]
-for md, t1 in (("1024", "2"), ("1024", "3"), ("1024", "4"), ("960", "2"), ("896", "2"), ("1024", "1")):
-    CONFIGS.append(dict(VIPRS_MEDIUM_BLOCK=md, VIPRS_TEAM1=t1, VIPRS_TEAM0="12"))
+for t0 in ("12", "16"):
+    CONFIGS.append(dict(VIPRS_TEAM0=t0))
+for lg, md in (("2048", "1408"), ("1792", "1280"), ("2560", "1792")):
+    CONFIGS.append(dict(VIPRS_LARGE_BLOCK=lg, VIPRS_MEDIUM_BLOCK=md))
+CONFIGS.append(dict(VIPRS_TEAM1="6"))
+CONFIGS.append(dict(VIPRS_TEAM1="2"))
+CONFIGS.append(dict(VIPRS_BOTTOM_MOD="4"))
 CONFIGS.append(dict())
 KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK")
 for cfg in CONFIGS:
