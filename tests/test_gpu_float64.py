@@ -78,7 +78,8 @@ def test_float64_windowed_components(gpu, m, wl, wr, jitter, low_memory, ld_dtyp
 @pytest.mark.parametrize("low_memory", [False, True])
 def test_float64_grid_matches_oracle(gpu, low_memory):
     from viprs_amd.vi import e_step_hip as S
-    ld, ss, inp = syn.make_problem(sizes=[130, 1300, 64], low_memory=low_memory, seed=33, kind="longrange", float_precision=T)
+    ld, ss, inp = syn.make_problem(sizes=[130, 1300, 64, 1900], low_memory=low_memory, seed=33, kind="longrange",
+                                   float_precision=T)           # 1 900: the 8-wave class beside the 4-wave one
     g, st0 = _grid_inputs(ld, ss, 12, T=T)
     active = np.array([11, 0, 7, 8, 3], dtype=np.int32)
     out = {}
