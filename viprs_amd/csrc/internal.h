@@ -48,8 +48,10 @@ inline size_t float_size(int t) { return t == VIPRS_F32 ? 4 : (t == VIPRS_F64 ? 
 struct SchedConfig {
     int large_block = 2304, medium_block = 1600;   // VIPRS_LARGE_BLOCK / VIPRS_MEDIUM_BLOCK
     int class_team[3] = {8, 4, 1};                 // workgroups (CUs) sharing one block of the class (0/1: teams)
-    // mixture: the chain step is ~4x the spike-and-slab one, every team member replicates it -- smaller teams
-    int class_team_mix[3] = {4, 1, 1};
+    // mixture: the same team sizes (rounds 1-2 ran teams of 4 / single workgroups -- every member replicates the chain,
+    // whose step is ~2.5x the spike-and-slab one; re-measured at the end of round 3, cfg3: K = 4 1.273 -> 1.230 ms
+    // symmetric, 1.40 -> 1.36 upper; K = 10 2.11 -> 2.08, K = 20 2.91 -> 2.88)
+    int class_team_mix[3] = {8, 4, 1};
     bool team_env = false;                         // VIPRS_TEAM0/1 given: they apply to every model
     // small-block queue: every `bottom_mod`-th workgroup pulls from the SMALL end of the size-sorted queue (0 = off)
     int bottom_mod = 0;                            // VIPRS_BOTTOM_MOD
