@@ -46,12 +46,17 @@ SS_CASES = [
     ([2400, 3619], "longrange", np.int8, 1),
     ([1400, 2400], "longrange", np.int16, 2),
     ([1700, 650], "sample", np.int8, 1),
+    # populous team classes: more large blocks than teams fit (team size drops 12 -> 8 -> 4, several blocks per team),
+    # and the team budget split between a populous large and a populous medium class (launch_panel.inc)
+    ([2400] * 30 + [300] * 40, "longrange", np.int8, 1),
+    ([2500] * 45 + [2000] * 60 + [500] * 30, "longrange", np.int8, 1),
 ]
 
 
 @pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
 @pytest.mark.parametrize("sizes, kind, ld_dtype, sweeps", SS_CASES,
-                         ids=[f"{'-'.join(map(str, c[0]))}_{c[1]}_{np.dtype(c[2]).name}" for c in SS_CASES])
+                         ids=[f"{'-'.join(map(str, c[0][:3]))}{'-x' + str(len(c[0])) if len(c[0]) > 3 else ''}_{c[1]}_{np.dtype(c[2]).name}"
+                              for c in SS_CASES])
 def test_spike_slab_far_field(gpu, sizes, kind, ld_dtype, sweeps, low_memory):
     ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=61, kind=kind)
     assert_far_field_matters(ld, inp)

@@ -12,14 +12,10 @@ upper = "upper" in sys.argv
 dt = np.int8 if "int8" in sys.argv else np.float32
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
 CONFIGS = [dict()]
-for t0 in ("12", "16"):
-    CONFIGS.append(dict(VIPRS_TEAM0=t0))
-for lg, md in (("2048", "1408"), ("1792", "1280"), ("2560", "1792")):
+for lg, md in (("1792", "1600"), ("2304", "1280"), ("2304", "1408"), ("1792", "1280")):
     CONFIGS.append(dict(VIPRS_LARGE_BLOCK=lg, VIPRS_MEDIUM_BLOCK=md))
-CONFIGS.append(dict(VIPRS_TEAM1="6"))
-CONFIGS.append(dict(VIPRS_TEAM1="2"))
-CONFIGS.append(dict(VIPRS_BOTTOM_MOD="4"))
-CONFIGS.append(dict())
+CONFIGS.append(dict(VIPRS_LARGE_BLOCK="1792", VIPRS_MEDIUM_BLOCK="1280", VIPRS_TEAM0="8"))
+CONFIGS.append(dict(VIPRS_LARGE_BLOCK="1792", VIPRS_MEDIUM_BLOCK="1280", VIPRS_TEAM1="2"))
 KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK")
 for cfg in CONFIGS:
     for k in KEYS:

@@ -198,8 +198,14 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         // SNPs of the largest block, 8..16 (cfg3, 3 619 SNPs: 12 -- 0.70-0.71 ms against 0.72-0.77 with 8 in the same
         // process; one 6 000-SNP block: 16 -- 1.05 against 1.17 ms).  VIPRS_TEAM0 overrides.
         // (bytes, not SNPs: int8 LD keeps 8 -- its sweep is bound by the number of chains in flight, 12 costs it 4 %)
-        if (!sched_config().team_env && P->class_begin[1] > 0)
+        if (!sched_config().team_env && P->class_begin[1] > 0) {
             P->team0 = std::min(16, std::max(8, 4 * (int)(((int64_t)P->dense_h[0].size * (int64_t)es + 5999) / 6000)));
+            // ... unless the class is populous: teams beyond the resident workgroups only queue up behind each other, and
+            // more, smaller teams get through the class's chains sooner (300 blocks of 2 400 SNPs: 12 -> 4 members,
+            // tools/mixed_blocks_bench.py)
+            const int64_t room = (int64_t)P->n_cu * 2 * 5 / 8;
+            while (P->team0 > 4 && (int64_t)P->class_begin[1] * P->team0 > room) P->team0 -= 4;
+        }
         // hand-off granules for the blocks served by teams (classes 0 and 1)
         int64_t rows = 0;
         for (int k = 0; k < P->class_begin[2]; ++k) {
