@@ -81,7 +81,8 @@ def _run_mix(mod, ld, inp, mix, st0, sweeps):
     (4, [1400, 2400], "longrange", np.int8),
     (10, [700, 1400, 2400], "longrange", np.float32),
     (20, [700, 1400, 2400], "longrange", np.float32),
-])
+    (4, [2400] * 45 + [2000] * 30 + [300] * 20, "longrange", np.int8),     # populous team classes (teams of 4, several blocks each)
+], ids=lambda v: None if not isinstance(v, list) else "-".join(map(str, v[:3])) + (f"-x{len(v)}" if len(v) > 3 else ""))
 def test_mixture_far_field(gpu, K, sizes, kind, ld_dtype, low_memory):
     from viprs_amd.vi import e_step_hip as S
     ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=62, kind=kind)
