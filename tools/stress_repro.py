@@ -2,7 +2,8 @@
 """Stress: N sweeps of the E-step on cfg3 from the same start must be bit-identical (development tool; reports the
 blocks whose state differs from the first sweep).  Two consecutive sweeps WITHOUT a reset in between are part of every
 iteration, so that the hand-off tags / arrival counters / queue heads of one launch meet the next launch unzeroed.
-    python tools/stress_repro.py N [--low-memory] [--int8] [--mixture] [--longrange]"""
+    python tools/stress_repro.py N [--low-memory] [--int8] [--mixture] [--longrange] [--populous]
+(--populous: 45 x 2 400 + 60 x 2 000 + 30 x 500 SNPs instead of cfg3 -- more team blocks than teams)"""
 import os
 import sys
 
@@ -15,7 +16,8 @@ from viprs_amd.utils import synthetic as syn            # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 low_memory = "--low-memory" in sys.argv
 mixture = "--mixture" in sys.argv
-ld, ss, inp = syn.make_problem("cfg3", low_memory=low_memory, ld_dtype=np.int8 if "--int8" in sys.argv else np.float32,
+sizes = [2400] * 45 + [2000] * 60 + [500] * 30 if "--populous" in sys.argv else None
+ld, ss, inp = syn.make_problem("cfg3", sizes=sizes, low_memory=low_memory, ld_dtype=np.int8 if "--int8" in sys.argv else np.float32,
                                kind="longrange" if "--longrange" in sys.argv else "ar1")
 plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory)
 if mixture:
