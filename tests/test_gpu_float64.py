@@ -198,3 +198,14 @@ def test_float64_mixture_matches_oracle(gpu, K, low_memory):
         assert_close_f64(got[k], ref[k], k)
     cut = _run_mix(O, H.cut_far_field(ld), inp, mix, st0, 2)
     assert np.max(np.abs(cut["q"] - ref["q"])) > 1e-4 * np.max(np.abs(ref["q"]))
+
+
+@pytest.mark.parametrize("low_memory", [False, True])
+@pytest.mark.parametrize("sizes", [[2000, 1900], [100, 64, 65, 1, 300], [1792, 1791]],
+                         ids=["big-class-only", "small-class-only", "at-the-class-limit"])
+def test_float64_block_classes(gpu, sizes, low_memory):
+    """The float64 launch runs blocks >= 1 792 SNPs on 8-wave workgroups beside the rest on a second stream; with one
+    class empty it is a single launch."""
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=np.int8, seed=44, kind="longrange", float_precision=T)
+    st0 = inp.state_copy()
+    assert_state_close_f64(H.run_hip(ld, inp, st0, sweeps=3), H.run_oracle(ld, inp, st0, sweeps=3))
