@@ -92,7 +92,26 @@ int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
         // an 8-wave workgroup fills a CU; the persistent workgroups of the other class leave those CUs alone (they would
         // not drain before their queue is empty)
         const int64_t big_items = (int64_t)n_big * std::max(1, A.n_active);
-        const int big_cus = (int)std::min<int64_t>(big_items, P->n_cu / 2);
+        // how many CUs for the big class: the split under which the later of the two classes ends earliest -- a panel
+        // costs the chain's 64 steps (~19 us on an 8-wave workgroup, ~25 us on a 4-wave one sharing its CU with another),
+        // a class cannot end before its largest block
+        int big_cus = 1;
+        {
+            double panels_big = 0.0, panels_small = 0.0;
+            for (int i = 0; i < (int)list.size(); ++i)
+                (i < n_big ? panels_big : panels_small) += (double)((list[(size_t)i].size + kPanel - 1) / kPanel);
+            const double nm = (double)std::max(1, A.n_active);
+            const double floor_big = (double)((list[0].size + kPanel - 1) / kPanel) * 19e-6;
+            const double floor_small = (double)((list[(size_t)n_big].size + kPanel - 1) / kPanel) * 25e-6;
+            double best = 1e30;
+            const int max_cus = (int)std::min<int64_t>(big_items, P->n_cu - 1);
+            for (int c = 1; c <= max_cus; ++c) {
+                const double tb = std::max(floor_big, panels_big * nm / c * 19e-6);
+                const double ts = std::max(floor_small, panels_small * nm / ((P->n_cu - c) * 2.0) * 25e-6);
+                const double t = std::max(tb, ts);
+                if (t < best * (1.0 - 1e-9)) { best = t; big_cus = c; }
+            }
+        }
         // the big class goes FIRST and on the plan's own stream (it starts the moment the work before it ends; the other
         // class has to come through the fork event and finds those CUs taken)
         int rc = launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, P->d_counters.p + (dense ? 20 : 21), P->stream, big_cus);
