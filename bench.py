@@ -4,6 +4,12 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU
 (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Rank 0 prints ONE JSON line.
+A BARE `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts the N ranks itself:
+the parent -- which never loads the HIP library -- spawns N fresh copies of this script with RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* / VIPRS_RUN_ID set (one process per GPU, the only parallel axis the
+reference has is process-level too: bin/viprs_fit:1079-1086), relays rank 0's line and exits non-zero
+if any rank does.  A line is never printed with a world size other than --gpus, nor with more ranks
+than HIP devices (`config.rccl_ranks` = the communicator size RCCL itself reports).
 
 A "step" = one pass of the hot path over one batch: the variational state is re-initialised on
 the device to the standard start (var_gamma = pi, var_mu = eta = q = eta_diff = 0; the reference's
@@ -353,14 +359,77 @@ def per_rank(comm, rank, world, x):
     return comm.allreduce_sum(v)
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU) and relay rank 0's
+    JSON line.  This parent never imports the HIP library or touches a device (children are fresh interpreters, not
+    an exec of a process that holds a GPU context).  Returns the exit status: 0 only if every rank exited 0 and
+    rank 0 printed exactly one line."""
+    import secrets
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as s:                              # a free port names this launch (nothing listens on it:
+        s.bind(("127.0.0.1", 0))                            # the RCCL id travels through files keyed by it)
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               VIPRS_RUN_ID=os.environ.get("VIPRS_RUN_ID") or secrets.token_hex(6), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs, outs = [], [[] for _ in range(n)]
+
+    def pump(r, stream):
+        for line in stream:
+            if line.startswith("{") and r == 0:
+                outs[r].append(line)
+            else:                                           # everything else (warnings, tracebacks) goes to stderr
+                sys.stderr.write(f"[rank {r}] {line}")
+
+    threads = []
+    for r in range(n):
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                             env=dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0"),
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, bufsize=1)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(r, p.stdout), daemon=True)
+        t.start()
+        threads.append(t)
+    status = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks\n")
+                for q in live:                              # exactly the processes started above
+                    procs[q].terminate()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=10)
+    if status == 0 and len(outs[0]) != 1:
+        sys.stderr.write(f"bench.py: rank 0 printed {len(outs[0])} JSON lines, expected 1\n")
+        status = 1
+    if status == 0:
+        sys.stdout.write(outs[0][0])
+        sys.stdout.flush()
+    return status
+
+
 def main():
     args = parse_args()
+    n_gpus = args.gpus
+    if n_gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and n_gpus > 1:
+        # no launcher: be the launcher (before anything loads the HIP library in this process)
+        raise SystemExit(launch_ranks(n_gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    if world != n_gpus and world > 1:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
+    if world != n_gpus:
+        # never a line whose n_gpus is not the number of ranks that ran
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}: refusing to print a mislabelled line")
 
     from viprs_amd import _lib
     from viprs_amd.parallel import LocalComm, RcclComm, rank_time_model
@@ -368,6 +437,10 @@ def main():
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (the E-step has no CPU fallback)")
+    dry = os.environ.get("VIPRS_BENCH_COMM") == "file"     # dry run of the multi-rank logic (ranks may share a device)
+    if world > ndev and not dry:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but only {ndev} HIP device(s) visible: one rank per GPU, refusing to "
+                         "oversubscribe (VIPRS_BENCH_COMM=file runs the multi-rank logic on fewer devices, labelled as such)")
     device = local_rank % ndev
     comm_kind = "rccl" if world > 1 else "none"
     if world > 1 and os.environ.get("VIPRS_BENCH_COMM") == "file":
@@ -394,6 +467,10 @@ def main():
             side.close()                                # RCCL is up on every rank: the side channel is done
     else:
         comm = LocalComm()
+    # the number of ranks the transport itself reports (RCCL: ncclCommCount through viprs_comm_rank)
+    comm_ranks = comm.size() if hasattr(comm, "size") else comm.world_size
+    if comm_ranks != n_gpus:
+        raise SystemExit(f"bench.py: the communicator spans {comm_ranks} ranks, --gpus says {n_gpus}")
 
     def barrier():
         # every rank: device idle (hipDeviceSynchronize), then all ranks arrived (RCCL collective + stream sync)
@@ -527,7 +604,8 @@ def main():
                 "primary": "`value` is the " + ("upper-triangular" if ld.low_memory else "symmetric") + " LD form; the other "
                            "form (the reference's default is low_memory=True) is in `secondary`",
                 "math_mode": args.math, "skipped_snps_last_sweep_rank0": int(skipped),
-                "comm": comm_kind,
+                "comm": comm_kind, "rccl_ranks": int(comm_ranks) if comm_kind == "rccl" else None,
+                "ranks": int(comm_ranks),
                 "parallelism": (f"ld-blocks x{n_gpus} (strong: chain-aware LPT, no data-path collective; RCCL barrier / max only)"
                                 if strong else f"one workload per GPU x{n_gpus}") if n_gpus > 1 else "single GPU",
                 "step": "device state re-init + one E-step sweep over all blocks",

@@ -189,3 +189,79 @@ def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra
     # the transport cleaned up after itself (stale rendezvous files)
     left = [f for f in os.listdir(tmp_path) if f.startswith("viprs_filecomm")]
     assert left == [], left
+
+
+# ---- the bare command: `python bench.py --gpus 2` with NO launcher environment -----------------------------------------
+# The device layer is stubbed from OUTSIDE bench.py: a sitecustomize module on PYTHONPATH patches viprs_amd in every
+# rank process (and only there: the launching parent never imports the library).
+_SITE_STUB = r"""
+import os, sys, time
+if "RANK" in os.environ:
+    sys.path.insert(0, {root!r})
+    from viprs_amd import _lib, plan as plan_mod
+    _lib.device_count = lambda: {ndev}
+    class _FakeLib:
+        def __getattr__(self, name):
+            return lambda *a, **k: 0
+    _lib.lib = _FakeLib()
+    _lib.check = lambda rc: None
+    class FakePlan:
+        def __init__(self, lb, ip, data, low_memory, device=0, math_mode="exact"):
+            self.m = int(lb.shape[0]); self.n = 0
+        def timing_reset(self): self.n = 0
+        def timing_history(self, which=0, capacity=256): return [0.5 + 0.01 * int(os.environ["RANK"])] * max(self.n, 1)
+        def last_skipped(self): return 7
+        def close(self): pass
+    class FakeState:
+        def __init__(self, plan, dtype, model, width): self.plan = plan
+        def upload(self, name, arr): assert arr.shape[0] == self.plan.m
+        def reset(self, pi): pass
+        def e_step(self, dq, active=None, sync=True): self.plan.n += 1; time.sleep(0.001)
+        def synchronize(self): pass
+        def close(self): pass
+    plan_mod.LDPlan, plan_mod.DeviceState = FakePlan, FakeState
+"""
+
+
+def _run_bare_bench(tmp_path, argv, ndev, env_extra):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "sitecustomize.py").write_text(_SITE_STUB.format(root=root, ndev=ndev))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VIPRS_BENCH_COMM")}
+    env.update(PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""), TMPDIR=str(tmp_path), **env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+def test_bare_bench_gpus_2_starts_two_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE must not run ONE process and print n_gpus 2 -- the
+    parent starts two fresh rank processes, relays rank 0's single line, and the line shows both ranks took part."""
+    import json
+    r = _run_bare_bench(tmp_path, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg2", "--cpu-seconds", "0"],
+                        ndev=2, env_extra={"VIPRS_BENCH_COMM": "file"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    sizes = bench.config_sizes("cfg2", 7209)
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["rccl_ranks"] is None
+    assert "file transport" in out["config"]["comm"]
+    pr = out["per_rank"]
+    assert len(pr["snps"]) == 2 and min(pr["snps"]) > 0 and sum(pr["snps"]) == int(sizes.sum())
+    assert pr["kernel_ms_avg"] == pytest.approx([0.5, 0.51])                 # each rank reported under its own RANK
+    assert out["roofline"]["peak"] == 2 * bench.HBM_PEAK_GBS
+
+
+def test_bare_bench_refuses_more_ranks_than_devices_and_mismatched_world(tmp_path):
+    """No mislabelled line, ever: more ranks than HIP devices (outside the labelled dry-run transport) and a launcher
+    world size different from --gpus both end non-zero without a JSON line."""
+    r = _run_bare_bench(tmp_path, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "cfg1", "--cpu-seconds", "0"],
+                        ndev=1, env_extra={})
+    assert r.returncode != 0 and "{" not in r.stdout, (r.stdout, r.stderr[-2000:])
+    assert "only 1 HIP device" in r.stderr
+    r = _run_bare_bench(tmp_path, ["--gpus", "4", "--steps", "2", "--warmup", "1", "--config", "cfg1", "--cpu-seconds", "0"],
+                        ndev=4, env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE=2" in r.stderr

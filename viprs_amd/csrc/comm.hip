@@ -21,6 +21,8 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 };
@@ -40,7 +42,7 @@ RcclApi* rccl() {
 #define SYM(NAME)                                                                      \
         api.NAME = reinterpret_cast<decltype(api.NAME)>(dlsym(api.handle, "nccl" #NAME)); \
         if (!api.NAME) { api.error = "librccl: missing symbol nccl" #NAME; dlclose(api.handle); api.handle = nullptr; return; }
-        SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(GetErrorString)
+        SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllGather) SYM(GetErrorString) SYM(CommCount) SYM(CommUserRank)
 #undef SYM
     });
     return &api;
@@ -147,9 +149,16 @@ int viprs_comm_destroy(viprs_comm* C) {
 }
 
 int viprs_comm_rank(const viprs_comm* C, int* rank, int* world_size) {
+    // what RCCL itself says about the communicator (not what the caller passed to viprs_comm_create): a launcher
+    // that started fewer processes than it claims shows up here
     if (!C) return fail(VIPRS_EINVAL, "null communicator");
-    if (rank) *rank = C->rank;
-    if (world_size) *world_size = C->world;
+    int r = C->rank, w = C->world;
+    if (C->comm) {
+        NCCL_TRY(rccl()->CommUserRank(C->comm, &r));
+        NCCL_TRY(rccl()->CommCount(C->comm, &w));
+    }
+    if (rank) *rank = r;
+    if (world_size) *world_size = w;
     return VIPRS_OK;
 }
 

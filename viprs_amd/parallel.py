@@ -286,6 +286,14 @@ class RcclComm:
             raise ValueError("RcclComm is closed")
         return self._h
 
+    def size(self):
+        """The communicator's size as RCCL reports it (ncclCommCount), not as this object was told."""
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._L.check(self._L.lib.viprs_comm_rank(self.handle, ctypes.byref(r), ctypes.byref(w)))
+        if r.value != self.rank:
+            raise RuntimeError(f"RCCL says this is rank {r.value}, the launcher said {self.rank}")
+        return int(w.value)
+
     def _reduce(self, vec, group):
         v = np.ascontiguousarray(vec, dtype=np.float64).copy()
         self._L.check(self._L.lib.viprs_comm_allreduce(self.handle, v.ctypes.data_as(ctypes.c_void_p),
