@@ -338,18 +338,148 @@ def pct(v, q):
     return float(np.percentile(v, q)) if len(v) else None
 
 
-def measure_secondary(name, sw, steps, barrier):
-    """One secondary configuration on one GPU: K timed steps, kernel time from the library's HIP events."""
+# ---- time model of one sweep on one GPU -----------------------------------------------------------------------
+# What a sweep cannot beat, from three measured machine constants: the HBM stream, the serial chain of the
+# largest block, and the chip's total chain work spread over the chains in flight.
+STREAM_GBS = 6300.0                                 # what a float4 copy reaches on MI355X (MI355X_MICROARCH.md)
+CHAIN_NS = {                                        # ns per serial SNP step of ONE chain, per-phase work included
+    ("spike_slab", "exact"): 135.0, ("spike_slab", "fast"): 95.0,
+    ("mixture", "exact"): 420.0, ("mixture", "fast"): 330.0,          # K = 4 (lane-parallel softmax chain)
+    ("grid", "exact"): 430.0, ("grid", "fast"): 420.0,                # 32 models per step
+    ("spike_slab_f64", "exact"): 300.0,                                # estep_tile.h: 237 ns + 4 us per panel
+}
+CHAINS_IN_FLIGHT = {"spike_slab": 512, "mixture": 512, "grid": 256, "spike_slab_f64": 256}
+
+
+def sweep_time_model(sizes, algo_bytes, model, math_mode, f64=False):
+    """max(bytes / 6.3 TB/s, largest block's chain, total chain work / chains in flight) in ms, and which term it is."""
+    key = "spike_slab_f64" if f64 else model
+    ns = CHAIN_NS.get((key, math_mode), CHAIN_NS[(key, "exact")])
+    sizes = np.asarray(sizes, dtype=np.float64)
+    terms = {"hbm_stream": algo_bytes / (STREAM_GBS * 1e9) * 1e3,
+             "largest_block_chain": float(sizes.max()) * ns * 1e-6 if sizes.size else 0.0,
+             "chain_throughput": float(sizes.sum()) * ns * 1e-6 / CHAINS_IN_FLIGHT[key]}
+    bound = max(terms, key=terms.get)
+    return terms[bound], bound, ns, terms
+
+
+def pmc_traffic(key):
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(prof)).get(key)
+    except Exception:
+        return None
+
+
+def measure_secondary(name, sw, steps, barrier, math_mode="exact", traffic_key=None):
+    """One secondary configuration on one GPU: K timed steps, kernel time from the library's HIP events; with the
+    time model of the sweep (what bounds it and how close the kernel is: `frac_of_model`) and the PMC traffic."""
     el = sw.run(steps, 3, barrier)
     k = sw.plan.timing_history(which=1)
+    k_all = sw.plan.timing_history(which=0)
     by = sw.algorithmic_bytes()
+    f64 = sw.state_itemsize != 4
+    t_model, bound, ns, terms = sweep_time_model(np.diff(sw.ld.block_start), by, sw.model, math_mode, f64)
+    k_avg = float(np.mean(k))
     out = {"name": name, "value": sw.ld.m * steps / el, "unit": "SNP-updates/s", "ms_per_step": el / steps * 1e3,
-           "kernel_ms_avg": float(np.mean(k)), "kernel_ms_p50": pct(k, 50),
-           "roofline_frac": by / (float(np.mean(k)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "algorithmic_bytes_per_launch": int(by), "steps": steps}
+           "kernel_ms_avg": k_avg, "kernel_ms_p50": pct(k, 50), "all_kernels_ms_avg": float(np.mean(k_all)) if k_all else None,
+           "roofline_frac": by / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": int(by), "steps": steps, "math_mode": math_mode,
+           "time_model_ms": t_model, "time_model_bound": bound, "time_model_terms_ms": terms,
+           "chain_ns_per_snp_model": ns, "frac_of_model": t_model / float(np.mean(k_all) if k_all else k_avg)}
+    tr = pmc_traffic(traffic_key) if traffic_key else None
+    out["traffic"] = tr
+    out["traffic_over_algorithmic"] = (tr / by) if tr else None
     if sw.model == "grid":
         out["snp_x_model_updates_per_s"] = out["value"] * sw.width
     return out
+
+
+def chain_ns_per_snp(args, device, math_mode, low_memory=False, size=6000, steps=10):
+    """Measured ns per serial chain step: one isolated LD block of `size` SNPs (nothing else on the chip), sweep time / size."""
+    from viprs_amd.utils import synthetic as syn
+
+    class A:
+        math = math_mode
+    ld, ss, inp = syn.make_problem(sizes=[size], low_memory=low_memory, seed=3)
+    sw = Sweep(A, ld, ss, inp, device, "spike_slab", 1, low_memory)
+    sw.run(steps, 3, lambda: None)
+    k = sw.plan.timing_history(which=1)
+    sw.close()
+    return float(np.median(k)) * 1e6 / size
+
+
+def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exact"):
+    """One EM iteration of VIPRS / VIPRSMix(K=4) / VIPRSGrid(32 models, batched) on the workload's LD: what
+    VIPRS.fit() does per iteration (VIPRS.py:979-1019: e_step, m_step, ELBO + stopping rules).
+    `ms_per_iteration` = wall time of `iters` free-running iterations of fit() from the standard start (after `warm`
+    iterations), / iters; `split_ms` = the same iteration taken apart with a device synchronisation between the phases
+    (which the free-running loop does not have): prep + sweep enqueue-to-idle, the sweep kernel alone (HIP events), the
+    device reduction of the partial sums + its read-back, the host's M-step / ELBO / stopping rules."""
+    from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
+    from viprs_amd.model import VIPRS, VIPRSMix
+    gdl = ArrayDataLoader({1: LDArrays(symmetric=(ld.ld_left_bound, ld.ld_indptr, ld.ld_data), dq_scale=ld.dq_scale)},
+                          {1: SumstatsArrays(ss.std_beta, ss.n_per_snp)}, n=float(ss.n))
+    stamps = []
+    cb = lambda i: stamps.append(time.perf_counter())
+    out = {"name": f"fit_iteration {kind}", "unit": "ms per EM iteration", "iterations": iters, "warmup_iterations": warm,
+           "math_mode": math_mode, "snps": int(ld.m)}
+    if kind.startswith("VIPRSGrid"):
+        from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+        from viprs_amd.model.gridsearch.VIPRSGrid import VIPRSGrid
+        grid = HyperparameterGrid(n_snps=gdl.m)
+        grid.generate_pi_grid(steps=8)
+        grid.generate_sigma_epsilon_grid(steps=4)
+        model = VIPRSGrid(gdl, grid, low_memory=False, device=device, math_mode=math_mode)
+        model.fit(max_iter=warm + iters, min_iter=warm + iters + 1, batched=True, on_iteration=cb)
+        plan = next(iter(model._plans.values()))
+        out["models"] = int(model.n_models)
+    else:
+        model = (VIPRSMix(gdl, K=4, low_memory=False, device=device, math_mode=math_mode) if kind.startswith("VIPRSMix")
+                 else VIPRS(gdl, low_memory=False, device=device, math_mode=math_mode))
+        model.fit(max_iter=warm + iters, min_iter=warm + iters + 1, on_iteration=cb)
+        plan = next(iter(model._plans.values()))
+    if len(stamps) != warm + iters:
+        raise RuntimeError(f"{kind}: fit() ran {len(stamps)} of {warm + iters} iterations")
+    d = np.diff(np.array(stamps))[warm - 1:]                               # iterations warm+1 .. warm+iters
+    out["ms_per_iteration"] = float(np.median(d)) * 1e3                    # (median: the host loop is Python, a GC pause is not the iteration)
+    out["ms_per_iteration_mean"] = float(np.mean(d)) * 1e3
+    out["ms_per_iteration_all"] = [round(float(x) * 1e3, 4) for x in d]
+    k = plan.timing_history(which=0)
+    out["sweep_kernels_ms_avg"] = float(np.mean(k[-iters:])) if k else None
+    out["skipped_snps_last_sweep"] = int(plan.last_skipped())
+    if not kind.startswith("VIPRSGrid"):
+        # the same iteration, phase by phase (continuing the same trajectory)
+        sync = lambda: _lib_sync(device)
+        ph = np.zeros(4)
+        n2 = max(5, iters // 2)
+        plan.timing_reset()
+        for _ in range(n2):
+            t0 = time.perf_counter()
+            model.e_step()
+            sync()
+            t1 = time.perf_counter()
+            model._reduce()
+            t2 = time.perf_counter()
+            model.m_step()
+            model.update_theta_history()
+            t3 = time.perf_counter()
+            ph += (t1 - t0, 0.0, t2 - t1, t3 - t2)
+        kk = plan.timing_history(which=0)
+        sweep = float(np.mean(kk)) if kk else 0.0
+        ph = ph / n2 * 1e3
+        out["split_ms"] = {"prep_launch_sync": max(0.0, ph[0] - sweep), "sweep_kernels": sweep, "sums_reduce_readback": ph[2],
+                           "host_mstep_elbo_rules": ph[3], "sum_with_syncs": float(ph[0] + ph[2] + ph[3])}
+    try:
+        model.close()
+    except Exception:
+        pass
+    return out
+
+
+def _lib_sync(device):
+    from viprs_amd import _lib
+    _lib.check(_lib.lib.viprs_device_synchronize(device))
 
 
 def per_rank(comm, rank, world, x):
@@ -515,6 +645,10 @@ def main():
     achieved = float(bytes_ranks.sum()) / (k_max_ms * 1e-3) / 1e9
     model_ms = float(np.max(model_ranks))
 
+    chain_ns = None
+    if world == 1 and args.model == "spike_slab" and args.precision == "float32" and not args.no_secondary:
+        chain_ns = chain_ns_per_snp(args, device, args.math, args.low_memory)     # isolated 6 000-SNP block
+
     # ---- secondary measurements -----------------------------------------------------------------------------
     secondary = []
     weak = None
@@ -522,10 +656,11 @@ def main():
         half = max(5, args.steps // 2)
         if world == 1 and not args.low_memory and args.ld_dtype == "float32" and args.config != "cfg1":
             # configs[3] / configs[4] on the LD plan that is already resident (symmetric fp32)
+            cfgk = args.config
             for model2, w2, nm in (("mixture", 4, "configs[3]: sparse mixture prior K=4, symmetric fp32 LD"),
                                    ("grid", 32, "configs[4]: grid of 32 (sigma_eps x pi) models batched per SNP, symmetric fp32 LD")):
                 sw2 = Sweep(args, ld, ss, inp, device, model2, w2, False, plan=sw.plan)
-                secondary.append(measure_secondary(nm, sw2, half, barrier))
+                secondary.append(measure_secondary(nm, sw2, half, barrier, args.math, f"{cfgk}_float32_sym_{model2}{w2}"))
                 sw2.close()
             # the reference's DEFAULT LD form (low_memory=True, VIPRS.py:75): upper-triangular store + second pass;
             # fp32, and int8 (dq_scale = 1/127): the format of the reference's published LD stores (docs/download_ld.md:6-10)
@@ -533,16 +668,37 @@ def main():
                             (np.dtype("int8"), "upper-triangular int8 LD (low_memory=True + the published store format), spike-and-slab")):
                 ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, dt2)
                 sw_u = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True)
-                secondary.append(measure_secondary(nm, sw_u, half, barrier))
+                secondary.append(measure_secondary(nm, sw_u, half, barrier, args.math, f"{cfgk}_{dt2.name}_upper"))
                 if dt2.itemsize == 1:
                     # float_precision='float64' (VIPRS.py:72) on the same plan: the panel-walking kernels of estep_tile.h
                     sw_d = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan, precision="float64")
                     secondary.append(measure_secondary("float64 state (float_precision='float64'), upper-triangular int8 LD, spike-and-slab",
-                                                       sw_d, half, barrier))
+                                                       sw_d, half, barrier, "exact", f"{cfgk}_int8_upper_f64"))
                     secondary[-1]["dtype"] = "f64"
                     sw_d.close()
+                if args.math == "exact":
+                    # math_mode = fast (v_exp_f32 / v_rcp_f32 sigmoid; deviations of the size a one-ulp change of the inputs
+                    # causes, tests/test_gpu_fast_math.py) on the same plan and inputs: the chain step is what changes
+                    sw_f = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan)
+                    sw_u.plan.set_math_mode("fast")
+                    secondary.append(measure_secondary("math_mode=fast: " + nm, sw_f, half, barrier, "fast"))
+                    sw_u.plan.set_math_mode("exact")
+                    secondary[-1]["chain_ns_per_snp"] = chain_ns_per_snp(args, device, "fast", True)
+                    sw_f.close()
                 sw_u.close()
                 del ld_u, sw_u
+            if args.math == "exact":
+                sw_f = Sweep(args, ld, ss, inp, device, "spike_slab", 1, False, plan=sw.plan)
+                sw.plan.set_math_mode("fast")
+                secondary.append(measure_secondary("math_mode=fast: symmetric fp32 LD, spike-and-slab (the headline configuration)",
+                                                   sw_f, half, barrier, "fast"))
+                sw.plan.set_math_mode("exact")
+                secondary[-1]["chain_ns_per_snp"] = chain_ns_per_snp(args, device, "fast", False)
+                sw_f.close()
+            # the EM iteration around the sweep (VIPRS.py:979-1019): what a user of fit() pays per iteration
+            if args.config in ("cfg3", "cfg2"):
+                for kind in ("VIPRS", "VIPRSMix(K=4)", "VIPRSGrid(32 models, batched)"):
+                    secondary.append(measure_fit_iteration(kind, ld, ss, device, math_mode=args.math))
         if strong:
             # weak scaling beside it: every rank sweeps a whole genome-scale workload of its own
             sw.close()
@@ -610,6 +766,7 @@ def main():
                                 if strong else f"one workload per GPU x{n_gpus}") if n_gpus > 1 else "single GPU",
                 "step": "device state re-init + one E-step sweep over all blocks",
                 "time_model_ms": model_ms,
+                "chain_ns_per_snp": chain_ns if world == 1 else None,
                 "secondary": secondary or None,
             },
             "roofline": {

@@ -265,3 +265,18 @@ def test_bare_bench_refuses_more_ranks_than_devices_and_mismatched_world(tmp_pat
     r = _run_bare_bench(tmp_path, ["--gpus", "4", "--steps", "2", "--warmup", "1", "--config", "cfg1", "--cpu-seconds", "0"],
                         ndev=4, env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE=2" in r.stderr
+
+
+def test_sweep_time_model_names_its_bound():
+    """Secondaries carry the time model of their sweep: max(bytes / copy rate, largest block's chain, total chain
+    work / chains in flight) -- a reader can tell "chain-bound at 90 % of its floor" from "3 x off"."""
+    sizes = bench.config_sizes("cfg3", 7209)
+    by = 4 * int((sizes.astype(np.int64) ** 2).sum()) + 68 * int(sizes.sum())
+    t, bound, ns, terms = bench.sweep_time_model(sizes, by, "spike_slab", "exact")
+    assert bound == "hbm_stream" and t == pytest.approx(by / 6.3e12 * 1e3) and ns == 135.0
+    t8, bound8, _, terms8 = bench.sweep_time_model(sizes, by // 4, "spike_slab", "exact")       # int8 LD: the chain of the largest block
+    assert bound8 == "largest_block_chain" and t8 == pytest.approx(sizes.max() * 135e-6)
+    tf, boundf, nsf, _ = bench.sweep_time_model(sizes, by // 4, "spike_slab", "fast")
+    assert nsf < ns and tf < t8
+    tg, boundg, _, _ = bench.sweep_time_model(sizes, by, "grid", "exact")
+    assert boundg == "chain_throughput" and tg == pytest.approx(sizes.sum() * 430e-6 / 256)

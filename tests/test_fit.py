@@ -44,10 +44,10 @@ def loader_from_fixture(fx):
     return ArrayDataLoader(ld, ss, n=float(fx["n"]))
 
 
-def build_model(fx, comm=None, e_step="oracle"):
+def build_model(fx, comm=None, e_step="oracle", math_mode="exact"):
     from viprs_amd.model import VIPRS, VIPRSMix
     K = int(fx["K"])
-    kw = dict(low_memory=bool(fx["low_memory"]), comm=comm,
+    kw = dict(low_memory=bool(fx["low_memory"]), comm=comm, math_mode=math_mode,
               dequantize_on_the_fly=bool(fx["dequantize_on_the_fly"]) if "dequantize_on_the_fly" in fx else False,
               float_precision=str(fx["float_precision"]) if "float_precision" in fx else "float32")
     if not np.isnan(float(fx["fix_sigma_epsilon"])):

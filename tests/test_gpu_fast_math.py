@@ -1,0 +1,161 @@
+"""GPU: `math_mode="fast"` (v_exp_f32 / v_rcp_f32 instead of the reference's glibc expf and double divide,
+e_step.hpp:245-261, :222-241) as a first-class mode -- on LD whose far field matters, team blocks, both LD forms,
+int8 LD, the K = 4 mixture and the grid (batched matrix-core kernel and item schedule).
+
+What can be asserted.  The north-star tolerance -- 1e-5 relative per entry -- is asserted where the problem is
+well conditioned (analytic AR(1) blocks: `test_fast_math_well_conditioned`).  On far-field LD it cannot hold for ANY
+arithmetic other than the bit-identical one, and the tests say so with a measurement instead of a looser constant:
+the REFERENCE ITSELF (the oracle, exact arithmetic) moves by up to 7e-4 relative in var_gamma and 4e-3 in eta when its
+own input `std_beta` is changed by +-1 ulp (the sigmoid's argument is u^2 + ulog with u^2 up to 10^3, and q is ~10 x
+beta - q: a relative change of 1e-7 in q becomes 1e-4 in the logit).  So every far-field case computes that yardstick
+with the oracle -- error quantiles of "oracle on inputs perturbed by one ulp" against the oracle -- and asserts that
+the fast mode's error quantiles stay within a small factor of it: fast mode is as close to the reference as the
+reference is to itself under the smallest possible change of its inputs.  Skip-branch flips (e_step.hpp:410-413) are
+counted and bounded the same way.  The exact mode stays the default and stays `==` (tests/test_gpu_farfield.py).
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers as H
+from tests.test_gpu_farfield import _run_grid, _run_mix, assert_far_field_matters
+from tests.test_oracle_vs_ref import _grid_inputs, _mixture_inputs
+from viprs_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+QUANTILES = (50.0, 99.0, 99.9)
+FACTOR = 3.0          # fast-mode error quantiles vs the one-ulp yardstick's
+FACTOR_MAX = 10.0     # the maximum is a single entry (whichever value sits closest to 0): a looser factor
+FLOOR = 1e-5          # the north-star tolerance: errors below it pass whatever the yardstick says
+
+
+def rel_err(got, ref):
+    g, r = got.astype(np.float64).ravel(), ref.astype(np.float64).ravel()
+    scale = float(np.max(np.abs(r))) if r.size else 0.0
+    return np.abs(g - r) / np.maximum(np.abs(r), 1e-7 * scale + 1e-300)
+
+
+def one_ulp(inp, seed=1):
+    """The inputs with std_beta moved by one ulp up or down (a random sign per SNP)."""
+    out = copy.copy(inp)
+    sgn = np.random.default_rng(seed).integers(0, 2, inp.std_beta.shape[0]) * 2 - 1
+    up = np.nextafter(inp.std_beta, np.float32(np.inf))
+    dn = np.nextafter(inp.std_beta, np.float32(-np.inf))
+    out.std_beta = np.where(sgn > 0, up, dn).astype(np.float32)
+    return out
+
+
+def assert_within_one_ulp_yardstick(fast, ref, ulp, what):
+    """`fast` (HIP, math_mode=fast) against `ref` (oracle), judged by `ulp` (oracle on one-ulp-perturbed inputs)."""
+    report = []
+    flips_fast, flips_ulp = H.branch_flips(fast, ref), H.branch_flips(ulp, ref)
+    assert flips_fast <= 2 * flips_ulp + 3, f"{what}: {flips_fast} skip-branch flips (one-ulp yardstick: {flips_ulp})"
+    for k in H.STATE:
+        ef, eu = rel_err(fast[k], ref[k]), rel_err(ulp[k], ref[k])
+        for qt in QUANTILES:
+            a, b = np.percentile(ef, qt), np.percentile(eu, qt)
+            assert a <= max(FACTOR * b, FLOOR), f"{what}: {k} p{qt} error {a:.2e}, one-ulp yardstick {b:.2e}"
+        assert ef.max() <= max(FACTOR_MAX * eu.max(), FLOOR), f"{what}: {k} max error {ef.max():.2e}, yardstick {eu.max():.2e}"
+        report.append(f"{k} p99.9 {np.percentile(ef, 99.9):.1e}/{np.percentile(eu, 99.9):.1e} n>1e-5 {int((ef > 1e-5).sum())}/{int((eu > 1e-5).sum())}")
+    print(f"[fast math] {what}: flips {flips_fast} (yardstick {flips_ulp}); fast/yardstick " + "; ".join(report))
+
+
+@pytest.fixture
+def fast_mode():
+    from viprs_amd.vi import e_step_hip as S
+    S.set_default_math_mode("fast")
+    yield S
+    S.set_default_math_mode("exact")
+
+
+SS_CASES = [
+    ([700, 1400, 90], "longrange", np.float32, 2),           # single workgroups
+    ([1700, 2400, 65], "longrange", np.float32, 2),          # teams
+    ([3619, 650, 1536], "longrange", np.float32, 2),         # cfg3's largest block
+    ([6000, 77], "longrange", np.float32, 1),                # BASELINE's clip limit
+    ([1700, 650], "sample", np.float32, 2),
+    ([2400, 3619], "longrange", np.int8, 2),
+]
+
+
+@pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
+@pytest.mark.parametrize("sizes, kind, ld_dtype, sweeps", SS_CASES,
+                         ids=[f"{'-'.join(map(str, c[0]))}_{c[1]}_{np.dtype(c[2]).name}" for c in SS_CASES])
+def test_spike_slab_fast_far_field(gpu, fast_mode, sizes, kind, ld_dtype, sweeps, low_memory):
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=61, kind=kind)
+    assert_far_field_matters(ld, inp)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=sweeps)
+    ulp = H.run_oracle(ld, one_ulp(inp), st0, sweeps=sweeps)
+    fast = H.run_hip(ld, inp, st0, sweeps=sweeps)
+    assert not all(np.array_equal(fast[k], ref[k]) for k in H.STATE), "fast mode did not run (results are bit-identical)"
+    assert_within_one_ulp_yardstick(fast, ref, ulp, f"spike-and-slab {sizes} {kind} {np.dtype(ld_dtype).name} "
+                                                    f"{'upper' if low_memory else 'symmetric'}")
+
+
+@pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
+@pytest.mark.parametrize("sizes, ld_dtype", [([700, 1400, 1700, 2400], np.float32), ([1400, 2400], np.int8)],
+                         ids=["f32", "int8"])
+def test_mixture_k4_fast_far_field(gpu, fast_mode, sizes, ld_dtype, low_memory):
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=62, kind="longrange")
+    mix, st0 = _mixture_inputs(ld, ss, 4)
+    ref = _run_mix(O, ld, inp, mix, st0, 2)
+    ulp = _run_mix(O, ld, one_ulp(inp), mix, st0, 2)
+    fast = _run_mix(fast_mode, ld, inp, mix, st0, 2)
+    assert not all(np.array_equal(fast[k], ref[k]) for k in H.STATE)
+    assert_within_one_ulp_yardstick(fast, ref, ulp, f"mixture K=4 {sizes} {'upper' if low_memory else 'symmetric'}")
+
+
+@pytest.mark.parametrize("mfma", ["1", "0"], ids=["mfma", "items"])
+@pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
+def test_grid_fast_far_field(gpu, fast_mode, low_memory, mfma, monkeypatch):
+    monkeypatch.setenv("VIPRS_GRID_MFMA", mfma)
+    ld, ss, inp = syn.make_problem(sizes=[700, 1400, 1700], low_memory=low_memory, seed=63, kind="longrange")
+    g, st0 = _grid_inputs(ld, ss, 32)
+    active = np.arange(0, 32, 5, dtype=np.int32)
+    take = lambda st: {k: v[:, active] for k, v in st.items()}
+    ref = take(_run_grid(O, ld, inp, g, st0, active, 2))
+    ulp = take(_run_grid(O, ld, one_ulp(inp), g, st0, active, 2))
+    fast = take(_run_grid(fast_mode, ld, inp, g, st0, active, 2))
+    assert not all(np.array_equal(fast[k], ref[k]) for k in H.STATE)
+    assert_within_one_ulp_yardstick(fast, ref, ulp, f"grid G=32 ({'batched' if mfma == '1' else 'items'}) "
+                                                    f"{'upper' if low_memory else 'symmetric'}")
+
+
+@pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
+def test_fast_math_well_conditioned(gpu, fast_mode, low_memory):
+    """AR(1) blocks (|q| << |beta|), three sweeps: 99 % of the entries of the posterior arrays within the north-star
+    tolerance 1e-5, every entry within 3e-5."""
+    ld, ss, inp = syn.make_problem(sizes=[700, 300, 1700], low_memory=low_memory, seed=12)
+    st0 = inp.state_copy()
+    ref = H.run_oracle(ld, inp, st0, sweeps=3)
+    fast = H.run_hip(ld, inp, st0, sweeps=3)
+    assert H.branch_flips(fast, ref) <= 3
+    for k in H.STATE:
+        e = rel_err(fast[k], ref[k])
+        assert np.percentile(e, 99.0) <= 1e-5, f"{k}: p99 {np.percentile(e, 99.0):.2e}"
+        # every entry: 3e-5 relative, entries that cancel to ~0 judged against 1e-2 of the array's largest value
+        scale = float(np.max(np.abs(ref[k])))
+        err = np.abs(fast[k].astype(np.float64) - ref[k].astype(np.float64))
+        assert np.all(err <= 3e-5 * np.maximum(np.abs(ref[k]), 1e-2 * scale)), f"{k}: worst {err.max():.2e} (scale {scale:.2e})"
+
+
+def test_fit_fixtures_in_fast_mode(gpu):
+    """The fit trajectories captured from the reference (tests/golden/fit_*.npz, fp32 state) reproduced with
+    math_mode="fast" at the SAME tolerances as the exact mode: iteration counts, stopping messages, ELBO history
+    (2e-7 relative), hyper-parameters, posterior (2e-3) and pseudo-R2."""
+    from tests.test_fit import FIT, build_model, check_against_fixture
+    n = 0
+    for path in FIT:
+        fx = np.load(path)
+        if "float_precision" in fx and str(fx["float_precision"]) != "float32":
+            continue                                   # a float64 state has one arithmetic (estep_tile.h)
+        model, theta = build_model(fx, e_step="hip", math_mode="fast")
+        assert all(p.math_mode == "fast" for p in model._plans.values())
+        model.fit(max_iter=60, theta_0=theta)
+        check_against_fixture(model, fx, pi_rtol=2e-3 if int(fx["K"]) else 2e-4)
+        n += 1
+    assert n >= 7

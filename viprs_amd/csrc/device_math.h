@@ -120,16 +120,27 @@ __device__ __forceinline__ float sigmoid_exact(float x, const ExpTab& tab, int s
     return (float)div_unit_range(num, 1.0 + ed);
 }
 
-// Hardware-transcendental variant (VIPRS_MATH_FAST): v_exp_f32 with a compensated x*log2(e)
-// product and v_rcp_f32; a few ulp from sigmoid_exact.
-__device__ __forceinline__ float sigmoid_fast(float x) {
-    const float t = -fabsf(x);
+// Hardware-transcendental variants (math_mode = fast, VIPRS_MATH_FAST): exp(x) for x <= 0 as v_exp_f32 of a
+// COMPENSATED x * log2(e) product -- p = fl(t * L_hi) goes to v_exp_f32 at once, the product's rounding error and the
+// low part of log2(e) come back in as a first-order correction e0 * (1 + ln2 * perr), whose factor is computed while
+// the transcendental unit works: TWO dependent instructions besides v_exp_f32 itself (the product and one fma).
+// Error: v_exp_f32's 1 ulp + 2^-23 -- a few 1e-7 relative for every argument (an uncompensated product is off by
+// |x| * 1e-7, 1e-5 at x = -100), against 1e-5 allowed.  Arguments below -126 / log2(e) give denormal or zero
+// results like expf's (v_exp_f32 flushes at 2^-126: below the resolution of anything the E-step adds them to).
+__device__ __forceinline__ float expf_fast_nonpos(float t) {
     const float L_hi = 0x1.715476p+0f;         // log2(e) rounded to float
     const float L_lo = 0x1.4ae0cp-26f;         // log2(e) - L_hi
     const float p = t * L_hi;
     const float perr = __builtin_fmaf(t, L_lo, __builtin_fmaf(t, L_hi, -p));
+    const float k = perr * 0x1.62e43p-1f;      // ln2 * perr (off the critical path)
     const float e0 = __builtin_amdgcn_exp2f(p);
-    const float e = __builtin_fmaf(e0 * 0x1.62e43p-1f, perr, e0);
+    return __builtin_fmaf(e0, k, e0);
+}
+
+// sigmoid (e_step.hpp:245-261) on the hardware units: v_exp_f32 + v_rcp_f32 (1 ulp each), fp32 throughout -- a few
+// ulp from sigmoid_exact (which follows the reference's double add and divide), inside the 1e-5 tolerance.
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    const float e = expf_fast_nonpos(-fabsf(x));
     const float num = (x < 0.0f) ? e : 1.0f;
     return num * __builtin_amdgcn_rcpf(1.0f + e);
 }

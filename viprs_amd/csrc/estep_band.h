@@ -122,7 +122,8 @@ __device__ __forceinline__ void band_strip(const U* __restrict__ ld, const BandR
 // The mixture model with the K components of a SNP evaluated one after the other in the SNP's own lane
 // (MixtureModel's lane-per-SNP update / finish: the same arithmetic as its lane-parallel chain in the
 // panel kernels, K + 1 expf and K divides per step instead of one each).
-struct MixtureSerialModel : MixtureModel {
+template <bool EXACT = true>
+struct MixtureSerialModel : MixtureModel<EXACT> {
     static constexpr bool kLaneParallel = false;
 };
 

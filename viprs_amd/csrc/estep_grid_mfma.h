@@ -228,7 +228,7 @@ __device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)
 }
 
 // ---- the chain wave's work for one panel: 64 serial SNP updates for all models ------------------------------
-template <bool SYM>
+template <bool SYM, bool EXACT = true>
 __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, float* io, float* la, float* dg, float* qx, int p, int b,
                                                  int64_t s0, int lane, int n_models, float dq, const ExpTab& tab
 #ifdef VIPRS_GRID_PROFILE
@@ -301,7 +301,7 @@ __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, floa
             const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
             const float mu = mm * (beta - qcur);                         // e_step.hpp:613
             const float u = ulog + hvt * mu * mu;                        // :616
-            const float gamma = sigmoid_exact<kLookupPerLane>(u, tab);   // :617
+            const float gamma = EXACT ? sigmoid_exact<kLookupPerLane>(u, tab) : sigmoid_fast(u);   // :617
             const float d = gamma * mu - eta_old;                        // :620
             const float a = (live && has_model) ? dq * d : 0.0f;
             // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order)
@@ -362,7 +362,7 @@ __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, floa
 // NEXT SNP needs (column jj+1) is read from the accumulators before this step's MFMAs are issued -- the previous step's
 // have long completed -- and gets row jj by one VALU fma with D[jj][jj+1] from a v_readlane; the matrix core applies the
 // same fma to the accumulator's copy.  Fully unrolled (the register <-> column map of the accumulators is fixed).
-template <bool SYM>
+template <bool SYM, bool EXACT = true>
 __device__ __forceinline__ void grid_chain_panel_mfma(const EStepArgs<float>& A, float* io, float* la, float* dg, float* qx, int p,
                                                       int b, int64_t s0, int lane, int n_models, float dq, const ExpTab& tab) {
     const int cg = lane & 31, ch = lane >> 5;
@@ -404,7 +404,7 @@ __device__ __forceinline__ void grid_chain_panel_mfma(const EStepArgs<float>& A,
         const float beta = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, betav), jj));
         const float mu = mm * (beta - qcur);                         // e_step.hpp:613
         const float u = ulog + hvt * mu * mu;                        // :616
-        const float gamma = sigmoid_exact<kLookupPerLane>(u, tab);   // :617
+        const float gamma = EXACT ? sigmoid_exact<kLookupPerLane>(u, tab) : sigmoid_fast(u);   // :617
         const float d = gamma * mu - eta_old;                        // :620
         const float a = (live && has_model) ? dq * d : 0.0f;
         const float dsub = (SYM && live && has_model) ? d : 0.0f;
@@ -646,7 +646,7 @@ __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __rest
     }
 }
 
-template <typename U, bool SYM>
+template <typename U, bool SYM, bool EXACT>
 __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, float* io, float* la, float* dg, f32x4* cy,
                                                     float* qx, const int* s_act, const BlockDesc& bd, int wave, int lane,
                                                     int n_models, float dq, const ExpTab& tab) {
@@ -725,9 +725,9 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
             __syncthreads();                                        // mid: the carry has put panel p into qx
             if (p < np) {
 #ifdef VIPRS_GRID_MFMA_CHAIN
-                grid_chain_panel_mfma<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
+                grid_chain_panel_mfma<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
 #else
-                grid_chain_panel<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
+                grid_chain_panel<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
 #ifdef VIPRS_GRID_PROFILE
                                       , 1, nullptr
 #endif
@@ -886,7 +886,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     }
 }
 
-template <typename U, bool SYM>
+template <typename U, bool SYM, bool EXACT>
 __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, int resident_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* io = smem;                                   // [2][4][32][65]: mm, ulog, hvt, eta -> mu, gamma, d, eta'
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
         const BlockDesc bd = A.blocks[blk];
         if (bd.size <= resident_max) {
             // q of the whole block fits the updater waves' accumulator registers: resident form (above)
-            grid_block_resident<U, SYM>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
+            grid_block_resident<U, SYM, EXACT>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
             continue;
         }
         const int64_t s0 = bd.start;
@@ -1026,9 +1026,9 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
                 // ---- (2) chain: 64 serial SNP updates for all models
                 if (p < np) {
 #ifdef VIPRS_GRID_MFMA_CHAIN
-                    grid_chain_panel_mfma<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
+                    grid_chain_panel_mfma<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
 #else
-                    grid_chain_panel<SYM>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
+                    grid_chain_panel<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
 #ifdef VIPRS_GRID_PROFILE
                                           , blk, &s_prof[0][0]
 #endif

@@ -356,7 +356,8 @@ struct SpikeSlabModel {                      // e_step, e_step.hpp:387-433
 // One column of e_step_grid (e_step.hpp:599-635): models of a grid are independent, so the host runs
 // this policy once per active model with the (m, G) column-major arrays offset to that column.
 // Different arithmetic from e_step: no fma in mu / the logit / d, half_var_tau instead of its
-// square root, no skip branch.
+// square root, no skip branch.  EXACT = false (math_mode = fast): the sigmoid on v_exp_f32 / v_rcp_f32.
+template <bool EXACT = true>
 struct GridColumnModel {
     static constexpr bool kLaneParallel = false;
     struct In { float mm, beta, hvt, ulog, eta_old; };
@@ -374,7 +375,7 @@ struct GridColumnModel {
                                                 float& d, int sel) {
         mu = in.mm * (in.beta - q);                                       // :613
         const float u = in.ulog + in.hvt * mu * mu;                       // :616
-        gamma = sigmoid_exact<LOOKUP>(u, tab, sel);                       // :617
+        gamma = EXACT ? sigmoid_exact<LOOKUP>(u, tab, sel) : sigmoid_fast(u);   // :617
         d = gamma * mu - in.eta_old;                                      // :620
     }
     static constexpr bool kHasSkip = false;
@@ -407,8 +408,23 @@ struct GridColumnModel {
     }
 };
 
+// exp(x), x <= 0, of the softmax (e_step.hpp:231-240): glibc's expf bit for bit, or v_exp_f32 (math_mode = fast)
+template <bool EXACT, int LOOKUP>
+__device__ __forceinline__ float softmax_exp(float x, const ExpTab& tab, int sel = 0) {
+    if constexpr (EXACT) return expf_glibc_nonpos<LOOKUP>(x, tab, sel);
+    else return expf_fast_nonpos(x);
+}
+// e / ssum of the softmax (:239): the IEEE fp32 divide, or e * v_rcp_f32(ssum) (math_mode = fast; 1 ulp + 1 rounding)
+template <bool EXACT>
+__device__ __forceinline__ float softmax_div(float e, float ssum) {
+    if constexpr (EXACT) return e / ssum;
+    else return e * __builtin_amdgcn_rcpf(ssum);
+}
+
 // e_step_mixture (e_step.hpp:496-537) for K <= kPanelMaxK components ((m, K) arrays C-ordered).
+template <bool EXACT = true>
 struct MixtureModel {
+    static constexpr bool kExact = EXACT;
     // the chain evaluates the K + 1 components of ONE SNP on K + 1 lanes (see the chain in panel_role)
     static constexpr bool kLaneParallel = true;
     struct In { float mm[kPanelMaxK], sv[kPanelMaxK], ulog[kPanelMaxK]; float lnp, beta, eta_old; int K; };
@@ -445,16 +461,16 @@ struct MixtureModel {
 #pragma unroll
         for (int k = 0; k < kPanelMaxK; ++k) {
             if (k < in.K) {
-                u[k] = expf_glibc_nonpos<LOOKUP>(u[k] - mx, tab, sel);
+                u[k] = softmax_exp<EXACT, LOOKUP>(u[k] - mx, tab, sel);
                 ssum += u[k];
             }
         }
-        ssum += expf_glibc_nonpos<LOOKUP>(in.lnp - mx, tab, sel);
+        ssum += softmax_exp<EXACT, LOOKUP>(in.lnp - mx, tab, sel);
         d = -in.eta_old;                                                  // :519
 #pragma unroll
         for (int k = 0; k < kPanelMaxK; ++k) {
             if (k < in.K) {
-                gam[k] = u[k] / ssum;                                     // :239
+                gam[k] = softmax_div<EXACT>(u[k], ssum);                  // :239
                 d = __builtin_fmaf(gam[k], mu[k], d);                     // :523
             }
         }
@@ -905,7 +921,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             mx = dpp_max_shr<4>(mx);
                             mx = dpp_max_shr<8>(mx);
                             mx = rl(mx, K);                                                    // c_max, :58-71
-                            const float e = expf_glibc_nonpos<kLookupPerLane>(u - mx, tab);
+                            const float e = softmax_exp<MODEL::kExact, kLookupPerLane>(u - mx, tab);
                             // softmax denominator, :231-240: s = ((e_0 + e_1) + ...) + e_null in this order.
                             // Lane k adds its e to lane k-1's running sum; after k rounds lane k is final
                             // and stays so: ROUNDS >= K rounds, no K-dependent branch inside the step.
@@ -913,7 +929,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #pragma unroll
                             for (int it = 0; it < ROUNDS; ++it) ssum = e + dpp_shr<1>(ssum, 0.0f);
                             ssum = rl(ssum, K);
-                            const float gam = e / ssum;                                        // :239
+                            const float gam = softmax_div<MODEL::kExact>(e, ssum);             // :239
                             // eta_diff, :519-523: d_k = fma(gam_k, mu_k, d_{k-1}), d_{-1} = -eta_old, same scheme
                             // (lane 0 of `dprev` is never written by the shift and keeps -eta_old)
                             float d = -eta_old, dprev = -eta_old;
@@ -992,8 +1008,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             const float dr = Dt[jj * kPanel];
                             const float d = MODEL::template delta<kLookupLane>(in, qf, tab, jj);
                             const float dz = (MODEL::kHasSkip && fabsf(d) < Eps<float>::value) ? 0.0f : d;   // :410
+                            // a = dq * d is formed per lane BEFORE the broadcast (same operands for the step's own lane, same
+                            // bits): the dependent chain is select -> mul -> v_readlane -> fma with the SGPR as the fma's
+                            // operand, not v_readlane -> v_mov -> mul -> fma; the second broadcast (d itself, for the
+                            // symmetric form's diagonal subtraction) hangs off the side
+                            const float az = dq * dz;
+                            const float sa = rl(az, jj);
                             const float sdz = rl(dz, jj);
-                            const float sa = dq * sdz;
                             qcap_v = sel_mask(qcap_v, qc, lane_bit);
                             qf = __builtin_fmaf(dr, sa, qc);
                             qc = SYM ? sel_mask(qf, qf - sdz, lane_bit) : qf;   // e_step.hpp:427 (own lane only)

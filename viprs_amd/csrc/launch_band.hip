@@ -21,8 +21,8 @@ int launch_band(viprs_plan* P, EStepArgs<float> A, int model) {
     const bool upper = P->low_memory != 0;
     void (*kfn)(EStepArgs<float>, int) = nullptr;
 #define BK(MODEL) (upper ? estep_band_kernel<U, MODEL, false> : estep_band_kernel<U, MODEL, true>)
-    if (model == kBandGridColumn) kfn = BK(GridColumnModel);
-    else if (model == kBandMixture) kfn = BK(MixtureSerialModel);
+    if (model == kBandGridColumn) kfn = exact ? BK(GridColumnModel<true>) : BK(GridColumnModel<false>);
+    else if (model == kBandMixture) kfn = exact ? BK(MixtureSerialModel<true>) : BK(MixtureSerialModel<false>);
     else kfn = exact ? BK(SpikeSlabModel<true>) : BK(SpikeSlabModel<false>);
 #undef BK
     HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

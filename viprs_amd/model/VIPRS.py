@@ -737,7 +737,8 @@ class VIPRS:
 
     # ---- EM loop (VIPRS.py:909-1124): same stopping rules, evaluated on the reduced sums ------------
     def fit(self, max_iter=1000, theta_0=None, param_0=None, continued=False, disable_pbar=True, min_iter=3,
-            f_abs_tol=1e-6, x_abs_tol=1e-6, patience=10, **kwargs):
+            f_abs_tol=1e-6, x_abs_tol=1e-6, patience=10, on_iteration=None, **kwargs):
+        """`on_iteration(i)`: optional callback at the end of every EM iteration (progress reporting, timing)."""
         if not continued:
             self.initialize(theta_0, param_0)
             first = 1
@@ -793,6 +794,8 @@ class VIPRS:
             else:
                 res.update(elbo, stop_iteration=True, success=stop[0], message=stop[1])
             prev_elbo, prev_sigma_g = elbo, self._sigma_g
+            if on_iteration is not None:
+                on_iteration(i)
 
         self.sync_host()
         self.update_posterior_moments()

@@ -201,7 +201,7 @@ class VIPRSGrid(VIPRS):
 
     # ---- all grid points at once -------------------------------------------------------------------------
     def _fit_batched(self, max_iter=1000, theta_0=None, min_iter=3, f_abs_tol=1e-6, x_abs_tol=1e-6, patience=10,
-                     **kwargs):
+                     on_iteration=None, **kwargs):
         if self._e_step_fn is not None or self.comm.world_size != 1:
             raise NotImplementedError("the batched grid fit runs on one GPU through the device-resident grid state")
         from ...plan import DeviceState
@@ -330,6 +330,8 @@ class VIPRSGrid(VIPRS):
                     results[g].update(e, stop_iteration=True, success=stop[0], message=stop[1])
                 prev_elbo[g], prev_sigma_g[g] = e, sigma_g[g]
             active = np.array(still, dtype=np.int32)
+            if on_iteration is not None:
+                on_iteration(i)
         for g in range(G):
             if not results[g].stop_iteration:
                 results[g].update(elbos[g], stop_iteration=True, success=False, increment=False,
