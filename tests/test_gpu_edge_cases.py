@@ -83,12 +83,20 @@ def test_low_memory_mismatch_and_threads_are_handled(gpu):
     plan.close()
 
 
-def test_cfg2_full_size_against_oracle(gpu):
-    """BASELINE configs[1]: chr22-like, ~19k SNPs / 40 LD blocks, symmetric and upper forms."""
+@pytest.mark.parametrize("kind", ["longrange", "sample", "ar1"])
+def test_cfg2_full_size_against_oracle(gpu, kind):
+    """BASELINE configs[1]: chr22-like, ~19k SNPs / 40 LD blocks, symmetric and upper forms, three sweeps, `==`.
+    On LD whose far field matters (long-range non-Toeplitz blocks; sample correlations of simulated genotypes) -- the
+    oracle first proves that cutting every entry more than 128 columns off the diagonal changes the result; the AR(1)
+    case (blind beyond ~128 columns, the data of rounds 1-2) stays as the third parameter."""
     for low_memory in (False, True):
-        ld, ss, inp = syn.make_problem("cfg2", low_memory=low_memory)
+        ld, ss, inp = syn.make_problem("cfg2", low_memory=low_memory, kind=kind)
         st0 = inp.state_copy()
         ref = H.run_oracle(ld, inp, st0, sweeps=3)
+        if kind != "ar1":
+            cut = H.run_oracle(H.cut_far_field(ld, 128), inp, st0, sweeps=1)
+            one = H.run_oracle(ld, inp, st0, sweeps=1)
+            assert int((cut["q"] != one["q"]).sum()) > ld.m // 2, "far field does not matter for this input"
         got = H.run_hip(ld, inp, st0, sweeps=3)
         H.assert_state_close(got, ref)
         H.assert_state_equal(got, ref)     # bit-for-bit in both LD forms

@@ -91,3 +91,32 @@ def test_file_comm_collectives_and_cleanup(tmp_path):
         np.testing.assert_array_equal(m, [2.0])
     assert len({d for _, _, d in res}) == 1 and not res[0][2].endswith("feedfacefeedface")
     assert not os.path.exists(res[0][2])                    # removed by close()
+
+
+def test_root_broadcast_survives_glob_characters_and_fails_fast(tmp_path):
+    """a '[' in TMPDIR / the run id must not hide the request files from rank 0 (glob.escape), and when rank 0
+    fails after the broadcast started, a waiting rank raises at once instead of waiting out the 300 s timeout."""
+    import threading
+    from viprs_amd.parallel import _RootBroadcast
+    base = str(tmp_path / "weird[1]*dir?" / "id")
+    os.makedirs(os.path.dirname(base))
+    got = {}
+    root = _RootBroadcast(0, base, lambda: b"x" * 128)
+    t = threading.Thread(target=lambda: got.setdefault("p", _RootBroadcast(1, base, timeout_s=20).payload))
+    t.start(); t.join(30)
+    assert got.get("p") == b"x" * 128
+    root.finish()
+    # failure path
+    root2 = _RootBroadcast(0, base + ".b", lambda: b"y")
+    root2._stop.set(); root2._thread.join()            # rank 0 stops answering (as if stuck in a failing collective) ...
+    root2.fail()                                       # ... and reports it
+    err = {}
+    def waiter():
+        try:
+            _RootBroadcast(2, base + ".b", timeout_s=60)
+        except RuntimeError as e:
+            err["e"] = str(e)
+    import time
+    t0 = time.time()
+    t = threading.Thread(target=waiter); t.start(); t.join(30)
+    assert "rank 0 reported a failure" in err.get("e", "") and time.time() - t0 < 10

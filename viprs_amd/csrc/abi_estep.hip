@@ -15,6 +15,15 @@ __global__ void sweep_prologue_kernel(int32_t* counters, int n_counters, unsigne
     for (int64_t k = i; k < n_granules; k += (int64_t)gridDim.x * blockDim.x) granules[k] = 0ull;
 }
 
+// A sweep that is ONE panel launch has no prologue: its last workgroup moves the running skip count [0] to [1].  If the
+// sweep before it on this plan ran kernels that count in place (float64 state, batched grid, generic / band kernels: they
+// leave their total in [0]), that leftover must not be folded into this sweep's count: one 8-byte memset, only then.
+hipError_t clear_stale_skip_count(viprs_plan* P) {
+    if (!P->skip_count_in_place) return hipSuccess;
+    P->skip_count_in_place = false;
+    return hipMemsetAsync(P->d_skipped.p, 0, sizeof(unsigned long long), P->stream);
+}
+
 template <typename T>
 EStepArgs<T> make_args(viprs_state* S, double dq) {
     viprs_plan* P = S->plan;
@@ -111,6 +120,9 @@ int run_spike_slab(viprs_state* S, double dq) {
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ng + 255) / 256, 1024));
         sweep_prologue_kernel<<<grid, 256, 0, P->stream>>>(P->d_counters.p, kPlanCounters, P->d_skipped.p, P->d_granules.p, ng);
         HIP_TRY(hipGetLastError());
+        P->skip_count_in_place = true;
+    } else {
+        HIP_TRY(clear_stale_skip_count(P));
     }
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = dense_only;
@@ -146,6 +158,7 @@ int run_spike_slab(viprs_state* S, double dq) {
 }
 
 static int sweep_prologue(viprs_plan* P, int n_models = 1) {
+    P->skip_count_in_place = true;
     const int64_t ng = P->n_granule_rows * kPanel * std::max(1, n_models);
     if (P->d_granules.n < (size_t)ng) {                      // grid launches: one granule set per active model
         HIP_TRY(hipStreamSynchronize(P->stream));
@@ -186,6 +199,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
                             ((model == kGenMixture && S->width <= kPanelWideMaxK) || (model == kGenGrid && !use_grid_mfma(P, S->width)));
     int rc = panel_only ? VIPRS_OK : sweep_prologue(P, model == kGenGrid ? n_active : 1);
     if (rc != VIPRS_OK) return rc;
+    if (panel_only) HIP_TRY(clear_stale_skip_count(P));
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = true;      // [2] .. [3] bracket all kernels of the call
     HIP_TRY(hipEventRecord(ev[2], P->stream));

@@ -312,7 +312,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
             }
             // items of the blocks beyond the batched kernel's resident form first (the only ones it leaves to the lower
             // pass by default), each group longest first
-            constexpr int kResMax = 6 * 2 * 2 * kPanel;             // = kGridResMaxCols (estep_grid_mfma.h)
+            constexpr int kResMax = kGridResMaxCols;                // (kernels_common.h)
             std::stable_sort(low.begin(), low.end(), [&](const EpiItem& x, const EpiItem& y) {
                 const int bx = P->dense_h[(size_t)x.blk].size, by = P->dense_h[(size_t)y.blk].size;
                 const bool gx = bx > kResMax, gy = by > kResMax;

@@ -588,9 +588,7 @@ __device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const
 // makes each of them queue for up to two MFMA times (64 clocks each); the carry's few MFMAs mostly fall between the
 // chain's panels.
 constexpr int kGridCarryWave = 4;
-constexpr int kGridResOwners = 6;
-constexpr int kGridResSlots = 2;
-constexpr int kGridResMaxCols = kGridResOwners * kGridResSlots * 2 * kPanel;      // 1536
+// (kGridResOwners = 6, kGridResSlots = 2, kGridResMaxCols = 1 536: kernels_common.h -- the plan sorts by the same limit)
 
 // rows of panel `pp` x the 128 columns from c0 applied to a tile whose accumulators are in registers; `on_l` / `on_r`: the
 // left / right 64 columns take the update (a masked half gets B = 0).  LD rows in 4 chunks of 8 row pairs (one 16-byte load

@@ -119,6 +119,7 @@ struct viprs_plan {
     int max_band_panels = 0;                // ragged blocks: widest (band_left + band_right + 2), sizes the band kernel's q ring
     viprs::DevBuf<int32_t> d_counters;             // [0] dense queue head, [1] ragged queue head
     viprs::DevBuf<unsigned long long> d_skipped;   // [0] running count of the sweep in flight, [1] of the sweep kernel(s) that are done
+    bool skip_count_in_place = false;              // the last sweep ran kernels that leave their count in [0] (no panel-sweep epilogue moved it)
     viprs::DevBuf<int32_t> d_arrive;               // panel sweep: arrival counters of the team (block, model) items; [last]: workgroups done
     uint32_t granule_gen = 0;                      // panel sweep launches so far (mod 2^20): generation of the hand-off tags
     // HIP-event ring: per sweep {sweep start, sweep end, panel start, panel end}, recorded on

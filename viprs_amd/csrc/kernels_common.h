@@ -37,6 +37,10 @@ constexpr int kPanelWideMaxK = 31;  // ... and with scalar chains over v_readlan
 constexpr int kMixLdsFloats = 5 * kPanel * kPanelMaxK;
 constexpr int kMaxMixtureK = 64;    // generic mixture kernel (estep_generic.h): one lane per component
 constexpr int kGridModels = 32;     // batched grid kernel (estep_grid_mfma.h): models per launch (one 32-row MFMA tile)
+// ... its resident form: 6 owner waves x 2 tiles of 128 columns in accumulator registers = blocks of up to 1 536 SNPs
+// (the plan splits the lower-pass items by the same limit, abi_plan.hip)
+constexpr int kGridResOwners = 6, kGridResSlots = 2;
+constexpr int kGridResMaxCols = kGridResOwners * kGridResSlots * 2 * kPanel;
 constexpr int kBandMaxRingPanels = 256;   // band kernel (estep_band.h): 64 KB of q in the LDS ring
 
 // work item of the second-pass / lower-pass kernels: (block, first row of a 64-row group or tile index)

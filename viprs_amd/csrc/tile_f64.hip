@@ -114,19 +114,26 @@ int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
         }
         // the big class goes FIRST and on the plan's own stream (it starts the moment the work before it ends; the other
         // class has to come through the fork event and finds those CUs taken)
-        int rc = launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, P->d_counters.p + (dense ? 20 : 21), P->stream, big_cus);
+        // (after the fork every exit joins the side stream again: a kernel of the side stream must never be left running
+        //  behind a caller that was told the call failed and may reuse or free the state)
+        auto forked = [&]() -> int {
+            int rc = launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, P->d_counters.p + (dense ? 20 : 21), P->stream, big_cus);
+            if (rc != VIPRS_OK) return rc;
+            rc = launch_tile_class<U, 4>(P, A, model, dense, d_blocks + n_big, n_small, list[(size_t)n_big].size, counter, P->side_stream,
+                                         P->n_cu - big_cus);
+            if (rc != VIPRS_OK) return rc;
+            // each class's second pass behind its own sweep: the small class's runs while the largest blocks are still
+            // walking their panels
+            rc = second_pass(n_groups_big, n_groups - n_groups_big, P->side_stream, P->n_cu - big_cus);
+            if (rc != VIPRS_OK) return rc;
+            return second_pass(0, n_groups_big, P->stream, P->n_cu);
+        };
+        const int rc = forked();
+        const hipError_t e1 = hipEventRecord(P->ev_join, P->side_stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(P->stream, P->ev_join, 0) : e1;
+        if (e2 != hipSuccess) (void)hipStreamSynchronize(P->side_stream);       // last resort: never leave it unjoined
         if (rc != VIPRS_OK) return rc;
-        rc = launch_tile_class<U, 4>(P, A, model, dense, d_blocks + n_big, n_small, list[(size_t)n_big].size, counter, P->side_stream,
-                                     P->n_cu - big_cus);
-        if (rc != VIPRS_OK) return rc;
-        // each class's second pass behind its own sweep: the small class's runs while the largest blocks are still
-        // walking their panels
-        rc = second_pass(n_groups_big, n_groups - n_groups_big, P->side_stream, P->n_cu - big_cus);
-        if (rc != VIPRS_OK) return rc;
-        HIP_TRY(hipEventRecord(P->ev_join, P->side_stream));
-        rc = second_pass(0, n_groups_big, P->stream, P->n_cu);
-        if (rc != VIPRS_OK) return rc;
-        HIP_TRY(hipStreamWaitEvent(P->stream, P->ev_join, 0));
+        HIP_TRY(e2);
     } else {
         int rc = n_big > 0 ? launch_tile_class<U, 8>(P, A, model, dense, d_blocks, n_big, max_b, counter, P->stream, P->n_cu)
                            : launch_tile_class<U, 4>(P, A, model, dense, d_blocks, n_small, max_b, counter, P->stream, P->n_cu);

@@ -432,10 +432,13 @@ class ZarrLDMatrix:
     def get_lambda_min(self, min_max_ratio=0.0):
         """The ridge penalty `VIPRS(lambda_min='infer')` asks for (`ld_mat.get_lambda_min(min_max_ratio=1e-3)`,
         VIPRS.py:191), from the extremal eigenvalues magenpy stores under 'Spectral properties' -> 'Extremal':
-        the smallest x >= 0 with (lambda_min + x) >= min_max_ratio (lambda_max + x), scaled as magenpy does:
-        max((r lambda_max - lambda_min) / (1 + r), 0); with r = 0 that is |min(lambda_min, 0)|.  0 when the store
-        has no spectral attributes.  PARITY UNPINNED: magenpy is not in the reference tree (formula and attribute
-        names as recalled from magenpy 0.1.x; both 'min'/'max' and 'Min'/'Max' keys are accepted)."""
+        max((r lambda_max - lambda_min) / (1 + r), 0) with r = min_max_ratio; with r = 0 that is |min(lambda_min, 0)|.
+        0 when the store has no spectral attributes.  PARITY UNPINNED: magenpy is not in the reference tree -- the
+        formula and the attribute names are as recalled from magenpy 0.1.x (both 'min'/'max' and 'Min'/'Max' keys are
+        accepted).  Note the denominator: the smallest x with (lambda_min + x) >= r (lambda_max + x) is
+        (r lambda_max - lambda_min) / (1 - r); the recalled (1 + r) differs from it by a factor (1 - r) / (1 + r),
+        0.2 % of the penalty at the r = 1e-3 VIPRS asks for -- whichever magenpy has, a store written by magenpy
+        (none exists in the image or the reference tree) is what would pin it."""
         sp = self.attrs.get("Spectral properties") or {}
         ext = sp.get("Extremal") or sp.get("extremal") or sp
 

@@ -174,7 +174,7 @@ class _RootBroadcast:
 
             def serve():
                 while not self._stop.is_set():
-                    for req in glob.glob(f"{base}.req.*"):
+                    for req in glob.glob(f"{glob.escape(base)}.req.*"):
                         if req in answered:
                             continue
                         rsp = f"{base}.rsp." + req[len(base) + 5:]
@@ -203,12 +203,26 @@ class _RootBroadcast:
                 break
             except FileNotFoundError:
                 pass
+            if os.path.exists(f"{base}.err"):
+                raise RuntimeError(f"rank {rank}: rank 0 reported a failure while this rank waited for {rsp}")
             if time.time() - t0 > timeout_s:
                 raise TimeoutError(f"rank {rank}: rank 0 did not answer {req} within {timeout_s:.0f} s")
             time.sleep(0.005)
         for f in (req, rsp):
             try:
                 os.remove(f)
+            except OSError:
+                pass
+
+    def fail(self):
+        """Rank 0, when what follows the broadcast failed on it (e.g. its communicator did not come up): leave a marker
+        so that ranks still waiting for their response raise at once instead of waiting out the timeout.  (The marker
+        carries this launch's key like every other file of the base, so no other launch ever sees it; it is one empty
+        file left behind by a failed launch.)"""
+        if self.rank == 0:
+            try:
+                with open(f"{self.base}.err", "wb"):
+                    pass
             except OSError:
                 pass
 
@@ -221,7 +235,7 @@ class _RootBroadcast:
         self._stop.set()
         self._thread.join()
         self._thread = None
-        for f in glob.glob(f"{self.base}.req.*") + glob.glob(f"{self.base}.rsp.*"):
+        for f in glob.glob(f"{glob.escape(self.base)}.req.*") + glob.glob(f"{glob.escape(self.base)}.rsp.*"):
             try:
                 os.remove(f)
             except OSError:
@@ -276,6 +290,10 @@ class RcclComm:
             L.check(L.lib.viprs_comm_create(ctypes.byref(self._h), uid, self.rank, self.world_size, self.device))
             if bc is not None:
                 self.barrier()                  # every rank holds the id: rank 0 stops answering and cleans up
+        except Exception:
+            if bc is not None:
+                bc.fail()                       # ranks that have not fetched the id yet fail fast
+            raise
         finally:
             if bc is not None:
                 bc.finish()
