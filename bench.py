@@ -448,6 +448,8 @@ def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exa
     k = plan.timing_history(which=0)
     out["sweep_kernels_ms_avg"] = float(np.mean(k[-iters:])) if k else None
     out["skipped_snps_last_sweep"] = int(plan.last_skipped())
+    # (VIPRS.py:1025-1044: a negative MSE restarts the fit with sigma_epsilon fixed; the synthetic workload does that once)
+    out["sigma_epsilon_fixed_by_restart"] = bool("sigma_epsilon" in getattr(model, "fix_params", {}))
     if not kind.startswith("VIPRSGrid"):
         # the same iteration, phase by phase (continuing the same trajectory)
         sync = lambda: _lib_sync(device)

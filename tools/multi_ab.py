@@ -1,0 +1,41 @@
+"""A/B/C... of several builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
+    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix] [uniform] [fast]
+(each library runs in its own subprocess, 3 rounds)"""
+import os, subprocess, sys
+sep = sys.argv.index('--') if '--' in sys.argv else len(sys.argv)
+libs = sys.argv[1:sep]
+args = sys.argv[sep + 1:]
+code = r'''
+import sys, os, numpy as np
+sys.path.insert(0, os.getcwd())
+from viprs_amd.plan import DeviceState, LDPlan
+from viprs_amd.utils import synthetic as syn
+upper = "upper" in sys.argv; dt = np.int8 if "int8" in sys.argv else np.int16 if "int16" in sys.argv else np.float32
+sizes = np.full(1700, 650) if "uniform" in sys.argv else None      # uniform: 1700 blocks of 650 SNPs (no large-block tail)
+ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt, sizes=sizes)
+model = "grid" if "grid" in sys.argv else "mixture" if "mix" in sys.argv else "spike_slab"
+width = {"grid": 32, "mixture": 4, "spike_slab": 1}[model]
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper, math_mode="fast" if "fast" in sys.argv else "exact"); ds = DeviceState(plan, "float32", model, width)
+ds.upload("std_beta", inp.std_beta)
+active, pi0 = None, inp.pi
+if model == "spike_slab":
+    for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"): ds.upload(k, getattr(inp, k))
+else:
+    extra = syn.make_mixture_inputs(ss, width) if model == "mixture" else syn.make_grid_inputs(ss, width)
+    pi0 = extra.pop("pi")
+    for k, a in extra.items(): ds.upload(k, a)
+    if model == "grid": active = np.arange(width, dtype=np.int32)
+for _ in range(5): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
+ds.synchronize(); plan.timing_reset()
+import time
+t0 = time.perf_counter()
+for _ in range(30): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
+ds.synchronize(); wall = (time.perf_counter() - t0) / 30 * 1e3
+t = np.array(plan.timing_history(which=1))
+print("%.4f %.4f %.4f  wall ms/step %.4f" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90), wall))
+'''
+for rnd in range(3):
+    for name, lib in zip("ABCDEFGH", libs):
+        env = dict(os.environ, VIPRS_HIP_LIB=os.path.abspath(lib))
+        out = subprocess.run([sys.executable, "-c", code] + args, env=env, capture_output=True, text=True)
+        print(rnd, name, os.path.basename(lib), out.stdout.strip() or out.stderr[-300:], flush=True)

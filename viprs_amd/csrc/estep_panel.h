@@ -170,6 +170,21 @@ template <typename U, int CPL> __device__ __forceinline__ RawRow<U, CPL> load_ra
 // columns per updater lane: 16-byte loads for fp32 and int16, 8-byte loads for int8 (wider strips leave
 // too few updater waves per block busy)
 template <typename U> __host__ __device__ constexpr int panel_cols() { return sizeof(U) == 4 ? 4 : 8; }
+// ... and per updater lane of a TEAM workgroup.  A team block is the sweep's critical path, and what bounds its phase is
+// not bandwidth but the memory LATENCY of its updater waves: a strip of 64 x CPL columns is one wave's unit of work per
+// phase (the fma chain of a column takes its rows in order), its 64 rows come in 64 / DEPTH round trips of ~2.5 us under
+// load, and with 4 columns per lane the 3 619-SNP block of cfg3 has 15 strips for the 36 updater waves of its 12 members:
+// most of them idle while the others need 4 round trips -- the in-kernel timeline showed the updaters of that block ending
+// their phase at 11-18 us against the chain's 9.  Narrower strips with proportionally more rows in flight (the same 64
+// VGPRs of row data per lane) give every wave of the team work and halve / quarter the round trips: 8-byte loads and 32
+// rows in flight for fp32 / int16 LD (29 strips, 2 round trips), 4-byte loads and all 64 rows in flight for int8.
+template <typename U> __host__ __device__ constexpr int panel_team_cols() {
+#ifdef PANEL_TEAM_CPL
+    return PANEL_TEAM_CPL;
+#else
+    return sizeof(U) == 4 ? 2 : 4;
+#endif
+}
 
 constexpr int kChainPrefetch = 16;   // diagonal-tile rows in flight ahead of the serial chain
 #ifndef PANEL_STRIP_DEPTH
@@ -565,11 +580,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     // upper-triangular form: one 32-row transposition buffer per updater wave (HalfTileRows::to_rows), behind ls[qcap]
     char* tbuf = reinterpret_cast<char*>(ls + qcap) + (threadIdx.x >> 6 ? (threadIdx.x >> 6) - 1 : 0) * kPanelUpperTransposeBytes;
     constexpr bool kSecondPassViaLds = !(MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value);
-#ifndef PANEL_TEAM_STRIP_DEPTH
-#define PANEL_TEAM_STRIP_DEPTH kStripRowsInFlight
-#endif
-    // row loads in flight per updater lane: team blocks (the critical path) may take a larger share of the memory system
+    // row loads in flight per updater lane: 64 VGPRs of row data whatever the strip width (team strips are narrower, see
+    // panel_team_cols: more rows in flight, fewer memory round trips per phase on the critical path)
+#ifdef PANEL_TEAM_STRIP_DEPTH
     constexpr int kDepth = TEAM ? PANEL_TEAM_STRIP_DEPTH : kStripRowsInFlight;
+#else
+    constexpr int kDepth = TEAM ? (kPanel / RawRow<U, CPL>::kWords < kPanel ? kPanel / RawRow<U, CPL>::kWords : kPanel) : kStripRowsInFlight;
+#endif
     __shared__ int s_blk;
     __shared__ int s_tdone;        // phases whose off-diagonal tile the chain has consumed (gate of the single lTo buffer)
 
@@ -1042,6 +1059,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             {
                 // ================================ updaters ===================================
                 const int uw = wave - 1;
+                auto stage_tiles = [&]() {
                 // stage the tile of the chain's next phase: the diagonal tile R[p+1, p+1] (lane-per-SNP models) or the
                 // off-diagonal tile R[p, p+1] (mixture).  16 row groups of 4 rows dealt to the updater waves, all of a
                 // wave's loads issued before its first LDS store (one memory round trip per phase)
@@ -1081,51 +1099,54 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         }
                     }
                 }
+                };
+                // strips of this member are dealt round-robin to its updater waves; the strip that holds panel p+1 goes
+                // first so that its q can be handed over early
+                const int pp = p - 1;                       // panel whose a-vector is applied (p > 0)
+                const int rr0 = pp * kPanel;
+                const int last_row = min(kPanel, b - rr0) - 1;
+                const float avec = p > 0 ? la[(pp & 1) * kPanel + lane] : 0.0f;
+                const int nstrips = (bpad + kSW - 1) / kSW;
+                const bool any_a = __ballot(avec != 0.0f) != 0;
+                const int s_pri = ((p + 1) * kPanel) / kSW;
+                const int n_mine = (nstrips - member + TS - 1) / TS;       // strips member, member+TS, ...
+                auto do_strip = [&](int k) {
+                    int st = member + k * TS, kl = k;                     // kl: the strip's index in this member's LDS
+                    if (TEAM) {
+                        // rotate so that the priority strip (if this member owns it) is slot 0
+                        const int k_pri = (s_pri % TS == member) ? (s_pri - member) / TS : 0;
+                        kl = (k + k_pri) % n_mine;
+                        st = member + kl * TS;
+                    }
+                    const int c = st * kSW + CPL * lane;
+                    float* __restrict__ lq_c = lq + (TEAM ? kl * kSW + CPL * lane : c);
+                    const int cp = c >> 6;
+                    // symmetric form: every column except the chain's two panels (left of the
+                    // chain = SNPs already visited, their q keeps accumulating for the next
+                    // sweep); upper-triangular form: right of the chain only (the rest is the
+                    // reference's second pass)
+                    const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
+                    if (any_a && active) {
+                        if (last_row == kPanel - 1)
+                            strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
+                        else
+                            strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
+                    }
+                    if (k == uw) PPROF(6, wave == 1);
+                    if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
+                        // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
+                        __builtin_amdgcn_wave_barrier();
+                        const float v = lq[loc((p + 1) * kPanel + lane)];
+                        const unsigned long long g =
+                            ((unsigned long long)(A.tag_base + (unsigned)(p + 2)) << 32) | (unsigned long long)__float_as_uint(v);
+                        __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                };
+                stage_tiles();
                 PPROF(5, wave == 1);
                 if (p > 0) {
-                    const int pp = p - 1;                       // panel whose a-vector is applied
-                    const int rr0 = pp * kPanel;
-                    const int last_row = min(kPanel, b - rr0) - 1;
-                    const float avec = la[(pp & 1) * kPanel + lane];
-                    const int nstrips = (bpad + kSW - 1) / kSW;
-                    const bool any_a = __ballot(avec != 0.0f) != 0;
-                    // strips of this member are dealt round-robin to its updater waves; the strip
-                    // that holds panel p+1 goes first so that its q can be handed over early
-                    const int s_pri = ((p + 1) * kPanel) / kSW;
-                    const int n_mine = (nstrips - member + TS - 1) / TS;       // strips member, member+TS, ...
-                    for (int k = uw; k < n_mine; k += NW - 1) {
-                        int st = member + k * TS, kl = k;                     // kl: the strip's index in this member's LDS
-                        if (TEAM) {
-                            // rotate so that the priority strip (if this member owns it) is slot 0
-                            const int k_pri = (s_pri % TS == member) ? (s_pri - member) / TS : 0;
-                            kl = (k + k_pri) % n_mine;
-                            st = member + kl * TS;
-                        }
-                        const int c = st * kSW + CPL * lane;
-                        float* __restrict__ lq_c = lq + (TEAM ? kl * kSW + CPL * lane : c);
-                        const int cp = c >> 6;
-                        // symmetric form: every column except the chain's two panels (left of the
-                        // chain = SNPs already visited, their q keeps accumulating for the next
-                        // sweep); upper-triangular form: right of the chain only (the rest is the
-                        // reference's second pass)
-                        const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
-                        if (any_a && active) {
-                            if (last_row == kPanel - 1)
-                                strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
-                            else
-                                strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
-                        }
-                        if (k == uw) PPROF(6, wave == 1);
-                        if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
-                            // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
-                            __builtin_amdgcn_wave_barrier();
-                            const float v = lq[loc((p + 1) * kPanel + lane)];
-                            const unsigned long long g =
-                                ((unsigned long long)(A.tag_base + (unsigned)(p + 2)) << 32) | (unsigned long long)__float_as_uint(v);
-                            __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
+                    for (int k = uw; k < n_mine; k += NW - 1) do_strip(k);
                     if (!SYM) {
                         // second pass, column panel pp: tiles R[r, pp], r = 0 .. pp, of the row panels this member owns
                         // (the owner of a strip owns the q -- and the sums -- of its rows), dealt to its updater waves
@@ -1264,7 +1285,10 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(S
     const int wg = blockIdx.x;
     const int team_cls = wg < S.n_wg[0] ? 0 : (wg < S.n_wg[0] + S.n_wg[1] ? 1 : 2);
     if (team_cls < 2) {
-        panel_role<U, MODEL, SYM, NW, true, CPL>(S.cls[team_cls], S.qcap[team_cls], smem, wg - (team_cls ? S.n_wg[0] : 0));
+        // (team strips are narrower for the lane-per-SNP models, panel_team_cols; the mixture chains, 3-4 x longer per step,
+        //  are never waiting for their updaters: measured 2.5 % slower with the narrow strips, they keep the wide ones)
+        constexpr int CPL_T = MODEL::kLaneParallel ? CPL : panel_team_cols<U>();
+        panel_role<U, MODEL, SYM, NW, true, CPL_T>(S.cls[team_cls], S.qcap[team_cls], smem, wg - (team_cls ? S.n_wg[0] : 0));
         __syncthreads();
     }
     if (S.cls[2].n_blocks > 0) panel_role<U, MODEL, SYM, NW, false, CPL>(S.cls[2], S.qcap[2], smem, wg);

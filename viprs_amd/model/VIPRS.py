@@ -772,6 +772,8 @@ class VIPRS:
                     self.initialize_theta(theta_0)
                     self.initialize_variational_parameters(param_0)
                     self.fix_params["sigma_epsilon"] = self.sigma_epsilon = 0.95
+                    if on_iteration is not None:
+                        on_iteration(i)
                     continue
                 stop = (False, f"The MSE is negative ({self.mse():.6f}).")
             elif not np.isfinite(elbo):
