@@ -598,13 +598,50 @@ constexpr int kGridCarryWave = 4;
 //           loop-invariant addresses into scratch);
 //   DEPTH 2 (streaming form, 64 VGPRs): the next chunk is in flight while the current one is multiplied.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// Four consecutive columns of one LD row as loaded (one dword for int8, two for int16, four for fp32), converted with
+// static_cast<float> (e_step.hpp:173) when consumed.  A masked half of a tile is masked on the raw dwords -- once per load
+// instead of once per element (float(0) == 0).
+// (Measured and withdrawn: one-instruction conversions, v_cvt_f32_i32 with an SDWA byte / word select and sign extension,
+// as inline asm -- the instructions are right for all 2^16 inputs (tools/ubench/sdwa_cvt.hip) but an inline-asm result
+// consumed as an MFMA operand gave wrong sums in the kernel: hipcc does not see the asm as a VALU instruction and leaves
+// out whatever it keeps between a VALU write and the matrix core.  The plain casts cost the same time.)
+template <typename U> struct RawCols4;
+template <> struct RawCols4<float> {
+    f32x4 v;
+    static constexpr int kDwords = 4;
+    __device__ __forceinline__ void mask(bool on) { v = on ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    template <int J> __device__ __forceinline__ float get() const { return v[J]; }
+};
+template <> struct RawCols4<int8_t> {
+    unsigned w;
+    static constexpr int kDwords = 1;
+    __device__ __forceinline__ void mask(bool on) { w = on ? w : 0u; }
+    template <int J> __device__ __forceinline__ float get() const { return static_cast<float>(static_cast<int8_t>(w >> (8 * J))); }
+};
+template <> struct RawCols4<int16_t> {
+    unsigned w[2];
+    static constexpr int kDwords = 2;
+    __device__ __forceinline__ void mask(bool on) { w[0] = on ? w[0] : 0u; w[1] = on ? w[1] : 0u; }
+    template <int J> __device__ __forceinline__ float get() const { return static_cast<float>(static_cast<int16_t>(w[J >> 1] >> (16 * (J & 1)))); }
+};
+template <typename U> __device__ __forceinline__ RawCols4<U> load_cols4(const char* p);
+template <> __device__ __forceinline__ RawCols4<float> load_cols4<float>(const char* p) {
+    return RawCols4<float>{*reinterpret_cast<const f32x4*>(p)};
+}
+template <> __device__ __forceinline__ RawCols4<int8_t> load_cols4<int8_t>(const char* p) {
+    return RawCols4<int8_t>{*reinterpret_cast<const unsigned*>(p)};
+}
+template <> __device__ __forceinline__ RawCols4<int16_t> load_cols4<int16_t>(const char* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    return RawCols4<int16_t>{{t.x, t.y}};
+}
 // (`after_first_issue` runs once the first chunk's loads are out and before the first MFMA: the streaming form finishes
 // the tile's accumulator loads there, so that they and the first rows share one memory round trip)
 template <typename U, int DEPTH, typename HOOK = NoHook>
 __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __restrict__ base, int stride, int pp, int c0,
                                                int lane, bool on_l, bool on_r, const float* __restrict__ a_lds,
                                                HOOK after_first_issue = HOOK()) {
-    using V = typename Vec4<U>::type;
     const int half = lane >> 5, l31 = lane & 31;
     const bool lane_on = (lane & 16) ? on_r : on_l;
     int col = c0 + 4 * l31;
@@ -612,34 +649,45 @@ __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __rest
     const unsigned voff = (unsigned)((half * stride + (col - c0)) * (int)sizeof(U));
     const char* __restrict__ sb = reinterpret_cast<const char*>(base + (int64_t)pp * kPanel * stride + c0);
     const size_t step = (size_t)2 * stride * sizeof(U);
-    constexpr int CH = 8, NCH = kPanel / 2 / CH;
-    V ring[DEPTH][CH];
-    if (DEPTH == 2) {
+    // a chunk = 32 VGPRs of raw rows whatever the LD type: 8 row pairs of fp32, 16 of int16, all 32 of int8 -- integer LD
+    // takes fewer memory round trips per tile, not fp32's four with a quarter of the bytes each
+    constexpr int CH = 8 * 4 / RawCols4<U>::kDwords, NCH = kPanel / 2 / CH;
+    constexpr int RING = NCH == 1 ? 1 : DEPTH;
+    RawCols4<U> ring[RING][CH];
+    if (RING == 2) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) ring[0][i] = *reinterpret_cast<const V*>(sb + i * step + voff);
+        for (int i = 0; i < CH; ++i) ring[0][i] = load_cols4<U>(sb + i * step + voff);
         asm volatile("" ::: "memory");
-        after_first_issue();
     }
+    if (DEPTH == 2 && RING == 1) {
+        // (one chunk is the whole tile: issue it, then let the caller issue what shares its round trip)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) ring[0][i] = load_cols4<U>(sb + i * step + voff);
+        asm volatile("" ::: "memory");
+    }
+    if (DEPTH == 2) after_first_issue();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (DEPTH == 1) {
+        if (RING == 1) {
+            if (!(DEPTH == 2 && c == 0)) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) ring[0][i] = *reinterpret_cast<const V*>(sb + (c * CH + i) * step + voff);
-            asm volatile("" ::: "memory");
+                for (int i = 0; i < CH; ++i) ring[0][i] = load_cols4<U>(sb + (c * CH + i) * step + voff);
+                asm volatile("" ::: "memory");
+            }
         } else if (c + 1 < NCH) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) ring[(c + 1) & 1][i] = *reinterpret_cast<const V*>(sb + ((c + 1) * CH + i) * step + voff);
+            for (int i = 0; i < CH; ++i) ring[(c + 1) & 1][i] = load_cols4<U>(sb + ((c + 1) * CH + i) * step + voff);
             asm volatile("" ::: "memory");
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const V v = ring[DEPTH == 2 ? (c & 1) : 0][i];
+            RawCols4<U> v = ring[RING == 2 ? (c & 1) : 0][i];
+            v.mask(lane_on);
             const float aop = a_lds[(2 * (c * CH + i) + half) * kGridModels + l31];      // A[model = lane & 31][k = lane >> 5]
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float bop = lane_on ? static_cast<float>(v[j]) : 0.0f;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, acc[j], 0, 0, 0);
-            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<0>(), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<1>(), acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<2>(), acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<3>(), acc[3], 0, 0, 0);
         }
     }
 }
