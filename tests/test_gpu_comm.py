@@ -19,6 +19,7 @@ def comm(gpu):
 
 
 def test_host_vector_collectives(comm):
+    assert comm.size() == 1                      # what RCCL itself reports (ncclCommCount), bench.py's `rccl_ranks`
     v = np.array([1.5, -2.0, 3.25, 7.0])
     np.testing.assert_array_equal(comm.allreduce_sum(v), v)
     np.testing.assert_array_equal(comm.allreduce_max(v), v)

@@ -206,3 +206,23 @@ def test_lambda_min_from_the_stored_extremal_eigenvalues(tmp_path, keys):
         m = Z.ZarrLDMatrix(path)
         assert m.get_lambda_min() == pytest.approx(max(-lam_min, 0.0))
         assert m.get_lambda_min(min_max_ratio=1e-3) == pytest.approx(max((1e-3 * lam_max - lam_min) / 1.001, 0.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("low_memory, expand", [(True, False), (False, False), (False, True)],
+                         ids=["upper", "symmetric-host-mirror", "symmetric-expanded-on-device"])
+def test_fit_from_a_store_on_the_gpu(gpu, tmp_path, low_memory, expand):
+    """The reader on the product path: VIPRS on the HIP E-step from ZarrLDMatrix stores (int8, dequantised on the fly)
+    against the same fit from in-memory arrays -- bit-identical histories, in the stored upper-triangular form, with the
+    symmetric rows mirrored on the host, and with the symmetric form built on the device from the stored rows
+    (`expand_ld_on_device`).  (The store layout itself stays parity-unpinned: no magenpy-written store exists here.)"""
+    from viprs_amd.model import VIPRS
+    g_store, g_arr = _loaders(tmp_path, {1: [60, 130, 700], 2: [80, 70]})
+    theta = {"pi": 0.02, "sigma_epsilon": 0.85}
+    kw = dict(low_memory=low_memory, dequantize_on_the_fly=True)
+    a = VIPRS(g_arr, **kw).fit(max_iter=12, theta_0=dict(theta))
+    b = VIPRS(g_store, expand_ld_on_device=expand, **kw).fit(max_iter=12, theta_0=dict(theta))
+    np.testing.assert_array_equal(a.history["ELBO"], b.history["ELBO"])
+    for c in a.chromosomes:
+        np.testing.assert_array_equal(a.pip[c], b.pip[c])
+        np.testing.assert_array_equal(a.post_mean_beta[c], b.post_mean_beta[c])

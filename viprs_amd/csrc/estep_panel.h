@@ -745,6 +745,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         // panel p lives in another member's strip: take its q (all trailing updates
                         // a_0 .. a_{p-2} applied) from the owner's granules, tag = p + 1
                         unsigned long long g = 0;
+#ifdef PANEL_TIMING_NO_HANDOFF_WAIT
+                        // TIMING EXPERIMENT (wrong results): the chain never waits for a hand-off -- what a zero-latency hand-off
+                        // would be worth
+                        if (false)
+#endif
                         for (unsigned spins = 0;; ++spins) {
                             g = __hip_atomic_load(gran + (int64_t)p * kPanel + lane, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_AGENT);
