@@ -209,13 +209,13 @@ def test_lambda_min_from_the_stored_extremal_eigenvalues(tmp_path, keys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("low_memory, expand", [(True, False), (False, False), (False, True)],
-                         ids=["upper", "symmetric-host-mirror", "symmetric-expanded-on-device"])
+@pytest.mark.parametrize("low_memory, expand", [(True, None), (False, None), (False, True)],
+                         ids=["upper", "symmetric-default", "symmetric-expanded-on-device"])
 def test_fit_from_a_store_on_the_gpu(gpu, tmp_path, low_memory, expand):
     """The reader on the product path: VIPRS on the HIP E-step from ZarrLDMatrix stores (int8, dequantised on the fly)
-    against the same fit from in-memory arrays -- bit-identical histories, in the stored upper-triangular form, with the
-    symmetric rows mirrored on the host, and with the symmetric form built on the device from the stored rows
-    (`expand_ld_on_device`).  (The store layout itself stays parity-unpinned: no magenpy-written store exists here.)"""
+    against the same fit from in-memory arrays -- bit-identical histories, in the stored upper-triangular form and in
+    the symmetric form, which a store can only provide by expansion on the device (the default for such a loader, and
+    asked for explicitly with `expand_ld_on_device=True`).  (The store layout itself stays parity-unpinned: no magenpy-written store exists here.)"""
     from viprs_amd.model import VIPRS
     g_store, g_arr = _loaders(tmp_path, {1: [60, 130, 700], 2: [80, 70]})
     theta = {"pi": 0.02, "sigma_epsilon": 0.85}

@@ -107,14 +107,17 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     const size_t es = ld_elem_size(ld_dtype);
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
-    // environment switches, re-read at every plan creation
+    // environment switches (EXPERIMENTS.md, "4.3 Environment switches" of rounds 1-3), re-read at every plan creation
     if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
     {
         SchedConfig c;                          // defaults
-        if (const char* f = getenv("VIPRS_LARGE_BLOCK")) c.large_block = atoi(f);
-        if (const char* f = getenv("VIPRS_MEDIUM_BLOCK")) c.medium_block = atoi(f);
-        if (const char* f = getenv("VIPRS_TEAM0")) { c.class_team[0] = std::max(1, atoi(f)); c.team_env = true; }
-        if (const char* f = getenv("VIPRS_TEAM1")) { c.class_team[1] = std::max(1, atoi(f)); c.team_env = true; }
+        // (an empty value means "not set": `VAR= command` from a shell loop must not turn into a team size of 1 or a class
+        //  limit of 0)
+        auto env = [](const char* name) -> const char* { const char* f = getenv(name); return (f && *f) ? f : nullptr; };
+        if (const char* f = env("VIPRS_LARGE_BLOCK")) c.large_block = atoi(f);
+        if (const char* f = env("VIPRS_MEDIUM_BLOCK")) c.medium_block = atoi(f);
+        if (const char* f = env("VIPRS_TEAM0")) { c.class_team[0] = std::max(1, atoi(f)); c.team_env = true; }
+        if (const char* f = env("VIPRS_TEAM1")) { c.class_team[1] = std::max(1, atoi(f)); c.team_env = true; }
         if (const char* f = getenv("VIPRS_BOTTOM_MOD")) c.bottom_mod = std::max(0, atoi(f));
         sched_config() = c;
     }

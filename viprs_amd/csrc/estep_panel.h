@@ -179,8 +179,8 @@ template <typename U> __host__ __device__ constexpr int panel_cols() { return si
 // VGPRs of row data per lane) give every wave of the team work and halve / quarter the round trips: 8-byte loads and 32
 // rows in flight for fp32 / int16 LD (29 strips, 2 round trips), 4-byte loads and all 64 rows in flight for int8.
 template <typename U> __host__ __device__ constexpr int panel_team_cols() {
-#ifdef PANEL_TEAM_CPL
-    return PANEL_TEAM_CPL;
+#ifdef PANEL_TEAM_CPL_F32
+    return sizeof(U) == 4 ? PANEL_TEAM_CPL_F32 : 4;      // (experiments)
 #else
     return sizeof(U) == 4 ? 2 : 4;
 #endif
