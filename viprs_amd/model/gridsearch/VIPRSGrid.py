@@ -237,101 +237,124 @@ class VIPRSGrid(VIPRS):
                 st.reset_column(g, float(th[g]["pi"]))
             states[key] = st
 
-        def prep_rows(models):
-            return np.array([[g, float(np.log(th[g]["pi"]) - np.log(1.0 - th[g]["pi"])), float(np.log(th[g]["tau_beta"])),
-                              th[g]["sigma_epsilon"], th[g]["tau_beta"], 1.0 + th[g]["lam"]] for g in models], dtype=np.float64)
+        # ---- per-model hyper-parameters as ARRAYS: the host side of an iteration is a handful of NumPy calls over the active
+        # models instead of ~40 Python statements (several np.log / np.isclose on scalars) per model -- for 32 models that
+        # loop cost as much as a third of the batched sweep itself.  The arithmetic follows the serial fit's DTYPES, which
+        # decide roundings: a hyper-parameter that is fixed stays a scalar of the state precision (VIPRS.set_fixed_params /
+        # _cast_theta), one that the M-step updates becomes a float64 (VIPRS.m_step) -- `*_is32` track which is which,
+        # and `in_dtype` evaluates an expression in float32 for the former.  (Array ufuncs give the same bits as the
+        # scalar calls they replace.)
+        f32, f64 = np.float32, np.float64
+        is32 = lambda v: isinstance(v, np.floating) and v.dtype == np.float32
+        pi_v = np.array([p["pi"] for p in th], dtype=T)                       # always of the state precision (m_step casts)
+        sig_v = np.array([p["sigma_epsilon"] for p in th], dtype=f64)
+        tau_v = np.array([p["tau_beta"] for p in th], dtype=f64)
+        sig_is32 = np.array([is32(p["sigma_epsilon"]) for p in th])
+        tau_is32 = np.array([is32(p["tau_beta"]) for p in th])
+        fx_pi = np.array(["pi" in p["fixed"] for p in th])
+        fx_tau = np.array(["tau_beta" in p["fixed"] for p in th])
+        fx_sig = np.array(["sigma_epsilon" in p["fixed"] for p in th])
+        lam1_v = np.array([float(1.0 + p["lam"]) for p in th], dtype=f64)
+        sig_e, tau_e = sig_v.copy(), tau_v.copy()                             # what var_tau of the last E-step was built from
+
+        def in_dtype(v, m32, fn):
+            """fn evaluated in float32 where the serial fit holds a float32 scalar (mask m32), in float64 elsewhere."""
+            out = fn(v)
+            if m32.any():
+                out = np.where(m32, fn(v.astype(f32)).astype(f64), out)
+            return out
+
+        def prep_rows(a):
+            pa = pi_v[a]
+            logit = (np.log(pa) - np.log(1.0 - pa)).astype(f64)
+            return np.column_stack([a.astype(f64), logit, in_dtype(tau_v[a], tau_is32[a], np.log), sig_v[a], tau_v[a], lam1_v[a]])
 
         def all_sums(models):
-            """{g: 11 sums} for the given models: one batched reduction per chromosome, all in flight at once"""
-            lam1 = np.array([1.0 + th[g]["lam"] for g in models])
+            """(len(models), 11) sums: one batched reduction per chromosome, all in flight at once"""
             for st in states.values():
-                st.sums_columns_begin(models, lam1)
+                st.sums_columns_begin(models, lam1_v[models])
             tot = np.zeros((len(models), 11))
             for key, st in states.items():
                 v = st.sums_columns_end()
                 tot[:, 0] += v[:, 0] if merged else v[:, 0] / self.shapes[key]      # merged: weights 1 / m_c on the device
                 tot[:, 1:10] += v[:, 1:10]
                 tot[:, 10] = np.maximum(tot[:, 10], v[:, 10])
-            return {int(g): tot[k] for k, g in enumerate(models)}
-
-        def elbo(g, s, sigma_g):
-            p = th[g]
-            e = -np.log(2.0 * np.pi * p["sigma_epsilon"])
-            if "sigma_epsilon" not in p["fixed"]:
-                e -= 1.0
-            else:
-                e -= (1.0 / p["sigma_epsilon"]) * (1.0 - 2.0 * s[3] + sigma_g)
-            e *= 0.5 * self.n
-            e -= s[5] - np.log(p["pi"]) * s[7]
-            e -= s[6] - np.log(1.0 - p["pi"]) * s[8]
-            e += 0.5 * ((1.0 + np.log(p["tau_beta"])) * s[7] - s[9])
-            e -= 0.5 * p["tau_beta"] * s[1]
-            return float(e)
+            return tot
 
         results = [OptimizeResult() for _ in range(G)]
         sigma_g = np.zeros(G)
         prev_elbo = np.full(G, -np.inf)
         prev_sigma_g = np.zeros(G)
-        plateau = [ConditionStreak() for _ in range(G)]
-        dropping = [ConditionStreak() for _ in range(G)]
+        plateau_n, dropping_n = np.zeros(G, dtype=np.int64), np.zeros(G, dtype=np.int64)     # ConditionStreak counters
         elbos = np.zeros(G)
         active = np.arange(G, dtype=np.int32)
         for st in states.values():               # initial ELBO needs var_tau of the initial hyper-parameters
-            st.prep_columns(prep_rows(range(G)))
+            st.prep_columns(prep_rows(active))
+        MESSAGES = (None, "The MSE is negative ({:.6f}).", "Objective (ELBO) is undefined.", "Residual variance estimate is negative.",
+                    "Estimated heritability is out of bounds.", "Objective (ELBO) converged successfully.",
+                    "Variational parameters converged successfully.", "LD-weighted variational parameters converged successfully.",
+                    "The objective (ELBO) is decreasing.")
+        SUCCESS = (False, False, False, False, False, True, True, True, False)
 
         for i in range(1, max_iter + 1):
             if active.size == 0:
                 break
-            for g in active:
-                p = th[g]
-                p["sigma_epsilon_e"], p["tau_beta_e"] = p["sigma_epsilon"], p["tau_beta"]   # what var_tau is built from
-            rows = prep_rows(active)
+            a = active
+            sig_e[a], tau_e[a] = sig_v[a], tau_v[a]                             # what var_tau is built from
+            rows = prep_rows(a)
             for st in states.values():               # one prep launch, one sweep and one reduction per plan
                 st.prep_columns(rows)
-                st.e_step(self.dequantize_scale, active_model_idx=active, sync=False)
-            sums_of = all_sums(active)
-            still = []
-            for g in active:
-                p, s = th[g], sums_of[int(g)]
-                if "pi" not in p["fixed"]:                                   # VIPRS.m_step, per model
-                    p["pi"] = T.type(s[0] / self._n_chroms_total)
-                if "tau_beta" not in p["fixed"]:
-                    p["tau_beta"] = p["pi"] * self.n_snps / s[1]
-                sigma_g[g] = s[2]
-                if "sigma_epsilon" not in p["fixed"]:
-                    p["sigma_epsilon"] = 1.0 + T.type(-2.0 * s[3]) + sigma_g[g]
-                e = elbos[g] = elbo(g, s, sigma_g[g])
-                mse = 1.0 - 2.0 * s[3] + (sigma_g[g] - s[1] + s[4])
-                h2 = sigma_g[g] / (sigma_g[g] + p["sigma_epsilon"])
-                plateau[g].update((i > min_iter) and np.isclose(sigma_g[g], prev_sigma_g[g], atol=x_abs_tol, rtol=0.0)
-                                  and s[10] < x_abs_tol * 10, i)
-                dropping[g].update((e < prev_elbo[g]) and not np.isclose(e, prev_elbo[g], atol=1e3 * f_abs_tol, rtol=1e-4), i)
-                stop = None                                                    # VIPRS.fit stopping rules
-                if mse < 0.0:
-                    stop = (False, f"The MSE is negative ({mse:.6f}).")
-                elif not np.isfinite(e):
-                    stop = (False, "Objective (ELBO) is undefined.")
-                elif p["sigma_epsilon"] < 0.0:
-                    stop = (False, "Residual variance estimate is negative.")
-                elif h2 > 1.0 or h2 < 0.0:
-                    stop = (False, "Estimated heritability is out of bounds.")
-                elif (i > min_iter) and np.isclose(prev_elbo[g], e, atol=f_abs_tol, rtol=0.0):
-                    stop = (True, "Objective (ELBO) converged successfully.")
-                elif (i > min_iter) and s[10] < x_abs_tol:
-                    stop = (True, "Variational parameters converged successfully.")
-                elif plateau[g].counter > patience:
-                    stop = (True, "LD-weighted variational parameters converged successfully.")
-                elif dropping[g].counter > patience:
-                    stop = (False, "The objective (ELBO) is decreasing.")
-                if stop is None:
-                    results[g].update(e)
-                    still.append(g)
+                st.e_step(self.dequantize_scale, active_model_idx=a, sync=False)
+            s = all_sums(a)
+            # ---- VIPRS.m_step, per model (VIPRS.py:426-484) ----
+            pi_v[a] = np.where(fx_pi[a], pi_v[a], (s[:, 0] / self._n_chroms_total).astype(T))
+            upd = ~fx_tau[a]
+            tau_v[a] = np.where(upd, pi_v[a] * self.n_snps / s[:, 1], tau_v[a])
+            tau_is32[a] &= ~upd
+            sigma_g[a] = s[:, 2]
+            upd = ~fx_sig[a]
+            sig_v[a] = np.where(upd, (1.0 + (-2.0 * s[:, 3]).astype(T)) + sigma_g[a], sig_v[a])
+            sig_is32[a] &= ~upd
+            # ---- ELBO (VIPRS.py:497-581) in the serial fit's dtypes ----
+            sg, sa, ta, pa = sigma_g[a], sig_v[a], tau_v[a], pi_v[a]
+            e = in_dtype(sa, sig_is32[a], lambda v: -np.log(2.0 * np.pi * v))
+            e = np.where(fx_sig[a], e - in_dtype(sa, sig_is32[a], lambda v: 1.0 / v) * (1.0 - 2.0 * s[:, 3] + sg), e - 1.0)
+            e = e * (0.5 * self.n)
+            e = e - (s[:, 5] - np.log(pa) * s[:, 7])
+            e = e - (s[:, 6] - np.log(1.0 - pa) * s[:, 8])
+            e = e + 0.5 * (in_dtype(ta, tau_is32[a], lambda v: 1.0 + np.log(v)) * s[:, 7] - s[:, 9])
+            e = e - 0.5 * ta * s[:, 1]
+            elbos[a] = e
+            mse = 1.0 - 2.0 * s[:, 3] + (sg - s[:, 1] + s[:, 4])
+            h2 = sg / (sg + sa)
+            # ---- VIPRS.fit stopping rules (VIPRS.py:1003-1080), first match wins ----
+            pl = (i > min_iter) & np.isclose(sg, prev_sigma_g[a], atol=x_abs_tol, rtol=0.0) & (s[:, 10] < x_abs_tol * 10)
+            dr = (e < prev_elbo[a]) & ~np.isclose(e, prev_elbo[a], atol=1e3 * f_abs_tol, rtol=1e-4)
+            plateau_n[a] = np.where(pl, plateau_n[a] + 1, 0)
+            dropping_n[a] = np.where(dr, dropping_n[a] + 1, 0)
+            code = np.select(
+                [mse < 0.0, ~np.isfinite(e), sa < 0.0, (h2 > 1.0) | (h2 < 0.0),
+                 (i > min_iter) & np.isclose(prev_elbo[a], e, atol=f_abs_tol, rtol=0.0),
+                 (i > min_iter) & (s[:, 10] < x_abs_tol), plateau_n[a] > patience, dropping_n[a] > patience],
+                [1, 2, 3, 4, 5, 6, 7, 8], default=0)
+            for k, g in enumerate(a):
+                c = int(code[k])
+                if c == 0:
+                    results[g].update(float(e[k]))
                 else:
-                    results[g].update(e, stop_iteration=True, success=stop[0], message=stop[1])
-                prev_elbo[g], prev_sigma_g[g] = e, sigma_g[g]
-            active = np.array(still, dtype=np.int32)
+                    msg = MESSAGES[c].format(float(mse[k])) if c == 1 else MESSAGES[c]
+                    results[g].update(float(e[k]), stop_iteration=True, success=SUCCESS[c], message=msg)
+            prev_elbo[a], prev_sigma_g[a] = e, sg
+            active = a[code == 0]
             if on_iteration is not None:
                 on_iteration(i)
+        # back into the per-model records the publishing code reads (in the serial fit's dtypes)
+        for g in range(G):
+            p = th[g]
+            p["pi"] = pi_v[g]
+            p["sigma_epsilon"] = f32(sig_v[g]) if sig_is32[g] else sig_v[g]
+            p["tau_beta"] = f32(tau_v[g]) if tau_is32[g] else tau_v[g]
+            p["sigma_epsilon_e"], p["tau_beta_e"] = sig_e[g], tau_e[g]
         for g in range(G):
             if not results[g].stop_iteration:
                 results[g].update(elbos[g], stop_iteration=True, success=False, increment=False,
