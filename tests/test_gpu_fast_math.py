@@ -157,3 +157,31 @@ def test_fit_fixtures_in_fast_mode(gpu):
         check_against_fixture(model, fx, pi_rtol=2e-3 if int(fx["K"]) else 2e-4)
         n += 1
     assert n >= 7
+
+
+@pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
+@pytest.mark.parametrize("model", ["spike_slab", "mixture", "grid"])
+def test_fast_math_windowed_components(gpu, fast_mode, model, low_memory):
+    """The band kernel (windowed / banded LD components, estep_band.h) has the same fast policies: spike-and-slab, the
+    K = 4 mixture (components evaluated serially in the SNP's lane) and grid columns on a +-130 / 70 ragged band."""
+    from tests.test_band import _inputs, banded_ld
+    ld = banded_ld(1500, 130, 70, low_memory, np.float32, seed=1500, jitter=40)
+    ss, inp = _inputs(ld.m)
+    if model == "spike_slab":
+        st0 = inp.state_copy()
+        ref = H.run_oracle(ld, inp, st0, sweeps=2)
+        ulp = H.run_oracle(ld, one_ulp(inp), st0, sweeps=2)
+        fast = H.run_hip(ld, inp, st0, sweeps=2)
+    elif model == "mixture":
+        mix, st0 = _mixture_inputs(ld, ss, 4)
+        ref = _run_mix(O, ld, inp, mix, st0, 2)
+        ulp = _run_mix(O, ld, one_ulp(inp), mix, st0, 2)
+        fast = _run_mix(fast_mode, ld, inp, mix, st0, 2)
+    else:
+        g, st0 = _grid_inputs(ld, ss, 6)
+        active = np.arange(6, dtype=np.int32)
+        ref = _run_grid(O, ld, inp, g, st0, active, 2)
+        ulp = _run_grid(O, ld, one_ulp(inp), g, st0, active, 2)
+        fast = _run_grid(fast_mode, ld, inp, g, st0, active, 2)
+    assert not all(np.array_equal(fast[k], ref[k]) for k in H.STATE), "fast mode did not run (results are bit-identical)"
+    assert_within_one_ulp_yardstick(fast, ref, ulp, f"band kernel, {model}, {'upper' if low_memory else 'symmetric'}")
