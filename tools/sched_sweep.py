@@ -12,10 +12,16 @@ upper = "upper" in sys.argv
 dt = np.int8 if "int8" in sys.argv else np.float32
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt)
 CONFIGS = [dict()]
-for lg, md in (("1792", "1600"), ("2304", "1280"), ("2304", "1408"), ("1792", "1280")):
+for lg, md in (("1792", "1600"), ("2304", "1280"), ("2304", "1408"), ("1792", "1280"), ("2816", "1600"), ("2304", "1024")):
     CONFIGS.append(dict(VIPRS_LARGE_BLOCK=lg, VIPRS_MEDIUM_BLOCK=md))
-CONFIGS.append(dict(VIPRS_LARGE_BLOCK="1792", VIPRS_MEDIUM_BLOCK="1280", VIPRS_TEAM0="8"))
-CONFIGS.append(dict(VIPRS_LARGE_BLOCK="1792", VIPRS_MEDIUM_BLOCK="1280", VIPRS_TEAM1="2"))
+for t0, t1 in (("8", "4"), ("16", "4"), ("12", "6"), ("12", "8"), ("16", "8"), ("12", "2")):
+    CONFIGS.append(dict(VIPRS_TEAM0=t0, VIPRS_TEAM1=t1))
+CONFIGS.append(dict(VIPRS_LARGE_BLOCK="1792", VIPRS_MEDIUM_BLOCK="1280", VIPRS_TEAM0="12", VIPRS_TEAM1="6"))
+CONFIGS.append(dict())                        # the default again (box drift over the run)
+if "teams" in sys.argv:
+    # team sizes only, three alternations (a box drifts by several % within a minute)
+    one = [dict(VIPRS_TEAM0=a, VIPRS_TEAM1=b) for a, b in (("12", "4"), ("16", "4"), ("14", "4"), ("16", "5"), ("16", "6"), ("12", "6"), ("12", "3"), ("16", "3"))]
+    CONFIGS = one * 3
 KEYS = ("VIPRS_BOTTOM_MOD", "VIPRS_MAX_WG_PER_CU", "VIPRS_TEAM0", "VIPRS_TEAM1", "VIPRS_LARGE_BLOCK", "VIPRS_MEDIUM_BLOCK")
 for cfg in CONFIGS:
     for k in KEYS:

@@ -170,14 +170,15 @@ template <typename U, int CPL> __device__ __forceinline__ RawRow<U, CPL> load_ra
 // columns per updater lane: 16-byte loads for fp32 and int16, 8-byte loads for int8 (wider strips leave
 // too few updater waves per block busy)
 template <typename U> __host__ __device__ constexpr int panel_cols() { return sizeof(U) == 4 ? 4 : 8; }
-// ... and per updater lane of a TEAM workgroup.  A team block is the sweep's critical path, and what bounds its phase is
-// not bandwidth but the memory LATENCY of its updater waves: a strip of 64 x CPL columns is one wave's unit of work per
-// phase (the fma chain of a column takes its rows in order), its 64 rows come in 64 / DEPTH round trips of ~2.5 us under
-// load, and with 4 columns per lane the 3 619-SNP block of cfg3 has 15 strips for the 36 updater waves of its 12 members:
-// most of them idle while the others need 4 round trips -- the in-kernel timeline showed the updaters of that block ending
-// their phase at 11-18 us against the chain's 9.  Narrower strips with proportionally more rows in flight (the same 64
-// VGPRs of row data per lane) give every wave of the team work and halve / quarter the round trips: 8-byte loads and 32
-// rows in flight for fp32 / int16 LD (29 strips, 2 round trips), 4-byte loads and all 64 rows in flight for int8.
+// ... and per updater lane of a LARGE TEAM's workgroup in the upper-triangular form (estep_sweep_kernel picks the role).
+// A team block is the sweep's critical path, and part of what bounds its phase is the memory LATENCY of its updater
+// waves: a strip of 64 x CPL columns is one wave's unit of work per phase (the fma chain of a column takes its rows in
+// order), its 64 rows come in 64 / DEPTH round trips of ~4 us under load (25 MB of row loads in flight on the chip), and
+// with 4 columns per lane the 3 619-SNP block of cfg3 has 15 strips for the 36 updater waves of its 12 members.  Narrower
+// strips with proportionally more rows in flight (the same 64 VGPRs of row data per lane) give every wave of the team
+// work and halve / quarter the round trips: 8-byte loads and 32 rows in flight for fp32 / int16 LD, 4-byte loads and all
+// 64 rows in flight for int8.  Worth 1.5-3 % where the updaters also carry the second pass (the upper form); the
+// symmetric form, whose sweep is bound by the stream, does better with the 16-byte loads.
 template <typename U> __host__ __device__ constexpr int panel_team_cols() {
 #ifdef PANEL_TEAM_CPL_F32
     return sizeof(U) == 4 ? PANEL_TEAM_CPL_F32 : 4;      // (experiments)
@@ -1278,6 +1279,7 @@ struct SweepArgs {
     EStepArgs<float> cls[3];     // per size class: block list, team geometry, queue counters
     int32_t qcap[3];             // LDS floats reserved for q per class (largest block of the class, padded)
     int32_t n_wg[2];             // team workgroups of class 0 / class 1 (0 = class empty)
+    int32_t narrow0;             // class 0 works on the narrow team strips (panel_team_cols): teams of 8 and more members
     // launch bookkeeping, done by the workgroup that finishes LAST instead of by a prologue launch: the small-block queue
     // heads go back to 0 for the next sweep and the skip counter moves to `skipped_last` (what the host reads)
     int32_t* done;               // workgroups that have finished
@@ -1290,10 +1292,18 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(S
     const int wg = blockIdx.x;
     const int team_cls = wg < S.n_wg[0] ? 0 : (wg < S.n_wg[0] + S.n_wg[1] ? 1 : 2);
     if (team_cls < 2) {
-        // (team strips are narrower for the lane-per-SNP models, panel_team_cols; the mixture chains, 3-4 x longer per step,
-        //  are never waiting for their updaters: measured 2.5 % slower with the narrow strips, they keep the wide ones)
-        constexpr int CPL_T = MODEL::kLaneParallel ? CPL : panel_team_cols<U>();
-        panel_role<U, MODEL, SYM, NW, true, CPL_T>(S.cls[team_cls], S.qcap[team_cls], smem, wg - (team_cls ? S.n_wg[0] : 0));
+        // Narrow team strips (panel_team_cols) for the LARGE teams of the largest class in the UPPER-TRIANGULAR form only.
+        // Measured, builds alternating on one box (EXPERIMENTS.md 4.2): upper fp32 cfg3max 1.09 -> 1.055 ms, int8 upper cfg3
+        // 0.510 -> 0.5025; the SYMMETRIC form loses with them (cfg3 fp32 0.755 -> 0.768, cfg3max 0.99 -> 1.04, int8
+        // +1 %), a block shared by 4 workgroups (the medium class; a populous large class) is bandwidth-bound and loses
+        // 5-12 % with the 8-byte loads (tools/mixed_blocks_bench.py: 300 x 2 400 SNPs 1.65 -> 1.85 ms), and the mixture
+        // chains, 3-4 x longer per step, never wait for their updaters (2.5 % slower): all of those keep the wide strips.
+        constexpr int CPL_N = (MODEL::kLaneParallel || SYM) ? CPL : panel_team_cols<U>();
+        const int wg_t = wg - (team_cls ? S.n_wg[0] : 0);
+        if (CPL_N != CPL && team_cls == 0 && S.narrow0)
+            panel_role<U, MODEL, SYM, NW, true, CPL_N>(S.cls[0], S.qcap[0], smem, wg_t);
+        else
+            panel_role<U, MODEL, SYM, NW, true, CPL>(S.cls[team_cls], S.qcap[team_cls], smem, wg_t);
         __syncthreads();
     }
     if (S.cls[2].n_blocks > 0) panel_role<U, MODEL, SYM, NW, false, CPL>(S.cls[2], S.qcap[2], smem, wg);
