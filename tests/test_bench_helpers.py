@@ -280,3 +280,32 @@ def test_sweep_time_model_names_its_bound():
     assert nsf < ns and tf < t8
     tg, boundg, _, _ = bench.sweep_time_model(sizes, by, "grid", "exact")
     assert boundg == "chain_throughput" and tg == pytest.approx(sizes.sum() * 430e-6 / 256)
+
+
+def test_bench_under_the_real_torch_launcher(tmp_path):
+    """The driver's own N > 1 command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 ...` (device layer stubbed through sitecustomize, file transport): the
+    environment the elastic agent really sets (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* / TORCHELASTIC_RUN_ID, one shared
+    parent process) drives the rendezvous keys, and rank 0 prints the one line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "sitecustomize.py").write_text(_SITE_STUB.format(root=root, ndev=2))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "VIPRS_BENCH_COMM")}
+    env.update(PYTHONPATH=str(tmp_path) + os.pathsep + env.get("PYTHONPATH", ""), TMPDIR=str(tmp_path), VIPRS_BENCH_COMM="file")
+    port = 29900 + os.getpid() % 90
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "cfg2", "--cpu-seconds", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and len(out["per_rank"]["snps"]) == 2
+    assert out["per_rank"]["kernel_ms_avg"] == pytest.approx([0.5, 0.51])
+    left = [f for f in os.listdir(tmp_path) if f.startswith("viprs_filecomm") or f.startswith("viprs_comm")]
+    assert left == [], left
