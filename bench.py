@@ -537,18 +537,29 @@ def launch_ranks(n, argv):
         threads.append(t)
     status = 0
     live = set(range(n))
-    while live:
-        for r in sorted(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0 and status == 0:
-                status = rc if rc > 0 else 1
-                sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks\n")
-                for q in live:                              # exactly the processes started above
+    deadline = time.time() + float(os.environ.get("VIPRS_BENCH_LAUNCH_TIMEOUT", "3600"))
+    try:
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+                    sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks\n")
+                    for q in live:                          # exactly the processes started above
+                        procs[q].terminate()
+            if live and time.time() > deadline and status == 0:
+                status = 124
+                sys.stderr.write(f"bench.py: ranks {sorted(live)} still running at the launch timeout; stopping them\n")
+                for q in live:
                     procs[q].terminate()
-        time.sleep(0.05)
+            time.sleep(0.05)
+    finally:
+        for p in procs:                                     # (interrupted parent: never leave rank processes behind)
+            if p.poll() is None:
+                p.kill()
     for t in threads:
         t.join(timeout=10)
     if status == 0 and len(outs[0]) != 1:
