@@ -161,3 +161,30 @@ def test_grid_resident_form_equals_streaming_form(gpu, low_memory, monkeypatch):
         out[mode] = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
     H.assert_state_equal(out["1"], out["0"])
     H.assert_state_equal(out["1"], _run_grid(O, ld, inp, g, st0, active, sweeps=2))
+
+
+@pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
+@pytest.mark.parametrize("sizes, ld_dtype, G, n_active", [
+    ([1537], np.float32, 32, 5),                   # one tile beyond the resident form: a team of 2, the second member holds one tile
+    ([3072, 100], np.float32, 32, 4),              # exactly two members' worth of tiles
+    ([3073, 700], np.float32, 8, 8),               # three members, the third holds one tile
+    ([3619, 1600, 650], np.float32, 32, 6),        # cfg3's largest block + a team of 2 + a single-workgroup block
+    ([4700], np.float32, 12, 3),                   # four members
+    ([2400, 1700], np.int8, 32, 5),
+    ([1700, 3000], np.int16, 6, 6),
+])
+def test_grid_mfma_team_blocks(gpu, sizes, ld_dtype, G, n_active, low_memory, monkeypatch):
+    """Blocks beyond the batched grid kernel's resident form (> 1 536 SNPs) on TEAMS of workgroups with a migrating chain
+    (estep_grid_mfma.h, GridTeam): `==` the oracle on far-field LD, two sweeps (the second one meets the first one's
+    generation-tagged a-vector granules), and `==` the streaming form + lower pass they replace (VIPRS_GRID_TEAMS=0)."""
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=ld_dtype, seed=41, kind="longrange")
+    g, st0 = _grid_inputs(ld, ss, G)
+    active = np.random.default_rng(G + n_active).permutation(G)[:n_active].astype(np.int32)
+    ref = _run_grid(O, ld, inp, g, st0, active, sweeps=2)
+    got = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
+    H.assert_state_equal(got, ref)
+    monkeypatch.setenv("VIPRS_GRID_TEAMS", "0")
+    old = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
+    H.assert_state_equal(old, ref)

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_farfield.py tests/test_gpu_fullsize_parity.py tests/test_grid.py -m gpu -x -q -k "grid" 2>&1 | tail -5
+for extra in "--model grid" "--model grid --low-memory" "--model grid --ld-dtype int8"; do timeout 300 python bench.py --no-secondary --cpu-seconds 0 $extra | python -c "
+import sys, json
+d=json.loads(sys.stdin.read()); print('$extra', 'kernel %.4f ms/step %.4f'%(d['roofline']['kernel_ms_avg'], d['ms_per_step']))"; done
+VIPRS_GRID_TEAMS=0 timeout 300 python bench.py --no-secondary --cpu-seconds 0 --model grid | python -c "
+import sys, json
+d=json.loads(sys.stdin.read()); print('teams off', 'kernel %.4f ms/step %.4f'%(d['roofline']['kernel_ms_avg'], d['ms_per_step']))"

@@ -692,10 +692,26 @@ __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __rest
     }
 }
 
+// Teams (blocks beyond one workgroup's accumulator capacity, TS > 1): member m of a team of TS workgroups on TS CUs holds
+// the tiles [12 m, 12 m + 12) of the block -- panels [24 m, 24 m + 24) -- resident in ITS owner waves' accumulators, and
+// every member runs the same phase loop over all panels of the block.  The CHAIN MIGRATES: the member whose range
+// holds panel p runs its 64 serial updates (its carry wave has the panel ready exactly as in a single-workgroup block),
+// the others RECEIVE the panel's a-vector (64 x 32 floats = 16 KB, published by the holder's carry wave as generation-
+// tagged 8-byte granules: relaxed agent-scope atomics, the data is the flag) and apply it to their own tiles one phase
+// behind -- tiles right of the chain, and in the symmetric form the tiles left of it, which is what the lower-pass
+// kernel did for such blocks.  No q value ever crosses a CU (the chain goes to where q lives), every LD row of the
+// block is read once, q once in and once out, and no chain step is computed twice.
+struct GridTeam {
+    int member = 0, size = 1;
+    unsigned long long* gran = nullptr;       // this block's a-vector granules: [panel][64 x 32]
+    uint32_t tag_base = 0;                    // generation << 12; a granule of panel p carries tag_base + p + 1
+};
+constexpr int kGridTeamPanels = 2 * kGridResOwners * kGridResSlots;       // 24 panels (12 tiles) per member
+
 template <typename U, bool SYM, bool EXACT>
 __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, float* io, float* la, float* dg, f32x4* cy,
                                                     float* qx, const int* s_act, const BlockDesc& bd, int wave, int lane,
-                                                    int n_models, float dq, const ExpTab& tab) {
+                                                    int n_models, float dq, const ExpTab& tab, const GridTeam tm = GridTeam()) {
     constexpr int NU = kGridNU;
     const int64_t s0 = bd.start;
     const int b = bd.size, stride = bd.stride;
@@ -703,6 +719,47 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     const int np = (b + kPanel - 1) / kPanel;
     float* cq = reinterpret_cast<float*>(cy + 16 * 64);          // [32 models][64 columns]: a panel on its way to the carry
     const int half = lane >> 5, n = lane & 31;
+    // team geometry (a single workgroup: member 0 of 1, every panel its own)
+    const bool team = tm.size > 1;
+    const int p_lo = tm.member * kGridTeamPanels, p_hi = min(np, p_lo + kGridTeamPanels);
+    const int T_lo = tm.member * kGridResOwners * kGridResSlots;
+    auto mine = [&](int p) { return !team || (p >= p_lo && p < p_hi); };
+    // upper-triangular form: a member whose panels the chain has passed has nothing left to receive
+    const int p_end = (team && !SYM) ? min(np, p_hi) : np;
+    // the a-vector of panel p: published by the holder's carry wave, received by the other members' chain wave
+    auto publish_a = [&](int p) {
+        const float* src = la + (p & 1) * kGridAFloats;
+        unsigned long long* g = tm.gran + (int64_t)p * kGridAFloats;
+        const unsigned long long tag = (unsigned long long)(tm.tag_base + (unsigned)(p + 1)) << 32;
+#pragma unroll 8
+        for (int i = 0; i < kGridAFloats / 64; ++i)
+            __hip_atomic_store(g + i * 64 + lane, tag | (unsigned long long)__float_as_uint(src[i * 64 + lane]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto receive_a = [&](int p) {
+        float* dst = la + (p & 1) * kGridAFloats;
+        const unsigned long long* g = tm.gran + (int64_t)p * kGridAFloats;
+        const unsigned want = tm.tag_base + (unsigned)(p + 1);
+        for (int i0 = 0; i0 < kGridAFloats / 64; i0 += 8) {
+            unsigned long long v[8];
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = __hip_atomic_load(g + (i0 + k) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(v[k] >> 32) == want;
+                }
+                if (__all(ok)) break;
+                if (spins > (1u << 22)) {              // ~seconds: give up loudly, never hang
+                    if (lane == 0) atomicExch(A.error, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[(i0 + k) * 64 + lane] = __uint_as_float((unsigned)v[k]);
+        }
+    };
 
     // the per-panel input / output staging of the streaming form (waves 1..7; sym: q of a panel is NOT written here)
     auto stage_inputs = [&](int pp, bool with_q) {
@@ -767,9 +824,9 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     if (wave == 0) {
         // ================================================= chain =========================================================
         __syncthreads();                                            // B0: inputs of panel 0 staged
-        for (int p = 0; p <= np; ++p) {
+        for (int p = 0; p <= p_end; ++p) {
             __syncthreads();                                        // mid: the carry has put panel p into qx
-            if (p < np) {
+            if (p < np && mine(p)) {
 #ifdef VIPRS_GRID_MFMA_CHAIN
                 grid_chain_panel_mfma<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
 #else
@@ -779,21 +836,24 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
 #endif
                                       );
 #endif
+            } else if (p < np && (SYM || p < p_hi)) {
+                receive_a(p);                                       // another member holds the chain: its a-vector -> la
             }
             __syncthreads();                                        // end
         }
     } else if (wave == kGridCarryWave) {
         // ================================================= carry =========================================================
-        stage_inputs(0, true);
+        if (mine(0)) stage_inputs(0, true);
         __syncthreads();                                            // B0
         // the carried panel: during phase p it is panel p+1 (taking a_{p-1}), between the chain's panels it is finished
         // with a_p and handed to the chain; then the next one is picked up (ONE set of 32 accumulators, in registers
-        // across the barriers)
+        // across the barriers).  Teams: only for the panels of this member's own range (the a-vectors it applies are
+        // its own chain's or the ones its chain wave received).
         f32x16 c0v, c1v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { c0v[r] = 0.0f; c1v[r] = 0.0f; }
-        for (int p = 0; p <= np; ++p) {
-            if (p > 0 && p < np) {
+        for (int p = 0; p <= p_end; ++p) {
+            if (p > 0 && p < np && mine(p)) {
                 float R1[kPanel];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -810,7 +870,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                     qd[g * kGridQxPitch + 32] = c1v[r];
                 }
             }
-            if (p + 1 < np) {
+            if (p + 1 < np && mine(p + 1)) {
                 // panel p+1 as its owner left it at the end of the previous phase (a_0 .. a_{p-2} applied)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -820,9 +880,10 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                 }
             }
             __syncthreads();                                        // mid
-            if (p > 0) flush_outputs(p - 1);
-            if (p + 1 < np) stage_inputs(p + 1, false);
-            if (p + 1 < np) {
+            if (team && p > 0 && mine(p - 1)) publish_a(p - 1);     // (first: the other members' tiles wait for it)
+            if (p > 0 && mine(p - 1)) flush_outputs(p - 1);
+            if (p + 1 < np && mine(p + 1)) stage_inputs(p + 1, false);
+            if (p + 1 < np && mine(p + 1)) {
                 // one tile of LD rows at a time (this wave has the whole phase for two memory round trips; both tiles in
                 // registers at once, 128 VGPRs, is what pushed loop-invariant addresses of every role into scratch)
                 if (p > 0) {
@@ -841,8 +902,9 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     } else {
         // ================================================= owners ========================================================
         const int ow = wave < kGridCarryWave ? wave - 1 : wave - 2;     // waves 1, 2, 3, 5, 6, 7
-        f32x16 accA[4], accB[4];                                    // tiles T = ow and T = ow + kGridResOwners
-        const int cA = ow * 2 * kPanel, cB = (ow + kGridResOwners) * 2 * kPanel;
+        f32x16 accA[4], accB[4];                                    // tiles T = T_lo + ow and T = T_lo + ow + kGridResOwners
+        const int TA = T_lo + ow, TB = T_lo + ow + kGridResOwners;
+        const int cA = TA * 2 * kPanel, cB = TB * 2 * kPanel;
         const bool hasA = cA < b, hasB = cB < b;
         auto load_tile = [&](f32x16 (&acc)[4], int c0, bool has) {
             if (!has) {
@@ -884,19 +946,19 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
         };
         auto tile_of = [&](int panel) { return panel >> 1; };
         if (np > 1) {
-            if (tile_of(1) == ow) extract(accA, 1);                 // (tile 0 is wave 2's first tile)
+            if (tile_of(1) == TA) extract(accA, 1);                 // (tile 0 is wave 2's first tile)
         }
-        stage_inputs(0, true);
+        if (mine(0)) stage_inputs(0, true);
         __syncthreads();                                            // B0
-        for (int p = 0; p <= np; ++p) {
+        for (int p = 0; p <= p_end; ++p) {
             __syncthreads();                                        // mid
-            if (p > 0) flush_outputs(p - 1);
-            if (p + 1 < np) stage_inputs(p + 1, false);
+            if (p > 0 && mine(p - 1)) flush_outputs(p - 1);
+            if (p + 1 < np && mine(p + 1)) stage_inputs(p + 1, false);
             if (p > 0) {
                 const int pp = p - 1;
                 if (SYM) {
-                    if (tile_of(pp) == ow) take_back(accA, pp);
-                    else if (tile_of(pp) == ow + kGridResOwners) take_back(accB, pp);
+                    if (tile_of(pp) == TA) take_back(accA, pp);
+                    else if (tile_of(pp) == TB) take_back(accB, pp);
                 }
                 const float* a_lds = la + (pp & 1) * kGridAFloats;
                 auto panel_on = [&](int c) {
@@ -904,19 +966,18 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                     return SYM ? (c < p - 1 || c > p + 1) : (c > p + 1);
                 };
                 if (hasA) {
-                    const bool l = panel_on(2 * ow), r = panel_on(2 * ow + 1);
+                    const bool l = panel_on(2 * TA), r = panel_on(2 * TA + 1);
                     if (l || r) res_tile_apply<U, 1>(accA, base, stride, pp, cA, lane, l, r, a_lds);
                 }
                 if (hasB) {
-                    const int T = ow + kGridResOwners;
-                    const bool l = panel_on(2 * T), r = panel_on(2 * T + 1);
+                    const bool l = panel_on(2 * TB), r = panel_on(2 * TB + 1);
                     if (l || r) res_tile_apply<U, 1>(accB, base, stride, pp, cB, lane, l, r, a_lds);
                 }
             }
             if (p + 2 < np) {
                 const int e = p + 2;                                // (a_0 .. a_{p-1} applied) -> the carry's next panel
-                if (tile_of(e) == ow) extract(accA, e);
-                else if (tile_of(e) == ow + kGridResOwners) extract(accB, e);
+                if (tile_of(e) == TA) extract(accA, e);
+                else if (tile_of(e) == TB) extract(accB, e);
             }
             __syncthreads();                                        // end
         }
@@ -932,8 +993,21 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     }
 }
 
+// Team blocks of a launch (host: launch_grid.inc): the first `n_wgs` workgroups are team members -- workgroup w is member
+// `member[w]` of the team of block `block[w]` (the `n_blocks` largest blocks of the size-sorted list, all of them beyond the
+// resident form) -- and join the queue of the remaining blocks when their team block is done.
+struct GridTeams {
+    int32_t n_wgs = 0, n_blocks = 0;
+    const int32_t* block = nullptr;           // [n_wgs]
+    const int32_t* member = nullptr;          // [n_wgs]
+    const int32_t* size = nullptr;            // [n_wgs] team size
+    const int64_t* goff = nullptr;            // [n_blocks] granule offset of the block's a-vectors
+    unsigned long long* gran = nullptr;
+    uint32_t tag_base = 0;
+};
+
 template <typename U, bool SYM, bool EXACT>
-__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, int resident_max) {
+__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, int resident_max, GridTeams teams) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* io = smem;                                   // [2][4][32][65]: mm, ulog, hvt, eta -> mu, gamma, d, eta'
     float* la = smem + 2 * kGridIoFloats;               // [2][64][32] scaled eta_diff of a panel
@@ -954,8 +1028,18 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
     if (tid < kGridModels) s_act[tid] = A.active[min(tid, n_models - 1)];
     __syncthreads();
 
+    if ((int)blockIdx.x < teams.n_wgs) {
+        const int tb = teams.block[blockIdx.x];
+        GridTeam tm;
+        tm.member = teams.member[blockIdx.x];
+        tm.size = teams.size[blockIdx.x];
+        tm.gran = teams.gran + teams.goff[tb];
+        tm.tag_base = teams.tag_base;
+        grid_block_resident<U, SYM, EXACT>(A, io, la, dg, cy, qx, s_act, A.blocks[tb], wave, lane, n_models, dq, tab, tm);
+        __syncthreads();
+    }
     for (;;) {
-        if (tid == 0) s_blk = atomicAdd(A.counter, 1);
+        if (tid == 0) s_blk = teams.n_blocks + atomicAdd(A.counter, 1);       // (the team blocks are the head of the list)
         __syncthreads();
         const int blk = s_blk;
         __syncthreads();

@@ -122,6 +122,14 @@ struct viprs_plan {
     bool skip_count_in_place = false;              // the last sweep ran kernels that leave their count in [0] (no panel-sweep epilogue moved it)
     viprs::DevBuf<int32_t> d_arrive;               // panel sweep: arrival counters of the team (block, model) items; [last]: workgroups done
     uint32_t granule_gen = 0;                      // panel sweep launches so far (mod 2^20): generation of the hand-off tags
+    // batched grid kernel, teams for the blocks beyond its resident form (launch_grid.inc): per team workgroup (block of the
+    // size-sorted list, member, team size), per team block the offset of its a-vector granules
+    bool grid_teams_built = false;
+    int grid_team_blocks = 0, grid_team_wgs = 0;
+    viprs::DevBuf<int32_t> d_grid_team_block, d_grid_team_member, d_grid_team_size;
+    viprs::DevBuf<int64_t> d_grid_team_goff;
+    viprs::DevBuf<unsigned long long> d_grid_gran;
+    uint32_t grid_gen = 0;
     // HIP-event ring: per sweep {sweep start, sweep end, panel start, panel end}, recorded on
     // the stream the kernels are launched on
     static constexpr int kRing = 256;
