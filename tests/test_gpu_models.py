@@ -188,3 +188,23 @@ def test_grid_mfma_team_blocks(gpu, sizes, ld_dtype, G, n_active, low_memory, mo
     monkeypatch.setenv("VIPRS_GRID_TEAMS", "0")
     old = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
     H.assert_state_equal(old, ref)
+
+
+def test_grid_mfma_more_team_blocks_than_fit(gpu, monkeypatch):
+    """More blocks beyond the resident form than half the chip has workgroups for (70 x 1 600-SNP blocks = 140 team
+    workgroups on 256 CUs): the largest take teams, the rest keep the streaming form + lower pass (which skips the team
+    blocks) -- `==` the all-streaming schedule."""
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_GRID_MFMA", "1")
+    ld, ss, inp = syn.make_problem(sizes=[1700] + [1600] * 69 + [300] * 10, low_memory=False, seed=43, kind=KIND)
+    g, st0 = _grid_inputs(ld, ss, 8)
+    active = np.arange(8, dtype=np.int32)
+    got = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
+    monkeypatch.setenv("VIPRS_GRID_TEAMS", "0")
+    old = _run_grid(S, ld, inp, g, st0, active, sweeps=2)
+    H.assert_state_equal(got, old)
+    # ... and two of the models against the oracle
+    monkeypatch.delenv("VIPRS_GRID_TEAMS")
+    ref = _run_grid(O, ld, inp, g, st0, active[:2], sweeps=2)
+    got2 = _run_grid(S, ld, inp, g, st0, active[:2], sweeps=2)
+    H.assert_state_equal(got2, ref)

@@ -1362,7 +1362,8 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
 // ---------------------------------------------------------------------------------------------
 template <typename U>
 __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kernel(EStepArgs<float> A, const EpiItem* items,
-                                                                                   int n_items, int32_t* counter, int split) {
+                                                                                   int n_items, int32_t* counter, int split,
+                                                                                   int skip_blocks_below) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_act[kGridModels];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1378,6 +1379,7 @@ __global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kern
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
         const EpiItem it = items[item];
+        if (it.blk < skip_blocks_below) continue;           // (a team block of the sweep: its left columns are done)
         // row0 = index of the 128-column tile; split launches: 2 x tile + column-group pair
         if (!split) grid_lower_tile<U, -1>(A, s_act, A.blocks[it.blk], it.row0, el, lane, n_models, dq);
         else if (it.row0 & 1) grid_lower_tile<U, 1>(A, s_act, A.blocks[it.blk], it.row0 >> 1, el, lane, n_models, dq);

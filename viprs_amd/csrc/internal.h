@@ -126,6 +126,7 @@ struct viprs_plan {
     // size-sorted list, member, team size), per team block the offset of its a-vector granules
     bool grid_teams_built = false;
     int grid_team_blocks = 0, grid_team_wgs = 0;
+    std::vector<int> grid_team_ts;                 // team size per team block (largest block first)
     viprs::DevBuf<int32_t> d_grid_team_block, d_grid_team_member, d_grid_team_size;
     viprs::DevBuf<int64_t> d_grid_team_goff;
     viprs::DevBuf<unsigned long long> d_grid_gran;
