@@ -1267,25 +1267,28 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
 // lane n supplies row n as the B operand; the eta_diff tile goes through LDS as [k][model].
 // ---------------------------------------------------------------------------------------------
 constexpr int kGridEpiTPitch = kPanel + 1, kGridEpiEPitch = kGridModels + 1;
-constexpr int kGridEpiWaveFloats = kPanel * kGridEpiTPitch + kPanel * kGridEpiEPitch;
+constexpr int kGridEpiWaveFloats = 2 * kPanel * kGridEpiEPitch;        // two eta_diff tiles [64 k][33] per wave
 constexpr int kGridEpiWaves = 4;        // (3 waves x 2 workgroups per CU: 7 % slower; 2 x 3: the same)
 
+// (round 4) The LD tile is no longer transposed through LDS: lane n loads ITS OWN rows (n and 32 + n of the group; 16 bytes =
+// four consecutive columns per load, 16 loads per row and tile) and so holds the B operands of its accumulator columns
+// directly -- the MFMA's two k slots are the even (lanes 0-31) and odd (lanes 32-63) column of a pair, picked from the
+// loaded four by the lane's half.  Both halves load the same rows (the second read hits L1); what is gone are the 64 LDS
+// writes and 64 LDS reads per lane and tile that the transposition cost (the eta_diff tile still goes through LDS as
+// [k][model]).
 template <typename U>
 __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_kernel(EStepArgs<float> A,
                                                                                        const EpiItem* items, int n_items,
                                                                                        int32_t* counter) {
-    using V = typename Vec4<U>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_act[kGridModels];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* tl = smem + wave * kGridEpiWaveFloats;       // [64 rows][65]  LD tile, row-major
-    float* el = tl + kPanel * kGridEpiTPitch;           // [64 k][33]     eta_diff tile, [k][model]
+    float* el = smem + wave * kGridEpiWaveFloats;       // [2][64 k][33]   eta_diff tiles, [k][model], double-buffered
     const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
     const int n_models = A.n_active;
     if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
     __syncthreads();
     const int half = lane >> 5, l31 = lane & 31;
-    const int lrow = lane >> 4, lcol = (lane & 15) * 4;  // tile loads: 4 rows x 64 columns per instruction
 
     for (;;) {
         int item = 0;
@@ -1297,48 +1300,73 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
         const int b = bd.size, stride = bd.stride, r0 = it.row0;
         const int64_t s0 = bd.start;
         const int nrows = min(kPanel, b - r0);
-        const U* __restrict__ base = ldd + bd.ld_off + (int64_t)r0 * stride + lcol;
+        // this lane's two rows (clamped into the group: rows past the block are loaded, never stored)
+        const char* __restrict__ row0p = reinterpret_cast<const char*>(ldd + bd.ld_off + (int64_t)(r0 + min(l31, nrows - 1)) * stride);
+        const char* __restrict__ row1p = reinterpret_cast<const char*>(ldd + bd.ld_off + (int64_t)(r0 + min(32 + l31, nrows - 1)) * stride);
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
 
-        V cur[16], nxt[16];
-        float ecur[kGridModels], enxt[kGridModels];
-        auto load_tile = [&](V (&t)[16], float (&e)[kGridModels], int c0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                t[i] = *reinterpret_cast<const V*>(base + (int64_t)min(4 * i + lrow, nrows - 1) * stride + c0);
-            const int col = c0 + lane;
-            const unsigned off = (unsigned)s0 + (unsigned)min(col, b - 1);
+        // 8 pieces of 4 columns = half a tile (32 columns) of both rows per buffer, two buffers: the next half tile's loads
+        // are in flight while the current one is multiplied (fp32: 2 x 64 VGPRs of rows)
+        constexpr int PIECES = 8;
+        RawCols4<U> va0[PIECES], va1[PIECES], vb0[PIECES], vb1[PIECES];
+        float e[kGridModels];
+        auto load_e = [&](int c0) {
+            const unsigned off = (unsigned)s0 + (unsigned)min(c0 + lane, b - 1);
 #pragma unroll
             for (int g = 0; g < kGridModels; ++g) e[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
+        };
+        auto load_half = [&](RawCols4<U> (&w0)[PIECES], RawCols4<U> (&w1)[PIECES], int cc) {     // 32 columns from cc
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                w0[i] = load_cols4<U>(row0p + (size_t)(cc + 4 * i) * sizeof(U));
+                w1[i] = load_cols4<U>(row1p + (size_t)(cc + 4 * i) * sizeof(U));
+            }
             asm volatile("" ::: "memory");
         };
-        load_tile(cur, ecur, r0);
+        auto mult_half = [&](const RawCols4<U> (&w0)[PIECES], const RawCols4<U> (&w1)[PIECES], const float* eb, int h) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                // columns 32 h + 4 i .. + 3: the pairs (0, 1) and (2, 3); the lane's half picks its column of the pair
+                const int kk = 32 * h + 4 * i;
+                const float a0 = eb[(kk + half) * kGridEpiEPitch + l31];
+                const float a1 = eb[(kk + 2 + half) * kGridEpiEPitch + l31];
+                const float b00 = half ? w0[i].template get<1>() : w0[i].template get<0>();
+                const float b10 = half ? w1[i].template get<1>() : w1[i].template get<0>();
+                const float b01 = half ? w0[i].template get<3>() : w0[i].template get<2>();
+                const float b11 = half ? w1[i].template get<3>() : w1[i].template get<2>();
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b10, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b01, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, acc1, 0, 0, 0);
+            }
+        };
+        // integer LD (16 / 32 VGPRs per half tile): the next half tile's loads are in flight while the current one is
+        // multiplied (int8 upper, cfg3: 2.25 -> 2.08 ms per sweep); fp32 LD (2 x 64 VGPRs: one workgroup per CU less)
+        // measured slower that way (2.34 -> 2.40) and loads half by half
+        constexpr bool kPrefetch = sizeof(U) < 4;
+        int buf = 0;
+        if (kPrefetch) load_half(va0, va1, r0);
         for (int c0 = r0; c0 < b; c0 += kPanel) {
-            const int cn = (c0 + kPanel < b) ? c0 + kPanel : c0;            // next tile (or this one again)
-            load_tile(nxt, enxt, cn);
+            float* eb = el + buf * (kPanel * kGridEpiEPitch);
+            load_e(c0);
+            if (kPrefetch) load_half(vb0, vb1, c0 + 32);                  // second half of this tile
+            else load_half(va0, va1, c0);
             const bool colok = c0 + lane < b;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tl[(4 * i + lrow) * kGridEpiTPitch + lcol + e] = static_cast<float>(cur[i][e]);
-#pragma unroll
-            for (int g = 0; g < kGridModels; ++g) el[lane * kGridEpiEPitch + g] = (colok && g < n_models) ? ecur[g] : 0.0f;
+            for (int g = 0; g < kGridModels; ++g) eb[lane * kGridEpiEPitch + g] = (colok && g < n_models) ? e[g] : 0.0f;
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int kk = 0; kk < kPanel; kk += 2) {
-                const float aop = el[(kk + half) * kGridEpiEPitch + l31];
-                const float b0 = tl[l31 * kGridEpiTPitch + kk + half];
-                const float b1 = tl[(32 + l31) * kGridEpiTPitch + kk + half];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b1, acc1, 0, 0, 0);
+            mult_half(va0, va1, eb, 0);
+            if constexpr (kPrefetch) {
+                // first half of the next tile (clamped to this one at the end of the row: loaded, never used)
+                load_half(va0, va1, (c0 + kPanel < b) ? c0 + kPanel : c0);
+                mult_half(vb0, vb1, eb, 1);
+            } else {
+                load_half(va0, va1, c0 + 32);            // (the same registers: one half tile of rows live at a time)
+                mult_half(va0, va1, eb, 1);
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
-#pragma unroll
-            for (int g = 0; g < kGridModels; ++g) ecur[g] = enxt[g];
+            buf ^= 1;                                    // (the other buffer: no barrier needed before the next tile's stores)
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
