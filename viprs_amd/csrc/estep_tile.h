@@ -602,11 +602,32 @@ __global__ __launch_bounds__(kTileThreads, 3) void tile_f64_second_pass_kernel(E
                 }
             }
         }
+        // The 8 row sums across the 64 lanes, all at once: three exchange steps in which a lane gives away the half of its
+        // values it does not keep (after them lane l holds the 8-lane partial of row l & 7), then three steps across the
+        // 8-lane groups -- 10 double exchanges instead of 48 (each one is two ds_bpermute; with ~1 000 columns per item the
+        // reduction was as long as the fma loop).
+        static_assert(R == 8, "the butterfly below reduces 8 rows");
+        {
+            T t4[4], t2[2], t1;
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
+            for (int j = 0; j < 4; ++j) {
+                const T give = b0 ? s[2 * j] : s[2 * j + 1], keep = b0 ? s[2 * j + 1] : s[2 * j];
+                t4[j] = keep + __shfl_xor(give, 1);                  // rows 2 j + (lane & 1)
+            }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
-            if (lane == 0 && k < nr) A.q[s0 + row0 + k] += A.dq * s[k];
+            for (int j = 0; j < 2; ++j) {
+                const T give = b1 ? t4[2 * j] : t4[2 * j + 1], keep = b1 ? t4[2 * j + 1] : t4[2 * j];
+                t2[j] = keep + __shfl_xor(give, 2);                  // rows 4 j + (lane & 3)
+            }
+            {
+                const T give = b2 ? t2[0] : t2[1], keep = b2 ? t2[1] : t2[0];
+                t1 = keep + __shfl_xor(give, 4);                     // row lane & 7
+            }
+            t1 += __shfl_xor(t1, 8);
+            t1 += __shfl_xor(t1, 16);
+            t1 += __shfl_xor(t1, 32);
+            if (lane < R && lane < nr) A.q[s0 + row0 + lane] += A.dq * t1;
         }
         g = g_n;
         g_n = g_nn;
