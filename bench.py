@@ -798,6 +798,9 @@ def main():
                 "bound": "hbm",
                 "kernel": ("estep_grid_mfma_kernel (one workgroup per LD block, LD read once for all models)"
                            + (" + estep_grid_upper_epilogue_kernel" if ld.low_memory else "")) if args.model == "grid" else
+                          ("estep_tile_f64_kernel (float64 state: one workgroup per LD block, two block-size classes on two "
+                           "streams" + (" + tile_f64_second_pass_dense_kernel" if ld.low_memory else "") + ")")
+                          if args.precision == "float64" else
                           ("estep_sweep_kernel (ONE launch per sweep: team workgroups for the large LD blocks, small-block workers "
                            "behind them" + ("; the upper-triangular form's second pass runs inside it" if ld.low_memory else "") + ")"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n_gpus),

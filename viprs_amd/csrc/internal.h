@@ -124,6 +124,8 @@ struct viprs_plan {
     uint32_t granule_gen = 0;                      // panel sweep launches so far (mod 2^20): generation of the hand-off tags
     // batched grid kernel, teams for the blocks beyond its resident form (launch_grid.inc): per team workgroup (block of the
     // size-sorted list, member, team size), per team block the offset of its a-vector granules
+    // the split of the team budget between the two team classes (launch_panel.inc) depends on the plan and on these only
+    struct TeamSplit { int64_t key[6] = {-1, -1, -1, -1, -1, -1}; int best[2] = {0, 0}; } team_split;
     bool grid_teams_built = false;
     int grid_team_blocks = 0, grid_team_wgs = 0;
     std::vector<int> grid_team_ts;                 // team size per team block (largest block first)

@@ -73,9 +73,16 @@ int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
         A2.n_blocks = (int)list.size();
         const int64_t* pp = groups.p + first;
         void* params2[] = {(void*)&A2, (void*)&pp, (void*)&count};
-        const void* k2 = dense ? (const void*)tile_f64_second_pass_kernel<U, true> : (const void*)tile_f64_second_pass_kernel<U, false>;
         const int64_t n_items = count * std::max(1, A.n_active);
-        const int grid = (int)std::min<int64_t>((n_items + kTileThreads / 64 - 1) / (kTileThreads / 64), (int64_t)cus * 8);
+        const void* k2 = dense ? (const void*)tile_f64_second_pass_dense_kernel<U> : (const void*)tile_f64_second_pass_kernel<U, false>;
+        // (the dense kernel: as many workgroups as are resident at a time, each wave a pipeline over its share of the groups)
+        int per_cu = 8;
+        if (dense) {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2, kTileThreads, 0));
+            per_cu = std::max(1, per_cu);
+            if (const char* f = getenv("VIPRS_F64_PASS2_WGS")) if (*f) per_cu = std::max(1, atoi(f));       // experiments
+        }
+        const int grid = (int)std::min<int64_t>((n_items + kTileThreads / 64 - 1) / (kTileThreads / 64), (int64_t)cus * per_cu);
         HIP_TRY(hipLaunchKernel(k2, dim3(grid), dim3(kTileThreads), params2, 0, stream));
         return VIPRS_OK;
     };
