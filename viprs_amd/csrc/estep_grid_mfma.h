@@ -1267,7 +1267,15 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
 // lane n supplies row n as the B operand; the eta_diff tile goes through LDS as [k][model].
 // ---------------------------------------------------------------------------------------------
 constexpr int kGridEpiTPitch = kPanel + 1, kGridEpiEPitch = kGridModels + 1;
-constexpr int kGridEpiWaveFloats = 2 * kPanel * kGridEpiEPitch;        // two eta_diff tiles [64 k][33] per wave
+// One eta_diff tile [64 k][33] per wave: the LDS operations of a wave execute in issue order, so the next tile's stores
+// need no second buffer behind this tile's reads -- and with 34 instead of 68 KB per workgroup three workgroups fit a CU
+// (registers permitting) instead of two: cfg3 upper form 2.406 -> 2.382 ms (fp32 LD), 2.085 -> 2.042 (int8), tools/multi_ab.py.
+// (-DGRID_EPI_BUFS=2: the double-buffered variant.)
+#ifndef GRID_EPI_BUFS
+#define GRID_EPI_BUFS 1
+#endif
+constexpr int kGridEpiBufs = GRID_EPI_BUFS;
+constexpr int kGridEpiWaveFloats = kGridEpiBufs * kPanel * kGridEpiEPitch;
 constexpr int kGridEpiWaves = 4;        // (3 waves x 2 workgroups per CU: 7 % slower; 2 x 3: the same)
 
 // (round 4) The LD tile is no longer transposed through LDS: lane n loads ITS OWN rows (n and 32 + n of the group; 16 bytes =
@@ -1283,7 +1291,7 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_act[kGridModels];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* el = smem + wave * kGridEpiWaveFloats;       // [2][64 k][33]   eta_diff tiles, [k][model], double-buffered
+    float* el = smem + wave * kGridEpiWaveFloats;       // [64 k][33]   eta_diff tile, [k][model]
     const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
     const int n_models = A.n_active;
     if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
@@ -1366,7 +1374,7 @@ __global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_
                 load_half(va0, va1, c0 + 32);            // (the same registers: one half tile of rows live at a time)
                 mult_half(va0, va1, eb, 1);
             }
-            buf ^= 1;                                    // (the other buffer: no barrier needed before the next tile's stores)
+            buf ^= kGridEpiBufs - 1;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
