@@ -185,7 +185,8 @@ def test_float64_cfg3_full_size(gpu, low_memory):
 
 
 @pytest.mark.parametrize("low_memory", [False, True])
-@pytest.mark.parametrize("K", [1, 3, 4, 6])         # <= 4: the panel-walking kernel (estep_tile.h); 6: row by row
+# K <= 4 and 5 .. 10: the panel-walking kernel (estep_tile.h; 10 = the reference's own test, tests/test_basic.py:60); 12: row by row
+@pytest.mark.parametrize("K", [1, 3, 4, 6, 10, 12])
 def test_float64_mixture_matches_oracle(gpu, K, low_memory):
     from tests.test_gpu_models import _run_mix
     from tests.test_oracle_vs_ref import _mixture_inputs

@@ -84,11 +84,14 @@ __device__ __forceinline__ double sigmoid_f64_uniform(double x, const ExpTab64& 
 }
 
 // spike-and-slab (e_step.hpp:401-413) / one model of the grid (e_step.hpp:613-620: no skip branch, half_var_tau, no fma)
-constexpr int kTileMixK = 4;       // sparse mixture on this kernel: up to 4 components (more: estep_generic.h)
+constexpr int kTileMixK = 4;       // sparse mixture on this kernel: up to 4 components with the inputs prefetched a panel ahead,
+constexpr int kTileMixWideK = 10;  // up to 10 (the reference's own test, tests/test_basic.py:60) loading them at the panel's start
+                                   // (more: estep_generic.h)
 
 struct TileSpikeSlab {
     static constexpr bool kSkip = true;
     static constexpr bool kMixture = false;
+    static constexpr int kSlots = 1;
     __device__ static __forceinline__ void update(double mm, double beta, double s, double ulog, double eta_old, double qj,
                                                   const ExpTab64& tab, double& mu, double& gamma, double& d) {
         const double p = mm * qj;
@@ -101,6 +104,7 @@ struct TileSpikeSlab {
 struct TileGridColumn {
     static constexpr bool kSkip = false;
     static constexpr bool kMixture = false;
+    static constexpr int kSlots = 1;
     __device__ static __forceinline__ void update(double mm, double beta, double hvt, double ulog, double eta_old, double qj,
                                                   const ExpTab64& tab, double& mu, double& gamma, double& d) {
         mu = mm * (beta - qj);
@@ -113,9 +117,14 @@ struct TileGridColumn {
 // e_step_mixture (e_step.hpp:447-551) with K <= kTileMixK components: the chain wave evaluates the K components of the
 // step's SNP as wave-uniform scalars (every lane the same numbers -- no cross-lane reduction; the K exponentials and the
 // K divides are independent of each other and overlap), lane l keeps the K inputs / outputs of SNP l of the panel.
+// KMAX = kTileMixWideK: 3 x 10 + 3 doubles of inputs per lane -- a second set in flight for the next panel would not fit the
+// registers next to the K outputs and the step's K exponentials, so the chain wave loads its inputs when the panel starts
+// (one exposed round trip per 64 steps of ~1 us each).
+template <int KMAX>
 struct TileMixture {
     static constexpr bool kSkip = false;
     static constexpr bool kMixture = true;
+    static constexpr int kSlots = KMAX;
 };
 
 template <typename U, int N> struct alignas(sizeof(U) * N) UVec { U v[N]; };
@@ -241,7 +250,8 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                 if (jj < kPanel) tile[jj * kPanel + lane] = t[k];
             }
         };
-        constexpr int KM = MODEL::kMixture ? kTileMixK : 1;    // per-SNP input slots (mixture: one per component)
+        constexpr int KM = MODEL::kSlots;                      // per-SNP input slots (mixture: one per component)
+        constexpr bool kPrefetchInputs = KM <= kTileMixK;
         const int K = MODEL::kMixture ? A.width : 1;
         T in_mm[KM], in_sh[KM], in_ul[KM], in_sb = 0, in_eta = 0, in_lnp = 0;
 #pragma unroll
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
         load_tile(t_d, w_cur, 0, 0);
 #pragma unroll
         for (int k = 0; k < kRowsPerWave; ++k) t_o[k] = (U)0;
-        load_inputs(0);
+        if (kPrefetchInputs) load_inputs(0);
         T prev_a = 0;                                          // wave 0, lane jj: a_jj of the panel before (0: skipped)
 
         for (int p0 = 0; p0 < n; p0 += kPanel) {
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
             }
             store_tile(t_d, tile_d);
             if (p0 > 0) store_tile(t_o, tile_o);
+            if (!kPrefetchInputs) load_inputs(p0);
             T c_mm[KM], c_sh[KM], c_ul[KM];
 #pragma unroll
             for (int k = 0; k < KM; ++k) { c_mm[k] = in_mm[k]; c_sh[k] = in_sh[k]; c_ul[k] = in_ul[k]; }
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
             const TileWindow w_nn = load_window(p0 + 2 * kPanel);
             load_tile(t_d, w_nxt, p0 + kPanel, p0 + kPanel);
             load_tile(t_o, w_cur, p0, p0 + kPanel);
-            load_inputs(p0 + kPanel);
+            if (kPrefetchInputs) load_inputs(p0 + kPanel);
             TPROF(3);
 
             if (wave == 0) {

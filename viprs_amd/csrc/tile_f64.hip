@@ -18,8 +18,12 @@ static int launch_tile_class(viprs_plan* P, EStepArgs<double> A, int model, bool
     const void* kfn = nullptr;
     if (model == kGenGrid) kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileGridColumn, true, NW>
                                        : (const void*)estep_tile_f64_kernel<U, TileGridColumn, false, NW>;
-    else if (model == kGenMixture) kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileMixture, true, NW>
-                                               : (const void*)estep_tile_f64_kernel<U, TileMixture, false, NW>;
+    else if (model == kGenMixture && A.width <= kTileMixK)
+        kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileMixture<kTileMixK>, true, NW>
+                    : (const void*)estep_tile_f64_kernel<U, TileMixture<kTileMixK>, false, NW>;
+    else if (model == kGenMixture)
+        kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileMixture<kTileMixWideK>, true, NW>
+                    : (const void*)estep_tile_f64_kernel<U, TileMixture<kTileMixWideK>, false, NW>;
     else kfn = dense ? (const void*)estep_tile_f64_kernel<U, TileSpikeSlab, true, NW>
                      : (const void*)estep_tile_f64_kernel<U, TileSpikeSlab, false, NW>;
     if (shmem > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -44,8 +48,8 @@ int launch_tile_f64(viprs_plan* P, EStepArgs<double> A, int model, bool dense) {
     const std::vector<BlockDesc>& list = dense ? P->dense_h : P->ragged_h;
     if (list.empty()) return VIPRS_OK;
     const int max_b = dense ? P->max_dense : P->max_ragged;
-    // q of a block lives in LDS; blocks beyond that (and mixtures of more than kTileMixK components) keep the row-by-row kernels
-    if (tile_lds_bytes((max_b + 3) / 4 * 4, sizeof(U)) > 150 * 1024 || (model == kGenMixture && A.width > kTileMixK))
+    // q of a block lives in LDS; blocks beyond that (and mixtures of more than kTileMixWideK components) keep the row-by-row kernels
+    if (tile_lds_bytes((max_b + 3) / 4 * 4, sizeof(U)) > 150 * 1024 || (model == kGenMixture && A.width > kTileMixWideK))
         return launch_generic<double, U>(P, A, model, dense);
     const BlockDesc* d_blocks = dense ? P->d_dense.p : P->d_ragged.p;
     // the lists are in descending order of size: the big class is a prefix
