@@ -143,11 +143,12 @@ print("RANK_DONE", os.environ["RANK"])
 """
 
 
-@pytest.mark.parametrize("extra", [[], ["--scaling", "weak"]], ids=["strong", "weak"])
+@pytest.mark.parametrize("extra", [["--scaling", "strong"], []], ids=["strong", "weak"])
 def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra):
     """bench.py's N > 1 path run for real with two processes (torch.distributed.run-style environment,
     VIPRS_BENCH_COMM=file, device layer stubbed): ONE JSON line from rank 0 whose `n_gpus`, `comm`, `snps_total`,
-    `scaling` and per-rank vectors describe a strong-scaling run of ONE sharded workload."""
+    `scaling` and per-rank vectors describe the default run (weak: one workload per rank, the strong figure beside it)
+    or, with --scaling strong, a run of ONE sharded workload (the weak figure beside it)."""
     import json
     import os
     import subprocess
@@ -166,13 +167,18 @@ def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra
     assert len(lines) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]   # rank 0 only, one line
     out = json.loads(lines[0])
     sizes = bench.config_sizes("cfg2", 7209)
-    weak = "weak" in extra
+    weak = "strong" not in extra
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
     assert out["scaling"] == ("weak" if weak else "strong")
     assert "file transport" in out["config"]["comm"]
     pr = out["per_rank"]
     if weak:
         assert out["config"]["snps_total"] == 2 * int(sizes.sum()) and pr["snps"] == [int(sizes.sum())] * 2
+        assert "weak_scaling" not in out
+        st = out["strong_scaling"]
+        assert st["snps_total"] == int(sizes.sum()) and len(st["kernel_ms_avg_per_rank"]) == 2
+        assert max(st["largest_block_per_rank"]) == int(sizes.max())
+        assert st["value"] == pytest.approx(st["snps_total"] / (st["ms_per_step"] * 1e-3), rel=1e-6)
     else:
         # ONE workload: the shards partition its blocks, `value` counts its SNPs once
         assert out["config"]["snps_total"] == int(sizes.sum()) == sum(pr["snps"])
@@ -250,7 +256,9 @@ def test_bare_bench_gpus_2_starts_two_ranks_itself(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["rccl_ranks"] is None
     assert "file transport" in out["config"]["comm"]
     pr = out["per_rank"]
-    assert len(pr["snps"]) == 2 and min(pr["snps"]) > 0 and sum(pr["snps"]) == int(sizes.sum())
+    # the default series over N is weak: every rank its own workload; the sharded (strong) figure sits beside it
+    assert out["scaling"] == "weak" and pr["snps"] == [int(sizes.sum())] * 2
+    assert out["strong_scaling"]["snps_total"] == int(sizes.sum())
     assert pr["kernel_ms_avg"] == pytest.approx([0.5, 0.51])                 # each rank reported under its own RANK
     assert out["roofline"]["peak"] == 2 * bench.HBM_PEAK_GBS
 
