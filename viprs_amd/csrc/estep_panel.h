@@ -1153,7 +1153,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                 PPROF(5, wave == 1);
                 if (p > 0) {
                     for (int k = uw; k < n_mine; k += NW - 1) do_strip(k);
+#ifdef PANEL_TIMING_NO_SECOND_PASS           // (traffic experiments only: wrong results)
+                    if (false) {
+#else
                     if (!SYM) {
+#endif
                         // second pass, column panel pp: tiles R[r, pp], r = 0 .. pp, of the row panels this member owns
                         // (the owner of a strip owns the q -- and the sums -- of its rows), dealt to its updater waves
                         const float edv = led[(pp & 1) * kPanel + lane];
