@@ -1,5 +1,5 @@
 """A/B/C... of several builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
-    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix] [uniform] [fast]
+    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix [K=n]] [uniform] [fast]
 (each library runs in its own subprocess, 3 rounds)"""
 import os, subprocess, sys
 sep = sys.argv.index('--') if '--' in sys.argv else len(sys.argv)
@@ -15,6 +15,8 @@ sizes = np.full(1700, 650) if "uniform" in sys.argv else None      # uniform: 17
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt, sizes=sizes)
 model = "grid" if "grid" in sys.argv else "mixture" if "mix" in sys.argv else "spike_slab"
 width = {"grid": 32, "mixture": 4, "spike_slab": 1}[model]
+for a in sys.argv:
+    if a.startswith("K="): width = int(a[2:])          # mix K=8: another number of components
 plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper, math_mode="fast" if "fast" in sys.argv else "exact"); ds = DeviceState(plan, "float32", model, width)
 ds.upload("std_beta", inp.std_beta)
 active, pi0 = None, inp.pi

@@ -902,8 +902,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         const int kc = min(lane, K - 1);                   // lanes >= K: harmless copies
                         float cmm = Lmm[kc], csv = Lsv[kc], cul = Lul[kc];
                         float dvec = 0.0f, avec = 0.0f;                    // lane j: eta_diff / dq * eta_diff of SNP j
-                        auto run_panel = [&](auto rounds_c) {
+                        auto run_panel = [&](auto rounds_c, auto k4_c) {
                         constexpr int ROUNDS = decltype(rounds_c)::value;
+                        // The two ordered sums of the step run as SCALAR chains over v_readlane values (ROUNDS + 1 and ROUNDS
+                        // terms; the terms beyond K are exactly neutral: e = +0, gamma = 0) instead of lane-to-lane DPP
+                        // rounds -- a DPP operand needs two wait states behind the VALU write it reads, every round.
+                        // K == 4 exactly (BASELINE configs[3]): no masking of the terms either.
+                        constexpr bool K4 = decltype(k4_c)::value;
                         // Rolled in 4 groups of kChainPrefetch = 16 steps (the fully unrolled mixture chain does
                         // not fit the instruction cache): the row consumed at step 16 g + k was loaded 16 steps
                         // earlier into the same register win[k]; the last group loads the first rows of the NEXT
@@ -939,29 +944,30 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             float u = __builtin_fmaf(t, t, cul);                               // :511
                             u = (lane == K) ? lnp : u;
                             // max over lanes 0..K (order-free): inclusive prefix max along the row, read at lane K
-                            float mx = dpp_max_shr<1>(u);
-                            mx = dpp_max_shr<2>(mx);
-                            mx = dpp_max_shr<4>(mx);
-                            mx = dpp_max_shr<8>(mx);
-                            mx = rl(mx, K);                                                    // c_max, :58-71
+                            float mx;
+                            if constexpr (K4) {
+                                mx = rl(u, 0);
+#pragma unroll
+                                for (int i = 1; i <= 4; ++i) mx = fmaxf(mx, rl(u, i));
+                            } else {
+                                mx = dpp_max_shr<1>(u);
+                                mx = dpp_max_shr<2>(mx);
+                                mx = dpp_max_shr<4>(mx);
+                                mx = dpp_max_shr<8>(mx);
+                                mx = rl(mx, K);
+                            }                                                                  // c_max, :58-71
                             const float e = softmax_exp<MODEL::kExact, kLookupPerLane>(u - mx, tab);
                             // softmax denominator, :231-240: s = ((e_0 + e_1) + ...) + e_null in this order.
-                            // Lane k adds its e to lane k-1's running sum; after k rounds lane k is final
-                            // and stays so: ROUNDS >= K rounds, no K-dependent branch inside the step.
-                            float ssum = e;
+                            const float e_t = (K4 || lane <= K) ? e : 0.0f;
+                            float ssum = rl(e_t, 0);
 #pragma unroll
-                            for (int it = 0; it < ROUNDS; ++it) ssum = e + dpp_shr<1>(ssum, 0.0f);
-                            ssum = rl(ssum, K);
+                            for (int i = 1; i <= ROUNDS; ++i) ssum += rl(e_t, i);
                             const float gam = softmax_div<MODEL::kExact>(e, ssum);             // :239
-                            // eta_diff, :519-523: d_k = fma(gam_k, mu_k, d_{k-1}), d_{-1} = -eta_old, same scheme
-                            // (lane 0 of `dprev` is never written by the shift and keeps -eta_old)
-                            float d = -eta_old, dprev = -eta_old;
+                            // eta_diff, :519-523: d_k = fma(gam_k, mu_k, d_{k-1}), d_{-1} = -eta_old
+                            const float gam_t = (K4 || lane < K) ? gam : 0.0f;
+                            float d = -eta_old;
 #pragma unroll
-                            for (int it = 0; it < ROUNDS; ++it) {
-                                asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dprev) : "v"(d));
-                                d = __builtin_fmaf(gam, mu, dprev);
-                            }
-                            d = rl(d, K - 1);
+                            for (int i = 0; i < ROUNDS; ++i) d = __builtin_fmaf(rl(gam_t, i), rl(mu, i), d);
                             const bool livej = jj < nrows;                                     // wave-uniform
                             const float a = livej ? dq * d : 0.0f;
                             if (lane < K) {
@@ -983,8 +989,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[kMixLds ? 0 : k];
                         }
                         };
-                        if (K <= 4) run_panel(std::integral_constant<int, 4>{});
-                        else run_panel(std::integral_constant<int, kPanelMaxK>{});
+                        if (K == 4) run_panel(std::integral_constant<int, 4>{}, std::true_type{});
+                        else if (K < 4) run_panel(std::integral_constant<int, 4>{}, std::false_type{});
+                        else run_panel(std::integral_constant<int, kPanelMaxK>{}, std::false_type{});
                         __builtin_amdgcn_wave_barrier();
                         if (member == 0) {
                             // (m, K) C-order: the panel's var_mu / var_gamma are nrows * K contiguous floats
