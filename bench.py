@@ -347,7 +347,7 @@ def pct(v, q):
 STREAM_GBS = 6300.0                                 # what a float4 copy reaches on MI355X (MI355X_MICROARCH.md)
 CHAIN_NS = {                                        # ns per serial SNP step of ONE chain, per-phase work included
     ("spike_slab", "exact"): 135.0, ("spike_slab", "fast"): 95.0,
-    ("mixture", "exact"): 290.0, ("mixture", "fast"): 230.0,          # K = 4 (lane-parallel softmax chain; tools/chain_ns_models.py)
+    ("mixture", "exact"): 275.0, ("mixture", "fast"): 220.0,          # K = 4 (lane-parallel softmax chain; tools/chain_ns_models.py)
     ("grid", "exact"): 430.0, ("grid", "fast"): 420.0,                # 32 models per step
     ("spike_slab_f64", "exact"): 300.0,                                # estep_tile.h: 237 ns + 4 us per panel
 }

@@ -115,6 +115,16 @@ template <int N> __device__ __forceinline__ float dpp_shr(float v, float fill) {
 
 // max(x[lane - N], x[lane]) within a row of 16 lanes, lanes without a source keep x (no NaN canonicalisation:
 // the operands are finite); the two wait states a DPP read of a fresh VALU result needs are in the asm
+// Keeps N wave-uniform values (v_readlane results) in SGPRs at this point of the program: the reads are issued together and
+// the scalar chain that consumes them follows without the two wait states a VALU read of a just-written SGPR costs per term.
+template <int N> __device__ __forceinline__ void pin_sgprs(int (&v)[N]) {
+    static_assert(N == 4 || N == 5 || N == 8 || N == 9, "chain lengths of the K <= 8 mixture step");
+    if constexpr (N == 4) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]));
+    if constexpr (N == 5) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]));
+    if constexpr (N == 8) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]));
+    if constexpr (N == 9) asm volatile("" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]), "+s"(v[4]), "+s"(v[5]), "+s"(v[6]), "+s"(v[7]),
+                                       "+s"(v[8]));
+}
 template <int N> __device__ __forceinline__ float dpp_max_shr(float x) {
     float r;
     if (N == 1) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "0"(x));
@@ -846,14 +856,35 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             float e = expf_glibc_nonpos<kLookupPerLane>(u - mx, tab);
                             e = (lane <= K) ? e : 0.0f;                                        // neutral terms beyond the null component
                             // softmax denominator, :231-240: s = ((e_0 + e_1) + ...) + e_null, a scalar chain
-                            float ssum = rl(e, 0);
+                            // (8 reads at a time, pinned in SGPRs before the 8 additions that consume them: pin_sgprs)
+                            static_assert((KMAX + 1) % 8 == 0, "chunks of 8 terms");
+                            float ssum = 0.0f;
 #pragma unroll
-                            for (int i = 1; i <= KMAX; ++i) ssum += rl(e, i);
+                            for (int c = 0; c < (KMAX + 1) / 8; ++c) {
+                                int et[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) et[i] = __builtin_amdgcn_readlane(__float_as_int(e), 8 * c + i);
+                                pin_sgprs(et);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) ssum = (c == 0 && i == 0) ? __int_as_float(et[0]) : ssum + __int_as_float(et[i]);
+                            }
                             const float gam = comp ? e / ssum : 0.0f;                          // :239
-                            // eta_diff, :519-523: d = fma(gam_k, mu_k, d) for k = 0 .. K-1 (gam = 0 beyond: exact no-ops)
+                            // eta_diff, :519-523: d = fma(gam_k, mu_k, d) for k = 0 .. K-1 (gam = 0 beyond: exact no-ops; one more
+                            // such term, lane KMAX, fills the last chunk)
                             float d = -eta_old;
 #pragma unroll
-                            for (int i = 0; i < KMAX; ++i) d = __builtin_fmaf(rl(gam, i), rl(mu, i), d);
+                            for (int c = 0; c < (KMAX + 1) / 8; ++c) {
+                                int gt[8];
+                                float mb[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    gt[i] = __builtin_amdgcn_readlane(__float_as_int(gam), 8 * c + i);
+                                    mb[i] = rl(mu, 8 * c + i);
+                                }
+                                pin_sgprs(gt);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) d = __builtin_fmaf(__int_as_float(gt[i]), mb[i], d);
+                            }
                             const bool livej = jj < nrows;                                     // wave-uniform
                             const float a = livej ? dq * d : 0.0f;
                             if (comp && livej && member == 0) {
@@ -943,12 +974,20 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             const float t = csv * mu;
                             float u = __builtin_fmaf(t, t, cul);                               // :511
                             u = (lane == K) ? lnp : u;
+                            // mu_k in every lane (operands of the eta chain at the end of the step: read here, long before)
+                            float mub[ROUNDS];
+#pragma unroll
+                            for (int i = 0; i < ROUNDS; ++i) mub[i] = rl(mu, i);
                             // max over lanes 0..K (order-free): inclusive prefix max along the row, read at lane K
                             float mx;
                             if constexpr (K4) {
-                                mx = rl(u, 0);
+                                int ut[5];
 #pragma unroll
-                                for (int i = 1; i <= 4; ++i) mx = fmaxf(mx, rl(u, i));
+                                for (int i = 0; i < 5; ++i) ut[i] = __builtin_amdgcn_readlane(__float_as_int(u), i);
+                                pin_sgprs(ut);
+                                mx = __int_as_float(ut[0]);
+#pragma unroll
+                                for (int i = 1; i <= 4; ++i) mx = fmaxf(mx, __int_as_float(ut[i]));
                             } else {
                                 mx = dpp_max_shr<1>(u);
                                 mx = dpp_max_shr<2>(mx);
@@ -959,15 +998,25 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             const float e = softmax_exp<MODEL::kExact, kLookupPerLane>(u - mx, tab);
                             // softmax denominator, :231-240: s = ((e_0 + e_1) + ...) + e_null in this order.
                             const float e_t = (K4 || lane <= K) ? e : 0.0f;
-                            float ssum = rl(e_t, 0);
+                            // (all reads first, pinned by an empty asm: read-add-read-add costs two wait states per term
+                            //  between the v_readlane that writes the SGPR and the add that reads it)
+                            int et[ROUNDS + 1];
 #pragma unroll
-                            for (int i = 1; i <= ROUNDS; ++i) ssum += rl(e_t, i);
+                            for (int i = 0; i <= ROUNDS; ++i) et[i] = __builtin_amdgcn_readlane(__float_as_int(e_t), i);
+                            pin_sgprs(et);
+                            float ssum = __int_as_float(et[0]);
+#pragma unroll
+                            for (int i = 1; i <= ROUNDS; ++i) ssum += __int_as_float(et[i]);
                             const float gam = softmax_div<MODEL::kExact>(e, ssum);             // :239
                             // eta_diff, :519-523: d_k = fma(gam_k, mu_k, d_{k-1}), d_{-1} = -eta_old
                             const float gam_t = (K4 || lane < K) ? gam : 0.0f;
+                            int gt[ROUNDS];
+#pragma unroll
+                            for (int i = 0; i < ROUNDS; ++i) gt[i] = __builtin_amdgcn_readlane(__float_as_int(gam_t), i);
+                            pin_sgprs(gt);
                             float d = -eta_old;
 #pragma unroll
-                            for (int i = 0; i < ROUNDS; ++i) d = __builtin_fmaf(rl(gam_t, i), rl(mu, i), d);
+                            for (int i = 0; i < ROUNDS; ++i) d = __builtin_fmaf(__int_as_float(gt[i]), mub[i], d);
                             const bool livej = jj < nrows;                                     // wave-uniform
                             const float a = livej ? dq * d : 0.0f;
                             if (lane < K) {
