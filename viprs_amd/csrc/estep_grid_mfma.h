@@ -304,8 +304,9 @@ __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, floa
             const float gamma = EXACT ? sigmoid_exact<kLookupPerLane>(u, tab) : sigmoid_fast(u);   // :617
             const float d = gamma * mu - eta_old;                        // :620
             const float a = (live && has_model) ? dq * d : 0.0f;
-            // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order)
-            __builtin_amdgcn_sched_barrier(0);
+            // the next diagonal row goes out behind the sigmoid's table lookup (LDS is in-order).  (A scheduling barrier
+            // stood here; without it the compiler still keeps the row's reads behind the lookup and places a few of the
+            // fmas below into the sigmoid's shadows: configs[4] 1.986 -> 1.951 ms, tools/multi_ab.py.)
             f32x2 rn[16];
             load_row(rn, jn, (jj + 1) >> 4);
             const f32x2 a2 = {a, a};
