@@ -787,8 +787,25 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             float trow[kPanel];
 #pragma unroll
                             for (int k = 0; k < kPanel; ++k) trow[k] = lTo[k * kPanel + lane];
+                            if constexpr (sizeof(U) < 4) {
+                                // Integer LD (a chain-bound sweep): the 64 a-values as 16 broadcast LDS reads (la holds them for
+                                // the updaters) instead of 64 v_readlane, each followed by two wait states before the fma that
+                                // reads its SGPR: int8 upper 0.510 -> 0.500 ms, int8 symmetric 0.527 -> 0.518 (fp32 LD, a
+                                // bandwidth-bound sweep, measured slower with it and keeps the v_readlane form).
+                                const float4* __restrict__ av4 = reinterpret_cast<const float4*>(la + ((p - 1) & 1) * kPanel);
+                                float4 av[kPanel / 4];
 #pragma unroll
-                            for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(trow[k], rl(a_prev, k), qc);
+                                for (int i = 0; i < kPanel / 4; ++i) av[i] = av4[i];
+#pragma unroll
+                                for (int k = 0; k < kPanel; ++k) {
+                                    const float4 t = av[k >> 2];
+                                    const float ak = (k & 3) == 0 ? t.x : (k & 3) == 1 ? t.y : (k & 3) == 2 ? t.z : t.w;
+                                    qc = __builtin_fmaf(trow[k], ak, qc);
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(trow[k], rl(a_prev, k), qc);
+                            }
                         } else {
                             // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
                             const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
