@@ -787,8 +787,8 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             float trow[kPanel];
 #pragma unroll
                             for (int k = 0; k < kPanel; ++k) trow[k] = lTo[k * kPanel + lane];
-                            if constexpr (sizeof(U) < 4) {
-                                // Integer LD (a chain-bound sweep): the 64 a-values as 16 broadcast LDS reads (la holds them for
+                            if constexpr (sizeof(U) < 4 || MODEL::kLaneParallel) {
+                                // Integer LD and the K <= 8 mixture of the symmetric form (chain-bound sweeps; configs[3] 1.065 -> 1.054 ms): the 64 a-values as 16 broadcast LDS reads (la holds them for
                                 // the updaters) instead of 64 v_readlane, each followed by two wait states before the fma that
                                 // reads its SGPR: int8 upper 0.510 -> 0.500 ms, int8 symmetric 0.527 -> 0.518 (fp32 LD, a
                                 // bandwidth-bound sweep, measured slower with it and keeps the v_readlane form).
