@@ -570,11 +570,18 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     // carry the second pass and are the busier side: one more tile to stage per phase, and a go-ahead to wait for, cost them
     // more than the chain wins.  With int8 LD (a quarter of the bytes, a chain-bound sweep) it is the other way round
     // (panel_upper_tile_in_lds, kernels_common.h).
-    // The K <= 8 mixture chain (components of one SNP across the lanes) follows the same scheme in the symmetric form:
+    // The K <= 8 mixture chain (components of one SNP across the lanes) follows the same scheme, in both LD forms:
     // diagonal tiles staged in LDS, the off-diagonal tile of the next phase in the single gated buffer -- its chain wave
     // issues no vector-memory instruction inside a panel either (it used to stream the diagonal rows from global memory,
     // 16 rows ahead).
+    // (round 4: in the upper-triangular form too -- its chain used to stream the diagonal rows from global memory through a
+    //  16-row register window: cfg3 K = 4 1.217 -> 1.099 ms, int8 LD 1.100 -> 0.997, K = 8 1.425 -> 1.30; -DPANEL_MIX_UPPER_REGS:
+    //  the old form)
+#ifdef PANEL_MIX_UPPER_REGS
     constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value && SYM;
+#else
+    constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value;
+#endif
     constexpr bool kStageDiag = kDiagInLds || kMixLds;          // what the updaters stage into lT: diagonal tiles
     constexpr bool kTileInLds = (kDiagInLds && (SYM || panel_upper_tile_in_lds<U>())) || kMixLds;
     float* lq = smem;
