@@ -577,10 +577,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     // (round 4: in the upper-triangular form too -- its chain used to stream the diagonal rows from global memory through a
     //  16-row register window: cfg3 K = 4 1.217 -> 1.099 ms, int8 LD 1.100 -> 0.997, K = 8 1.425 -> 1.30; -DPANEL_MIX_UPPER_REGS:
     //  the old form)
+    // ... and the wide mixtures (K = 9 .. 31): K = 10 / 20 1.98 / 2.76 -> 1.86 / 2.61 ms, upper form 2.00 / 2.86 -> 1.82 / 2.55.
 #ifdef PANEL_MIX_UPPER_REGS
     constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value && SYM;
 #else
-    constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value;
+    constexpr bool kMixLds = MODEL::kLaneParallel;
 #endif
     constexpr bool kStageDiag = kDiagInLds || kMixLds;          // what the updaters stage into lT: diagonal tiles
     constexpr bool kTileInLds = (kDiagInLds && (SYM || panel_upper_tile_in_lds<U>())) || kMixLds;
@@ -840,9 +841,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         };
                         static_assert(kChainPrefetch == 16 && kPanel == 64, "window indexing");
                         float win[kChainPrefetch], rmm[kChainPrefetch], rsv[kChainPrefetch], rul[kChainPrefetch];
+                        const float* __restrict__ DtW = lT + (p & 1) * kPanel * kPanel + lane;    // kMixLds: the panel's diagonal tile in LDS
 #pragma unroll
                         for (int k = 0; k < kChainPrefetch; ++k) {
-                            win[k] = drow[k];
+                            win[k] = kMixLds ? 0.0f : drow[kMixLds ? 0 : k];
                             rmm[k] = *cptr(A.mu_mult, k);
                             rsv[k] = *cptr(A.shvt, k);
                             rul[k] = *cptr(A.u_logs, k);
@@ -852,13 +854,15 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #pragma unroll
                         for (int k = 0; k < kChainPrefetch; ++k) {
                             const int jj = kChainPrefetch * g + k;                             // wave-uniform
-                            const float drow_jj = win[k];
+                            const float drow_jj = kMixLds ? DtW[jj * kPanel] : win[k];
                             const float cmm = rmm[k], csv = rsv[k], cul = rul[k];
                             {
-                                const U* __restrict__ src = (g < kPanel / kChainPrefetch - 1)
-                                    ? dptr + (int64_t)min(jj + kChainPrefetch, last) * stride
-                                    : nptr + (int64_t)min(k, b - 1 - rn0) * stride;
-                                win[k] = static_cast<float>(*src);
+                                if (!kMixLds) {
+                                    const U* __restrict__ src = (g < kPanel / kChainPrefetch - 1)
+                                        ? dptr + (int64_t)min(jj + kChainPrefetch, last) * stride
+                                        : nptr + (int64_t)min(k, b - 1 - rn0) * stride;
+                                    win[k] = static_cast<float>(*src);
+                                }
                                 // (the ring runs on into the next panel; past the block it re-reads the last SNP)
                                 rmm[k] = *cptr(A.mu_mult, jj + kChainPrefetch);
                                 rsv[k] = *cptr(A.shvt, jj + kChainPrefetch);
@@ -925,8 +929,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             if (SYM) qc = (me && livej) ? qc - d : qc;                         // :527
                         }
                         }
+                        if (!kMixLds) {
 #pragma unroll
-                        for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[k];
+                            for (int k = 0; k < kChainPrefetch; ++k) dnext[k] = win[k];
+                        }
                         if (member == 0 && live) {
                             A.eta_diff[j] = dvec;
                             if (TEAM) stage_store(A.eta_out + j, in.eta_old + dvec); else A.eta[j] = in.eta_old + dvec;   // :536
