@@ -561,7 +561,8 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     //     chain reads its row with one ds_read per step and touches no LD memory on its critical path -- the
     //     off-diagonal tile R[p, p+1] of its next phase it prefetches into registers, one row per step, a whole
     //     phase ahead of its use);
-    //   mixture (rolled chain loop): the off-diagonal tiles R[p-1, p] / R[p, p+1], diagonal rows from global memory.
+    //   mixtures (rolled chain loop): the same since round 4 (before: the off-diagonal tiles R[p-1, p] / R[p, p+1] here and the
+    //     diagonal rows streamed from global memory by the chain wave; -DPANEL_MIX_UPPER_REGS keeps that for the upper form).
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     // The off-diagonal tile of the chain's next phase goes through LDS too (below) in the SYMMETRIC form.  The upper-
     // triangular form keeps the chain's own register prefetch for fp32 / int16 LD: measured with nothing else changed
