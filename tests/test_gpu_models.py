@@ -24,7 +24,8 @@ def _run_mix(mod, ld, inp, mix, st0, sweeps, **kw):
 
 
 @pytest.mark.parametrize("low_memory", [False, True])
-# K <= 8: panel kernels, DPP scans; 9..31: panel kernels, scalar chains over the lanes (10 = the reference's own test,
+# K <= 8: panel kernels, components across the lanes (ordered sums as scalar chains; the max by DPP unless K == 4); 9..31: the same with
+# the component inputs streamed from global memory (10 = the reference's own test,
 # 20 = its benchmark; 15 / 16 / 31: the edges of the two instantiations); 33: generic kernel
 @pytest.mark.parametrize("K", [1, 4, 8, 9, 10, 15, 16, 20, 31, 33])
 def test_mixture_matches_oracle(gpu, K, low_memory):
