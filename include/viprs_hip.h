@@ -73,6 +73,10 @@ typedef struct viprs_state viprs_state;   /* device-resident variational state b
 /* ---- library / device ------------------------------------------------------------------- */
 const char* viprs_last_error(void);
 const char* viprs_version(void);
+/* Experiment / instrumentation switches (-DPANEL_TIMING_*, -DVIPRS_*_PROFILE, ...: kernels_common.h) the translation
+ * units of this library were compiled with, space separated.  The shipped library returns "": some of those switches
+ * change results, a build that carries any is not the product (they do not compile without -DVIPRS_EXPERIMENTAL). */
+const char* viprs_build_flags(void);
 int viprs_device_count(int* count);
 /* Mirrors check_blas_support() / check_omp_support() (e_step_cpp.pyx:71-76): neither BLAS
  * nor OpenMP is involved on the device path, both report 0.                                   */

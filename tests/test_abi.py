@@ -85,3 +85,60 @@ def test_shim_rejects_mismatched_shapes_before_touching_the_device():
 def test_plan_cache_is_bounded_by_bytes_and_can_be_invalidated():
     from viprs_amd.vi import e_step_hip as S
     assert S._PLAN_CACHE_BYTES >= 1 << 30 and callable(S.invalidate) and callable(S.set_plan_cache_budget)
+
+
+def test_shipped_library_carries_no_experiment_switch():
+    """kernels_common.h: timing / profiling switches (some produce wrong results) are recorded per translation unit;
+    the library the tests load -- the one that ships -- must report none."""
+    assert L.build_flags() == "", f"libviprs_hip.so was built with experiment switches: {L.build_flags()!r}"
+
+
+def test_experiment_switch_without_the_gate_does_not_compile():
+    """-DPANEL_TIMING_NO_SECOND_PASS (wrong results) without -DVIPRS_EXPERIMENTAL must be a compile error; every
+    `#ifdef` knob of the kernel headers must be on the guarded list."""
+    import shutil
+    import subprocess
+    import pytest
+    csrc = os.path.join(ROOT, "viprs_amd", "csrc")
+    common = open(os.path.join(csrc, "kernels_common.h")).read()
+    knobs = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith((".h", ".inc", ".hip", ".cpp")):
+            for mm in re.finditer(r"^\s*#\s*(?:ifdef|ifndef|if\s+defined\(?|elif\s+defined\(?)\s*([A-Z][A-Z0-9_]+)",
+                                  open(os.path.join(csrc, fn)).read(), flags=re.M):
+                knobs.add(mm.group(1))
+    knobs -= {"VIPRS_EXPERIMENTAL", "VIPRS_HIP_H"}
+    knobs = {k for k in knobs if not k.startswith("VIPRS_BF_")}
+    assert knobs, "no knobs found: the scan is broken"
+    for k in sorted(knobs):
+        assert f"defined({k})" in common, f"{k} is an #ifdef switch of the kernels but not on kernels_common.h's guarded list"
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    cmd = [hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-x", "hip", "-DPANEL_TIMING_NO_SECOND_PASS",
+           os.path.join(csrc, "kernels_common.h")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and "VIPRS_EXPERIMENTAL" in r.stderr
+    r = subprocess.run(cmd + ["-DVIPRS_EXPERIMENTAL"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+
+
+def test_plan_cache_fingerprint_sees_in_place_edits():
+    """The drop-in entry points keep LD resident by buffer identity; the per-call content fingerprint must change when the
+    caller edits the arrays in place (small arrays: every byte; large ones: both ends + 256 sampled windows + length)."""
+    import numpy as np
+    from viprs_amd.vi import e_step_hip as S
+    small = np.arange(1000, dtype=np.float32)
+    f0 = S._fingerprint(small)
+    small[517] += 1
+    assert S._fingerprint(small) != f0
+    big = np.zeros(1 << 22, dtype=np.int8)
+    f0 = S._fingerprint(big)
+    for pos in (0, 4095, big.size - 1, big.size - 4096, ((big.size - 64) // S._FP_SAMPLES) * 100 + 5):
+        big[pos] = 1
+        assert S._fingerprint(big) != f0, pos
+        big[pos] = 0
+    assert S._fingerprint(big) == f0
+    assert S._fingerprint(big[:-1]) != f0                      # the length is part of it
+    lb = np.zeros(4, np.int32)
+    assert S._fingerprint(lb, small) != S._fingerprint(small, lb)

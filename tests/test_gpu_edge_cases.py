@@ -435,3 +435,26 @@ def test_dense_block_at_the_lds_limit(gpu, low_memory):
         ld, ss, inp = syn.make_problem(sizes=[size, 130], low_memory=low_memory, ld_dtype=np.int8, seed=19, kind="longrange")
         st0 = inp.state_copy()
         H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=1), H.run_oracle(ld, inp, st0, sweeps=1))
+
+
+def test_in_place_edit_of_ld_data_is_noticed_by_the_drop_in_call(gpu):
+    """e_step_cpp.pyx:91-122 reads the caller's memory on every call.  The drop-in keeps the LD resident on the device,
+    keyed by buffer identity: an in-place edit must not silently run on the stale device copy (content fingerprint,
+    viprs_amd/vi/e_step_hip.py::plan_for)."""
+    ld, ss, inp = syn.make_problem(sizes=[700, 90], seed=5, kind="longrange")
+    st0 = inp.state_copy()
+    H.assert_state_equal(H.run_hip(ld, inp, st0), H.run_oracle(ld, inp, st0))
+    off = ld.ld_data.copy()
+    d = off.reshape(-1)
+    mask = np.ones(d.shape[0], bool)
+    # halve every off-diagonal entry in place (same buffers, same identity)
+    for bi in range(len(ld.block_start) - 1):
+        s, e = int(ld.block_start[bi]), int(ld.block_start[bi + 1])
+        o, b = int(ld.ld_indptr[s]), e - s
+        mask[o:o + b * b:b + 1] = False
+    ld.ld_data[mask] *= np.float32(0.5)
+    ref = H.run_oracle(ld, inp, st0)
+    got = H.run_hip(ld, inp, st0)
+    H.assert_state_equal(got, ref)
+    ld.ld_data[...] = off
+    H.assert_state_equal(H.run_hip(ld, inp, st0), H.run_oracle(ld, inp, st0))

@@ -196,8 +196,9 @@ def test_two_rank_fit_reads_only_its_blocks_from_the_store(tmp_path):
 
 @pytest.mark.parametrize("keys", [("min", "max"), ("Min", "Max")])
 def test_lambda_min_from_the_stored_extremal_eigenvalues(tmp_path, keys):
-    """`VIPRS(lambda_min='infer')` calls get_lambda_min(min_max_ratio=1e-3) (VIPRS.py:191): the regulariser that
-    brings lambda_min / lambda_max up to the ratio, max((r lambda_max - lambda_min) / (1 + r), 0)."""
+    """`VIPRS(lambda_min='infer')` calls get_lambda_min(min_max_ratio=1e-3) (VIPRS.py:186-191).  The formula magenpy applies
+    to the stored extremal eigenvalues is unverified here, so with r > 0 the reader REFUSES by default and computes only
+    with an explicitly chosen candidate; r = 0 and stores without spectral attributes need no formula."""
     up = syn.make_ld([30, 20], low_memory=True, ld_dtype=np.int8, seed=3)
     for lam_min, lam_max in ((-0.25, 40.0), (0.5, 40.0), (0.01, 40.0)):
         path = str(tmp_path / f"s{lam_min}_{keys[0]}")
@@ -205,7 +206,13 @@ def test_lambda_min_from_the_stored_extremal_eigenvalues(tmp_path, keys):
                          attrs={"Chromosome": 1, "Spectral properties": {"Extremal": {keys[0]: lam_min, keys[1]: lam_max}}})
         m = Z.ZarrLDMatrix(path)
         assert m.get_lambda_min() == pytest.approx(max(-lam_min, 0.0))
-        assert m.get_lambda_min(min_max_ratio=1e-3) == pytest.approx(max((1e-3 * lam_max - lam_min) / 1.001, 0.0))
+        with pytest.raises(Z.UnpinnedLambdaMinError, match="check_store"):
+            m.get_lambda_min(min_max_ratio=1e-3)
+        assert isinstance(Z.UnpinnedLambdaMinError("x"), NotImplementedError)
+        assert m.get_lambda_min(min_max_ratio=1e-3, formula="one_plus_r") == \
+            pytest.approx(max((1e-3 * lam_max - lam_min) / 1.001, 0.0))
+        m.lambda_min_formula = "one_minus_r"
+        assert m.get_lambda_min(min_max_ratio=1e-3) == pytest.approx(max((1e-3 * lam_max - lam_min) / 0.999, 0.0))
 
 
 @pytest.mark.gpu
@@ -226,3 +233,29 @@ def test_fit_from_a_store_on_the_gpu(gpu, tmp_path, low_memory, expand):
     for c in a.chromosomes:
         np.testing.assert_array_equal(a.pip[c], b.pip[c])
         np.testing.assert_array_equal(a.post_mean_beta[c], b.post_mean_beta[c])
+
+
+def test_reader_matches_magenpy_fixture():
+    """Picks up fixtures written by tools/check_store.py on a machine that has magenpy and a real store (none exists
+    where this repository was written: the reader is 'parity unpinned' until one is committed).  Checks the two pieces
+    of arithmetic the reader shares with magenpy: load-time dequantisation and the lambda_min formula."""
+    import glob
+    import json
+    import os
+    fixtures = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "magenpy_store_*.npz")))
+    if not fixtures:
+        pytest.skip("no magenpy fixture (tools/check_store.py writes one)")
+    for fx in fixtures:
+        z = np.load(fx)
+        stored, as_f32 = z["stored_data"], z["float32_data"]
+        got = Z.ZarrLDMatrix._cast(None, stored, np.float32)
+        assert got.dtype == as_f32.dtype and np.array_equal(got, as_f32)
+        assert np.array_equal(z["stored_indptr"], z["float32_indptr"])
+        assert np.array_equal(z["stored_leftmost_idx"], np.arange(1, len(z["stored_leftmost_idx"]) + 1))
+        formula = str(z["lambda_min_formula"])
+        assert formula in ("one_plus_r", "one_minus_r"), "check_store.py found no matching formula"
+        m = Z.ZarrLDMatrix.__new__(Z.ZarrLDMatrix)
+        m.attrs, m.path = json.loads(str(z["attrs_json"])), fx
+        assert m.get_lambda_min() == float(z["lambda_min_r0"])
+        assert m.get_lambda_min(min_max_ratio=float(z["min_max_ratio"]), formula=formula) == pytest.approx(
+            float(z["lambda_min_r"]), rel=1e-12)

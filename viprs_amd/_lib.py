@@ -53,6 +53,7 @@ _pi32 = ctypes.POINTER(ctypes.c_int32)
 _PROTOS = {
     "viprs_last_error": (ctypes.c_char_p, []),
     "viprs_version": (ctypes.c_char_p, []),
+    "viprs_build_flags": (ctypes.c_char_p, []),
     "viprs_device_count": (_i, [ctypes.POINTER(_i)]),
     "viprs_check_blas_support": (_i, []),
     "viprs_check_omp_support": (_i, []),
@@ -132,6 +133,11 @@ def check(rc):
     if rc == EUNSUPPORTED:
         raise NotImplementedError(msg)
     raise ViprsHipError(msg)
+
+
+def build_flags():
+    """Experiment switches the loaded library was compiled with ('' for the shipped build; include/viprs_hip.h)."""
+    return (lib.viprs_build_flags() or b"").decode()
 
 
 def device_count():

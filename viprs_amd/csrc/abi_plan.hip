@@ -6,6 +6,7 @@ using namespace viprs;
 
 namespace {
 thread_local std::string g_err;
+viprs::BuildFlagsRegistrar tu_build_flags_(VIPRS_TU_BUILD_FLAGS);
 }
 
 namespace viprs {
@@ -16,6 +17,27 @@ int fail(int code, const std::string& msg) {
 SchedConfig& sched_config() {
     static SchedConfig c;
     return c;
+}
+// experiment switches the translation units of this library were compiled with (kernels_common.h); "" for a clean build
+static std::string& build_flags_registry() {
+    static std::string s;
+    return s;
+}
+void register_build_flags(const char* flags) {
+    // `flags` = " NAME NAME ...": keep the union
+    std::string& all = build_flags_registry();
+    const std::string f(flags ? flags : "");
+    size_t i = 0;
+    while (i < f.size()) {
+        while (i < f.size() && f[i] == ' ') ++i;
+        size_t j = i;
+        while (j < f.size() && f[j] != ' ') ++j;
+        if (j > i) {
+            const std::string name = f.substr(i, j - i);
+            if ((" " + all + " ").find(" " + name + " ") == std::string::npos) all += (all.empty() ? "" : " ") + name;
+        }
+        i = j;
+    }
 }
 }  // namespace viprs
 
@@ -371,6 +393,7 @@ extern "C" {
 
 const char* viprs_last_error(void) { return g_err.c_str(); }
 const char* viprs_version(void) { return "viprs_amd 0.1.0 (gfx950)"; }
+const char* viprs_build_flags(void) { return build_flags_registry().c_str(); }
 
 int viprs_device_count(int* count) {
     if (!count) return fail(VIPRS_EINVAL, "count is null");

@@ -3,6 +3,122 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Experiment / instrumentation switches (tools/build_variant.sh, EXPERIMENTS.md).  Some of them produce WRONG results
+// (timing experiments): none may reach a build by accident.  Every switch needs -DVIPRS_EXPERIMENTAL beside it, each
+// translation unit records what it was built with, and viprs_build_flags() (C ABI) returns the union -- the empty
+// string for the shipped library (tests/test_abi.py asserts that).
+#if (defined(PANEL_TIMING_NO_HANDOFF_WAIT) || \
+    defined(PANEL_TIMING_NO_SECOND_PASS) || \
+    defined(PANEL_NW) || \
+    defined(PANEL_MIX_UPPER_REGS) || \
+    defined(PANEL_UPPER_LDS_TILE) || \
+    defined(PANEL_STRIP_DEPTH) || \
+    defined(PANEL_MIN_WAVES) || \
+    defined(PANEL_TEAM_STRIP_DEPTH) || \
+    defined(PANEL_TEAM_CPL_F32) || \
+    defined(PANEL_CHAIN_PRIO) || \
+    defined(VIPRS_GRID_MFMA_CHAIN) || \
+    defined(GRID_EPI_BUFS) || \
+    defined(VIPRS_GRID_PROFILE) || \
+    defined(VIPRS_TILE_PROFILE) || \
+    defined(VIPRS_SWEEP_TRACE) || \
+    defined(VIPRS_PANEL_PROFILE)) && \
+    !defined(VIPRS_EXPERIMENTAL)
+#error "experiment switch defined without -DVIPRS_EXPERIMENTAL (see kernels_common.h)"
+#endif
+#ifdef VIPRS_EXPERIMENTAL
+#define VIPRS_BF_VIPRS_EXPERIMENTAL " VIPRS_EXPERIMENTAL"
+#else
+#define VIPRS_BF_VIPRS_EXPERIMENTAL ""
+#endif
+#ifdef PANEL_TIMING_NO_HANDOFF_WAIT
+#define VIPRS_BF_PANEL_TIMING_NO_HANDOFF_WAIT " PANEL_TIMING_NO_HANDOFF_WAIT"
+#else
+#define VIPRS_BF_PANEL_TIMING_NO_HANDOFF_WAIT ""
+#endif
+#ifdef PANEL_TIMING_NO_SECOND_PASS
+#define VIPRS_BF_PANEL_TIMING_NO_SECOND_PASS " PANEL_TIMING_NO_SECOND_PASS"
+#else
+#define VIPRS_BF_PANEL_TIMING_NO_SECOND_PASS ""
+#endif
+#ifdef PANEL_NW
+#define VIPRS_BF_PANEL_NW " PANEL_NW"
+#else
+#define VIPRS_BF_PANEL_NW ""
+#endif
+#ifdef PANEL_MIX_UPPER_REGS
+#define VIPRS_BF_PANEL_MIX_UPPER_REGS " PANEL_MIX_UPPER_REGS"
+#else
+#define VIPRS_BF_PANEL_MIX_UPPER_REGS ""
+#endif
+#ifdef PANEL_UPPER_LDS_TILE
+#define VIPRS_BF_PANEL_UPPER_LDS_TILE " PANEL_UPPER_LDS_TILE"
+#else
+#define VIPRS_BF_PANEL_UPPER_LDS_TILE ""
+#endif
+#ifdef PANEL_STRIP_DEPTH
+#define VIPRS_BF_PANEL_STRIP_DEPTH " PANEL_STRIP_DEPTH"
+#else
+#define VIPRS_BF_PANEL_STRIP_DEPTH ""
+#endif
+#ifdef PANEL_MIN_WAVES
+#define VIPRS_BF_PANEL_MIN_WAVES " PANEL_MIN_WAVES"
+#else
+#define VIPRS_BF_PANEL_MIN_WAVES ""
+#endif
+#ifdef PANEL_TEAM_STRIP_DEPTH
+#define VIPRS_BF_PANEL_TEAM_STRIP_DEPTH " PANEL_TEAM_STRIP_DEPTH"
+#else
+#define VIPRS_BF_PANEL_TEAM_STRIP_DEPTH ""
+#endif
+#ifdef PANEL_TEAM_CPL_F32
+#define VIPRS_BF_PANEL_TEAM_CPL_F32 " PANEL_TEAM_CPL_F32"
+#else
+#define VIPRS_BF_PANEL_TEAM_CPL_F32 ""
+#endif
+#ifdef PANEL_CHAIN_PRIO
+#define VIPRS_BF_PANEL_CHAIN_PRIO " PANEL_CHAIN_PRIO"
+#else
+#define VIPRS_BF_PANEL_CHAIN_PRIO ""
+#endif
+#ifdef VIPRS_GRID_MFMA_CHAIN
+#define VIPRS_BF_VIPRS_GRID_MFMA_CHAIN " VIPRS_GRID_MFMA_CHAIN"
+#else
+#define VIPRS_BF_VIPRS_GRID_MFMA_CHAIN ""
+#endif
+#ifdef GRID_EPI_BUFS
+#define VIPRS_BF_GRID_EPI_BUFS " GRID_EPI_BUFS"
+#else
+#define VIPRS_BF_GRID_EPI_BUFS ""
+#endif
+#ifdef VIPRS_GRID_PROFILE
+#define VIPRS_BF_VIPRS_GRID_PROFILE " VIPRS_GRID_PROFILE"
+#else
+#define VIPRS_BF_VIPRS_GRID_PROFILE ""
+#endif
+#ifdef VIPRS_TILE_PROFILE
+#define VIPRS_BF_VIPRS_TILE_PROFILE " VIPRS_TILE_PROFILE"
+#else
+#define VIPRS_BF_VIPRS_TILE_PROFILE ""
+#endif
+#ifdef VIPRS_SWEEP_TRACE
+#define VIPRS_BF_VIPRS_SWEEP_TRACE " VIPRS_SWEEP_TRACE"
+#else
+#define VIPRS_BF_VIPRS_SWEEP_TRACE ""
+#endif
+#ifdef VIPRS_PANEL_PROFILE
+#define VIPRS_BF_VIPRS_PANEL_PROFILE " VIPRS_PANEL_PROFILE"
+#else
+#define VIPRS_BF_VIPRS_PANEL_PROFILE ""
+#endif
+#define VIPRS_TU_BUILD_FLAGS VIPRS_BF_VIPRS_EXPERIMENTAL VIPRS_BF_PANEL_TIMING_NO_HANDOFF_WAIT VIPRS_BF_PANEL_TIMING_NO_SECOND_PASS VIPRS_BF_PANEL_NW VIPRS_BF_PANEL_MIX_UPPER_REGS VIPRS_BF_PANEL_UPPER_LDS_TILE VIPRS_BF_PANEL_STRIP_DEPTH VIPRS_BF_PANEL_MIN_WAVES VIPRS_BF_PANEL_TEAM_STRIP_DEPTH VIPRS_BF_PANEL_TEAM_CPL_F32 VIPRS_BF_PANEL_CHAIN_PRIO VIPRS_BF_VIPRS_GRID_MFMA_CHAIN VIPRS_BF_GRID_EPI_BUFS VIPRS_BF_VIPRS_GRID_PROFILE VIPRS_BF_VIPRS_TILE_PROFILE VIPRS_BF_VIPRS_SWEEP_TRACE VIPRS_BF_VIPRS_PANEL_PROFILE
+
+namespace viprs {
+// abi_plan.hip: the registry behind viprs_build_flags(); every translation unit with kernels registers its own string
+void register_build_flags(const char* flags);
+struct BuildFlagsRegistrar { explicit BuildFlagsRegistrar(const char* f) { register_build_flags(f); } };
+}  // namespace viprs
+
 namespace viprs {
 
 constexpr int kPanel = 64;          // SNPs per panel = lanes per wavefront on gfx950

@@ -429,16 +429,25 @@ class ZarrLDMatrix:
         data = self._cast(self._data.read(int(ip[start]), int(ip[stop])), dtype)
         return np.arange(start + 1, stop + 1, dtype=np.int32), ip[start:stop + 1] - ip[start], data
 
-    def get_lambda_min(self, min_max_ratio=0.0):
+    # Which of the two candidate formulas get_lambda_min uses when the store carries extremal eigenvalues and a
+    # min_max_ratio r > 0 is asked for.  None (the default) REFUSES: magenpy (not in the reference tree, not in this
+    # image) defines the formula; `tools/check_store.py` decides it against a real magenpy installation.
+    #   "one_plus_r"  : max((r lambda_max - lambda_min) / (1 + r), 0)   (as recalled from magenpy 0.1.x)
+    #   "one_minus_r" : max((r lambda_max - lambda_min) / (1 - r), 0)   (the algebraic solution of
+    #                   (lambda_min + x) = r (lambda_max + x))
+    lambda_min_formula = None
+
+    def get_lambda_min(self, min_max_ratio=0.0, formula=None):
         """The ridge penalty `VIPRS(lambda_min='infer')` asks for (`ld_mat.get_lambda_min(min_max_ratio=1e-3)`,
-        VIPRS.py:191), from the extremal eigenvalues magenpy stores under 'Spectral properties' -> 'Extremal':
-        max((r lambda_max - lambda_min) / (1 + r), 0) with r = min_max_ratio; with r = 0 that is |min(lambda_min, 0)|.
-        0 when the store has no spectral attributes.  PARITY UNPINNED: magenpy is not in the reference tree -- the
-        formula and the attribute names are as recalled from magenpy 0.1.x (both 'min'/'max' and 'Min'/'Max' keys are
-        accepted).  Note the denominator: the smallest x with (lambda_min + x) >= r (lambda_max + x) is
-        (r lambda_max - lambda_min) / (1 - r); the recalled (1 + r) differs from it by a factor (1 - r) / (1 + r),
-        0.2 % of the penalty at the r = 1e-3 VIPRS asks for -- whichever magenpy has, a store written by magenpy
-        (none exists in the image or the reference tree) is what would pin it."""
+        VIPRS.py:186-191), from the extremal eigenvalues magenpy stores under 'Spectral properties' -> 'Extremal'.
+
+        * no spectral attributes in the store: 0.0 -- what the reference documents (VIPRS.py:189-190: "If this is not
+          available, we set the minimum eigenvalue to 0");
+        * r = min_max_ratio == 0: |min(lambda_min, 0)| (no formula involved);
+        * r > 0: PARITY UNPINNED -- the two candidates above differ by (1 - r) / (1 + r) (0.2 % at VIPRS's r = 1e-3) and
+          nothing in the reference tree or this image decides between them.  Rather than hand `fit()` an unverified
+          ridge, this RAISES unless a formula is chosen explicitly (`formula=` here, or the class / instance attribute
+          `lambda_min_formula`); passing a numeric `lambda_min` to VIPRS avoids the question altogether."""
         sp = self.attrs.get("Spectral properties") or {}
         ext = sp.get("Extremal") or sp.get("extremal") or sp
 
@@ -453,8 +462,21 @@ class ZarrLDMatrix:
             return 0.0
         r = float(min_max_ratio or 0.0)
         if r > 0.0 and lam_max is not None:
-            return max((r * lam_max - lam_min) / (1.0 + r), 0.0)
+            formula = formula or self.lambda_min_formula
+            if formula not in ("one_plus_r", "one_minus_r"):
+                raise UnpinnedLambdaMinError(
+                    f"{self.path}: the store carries extremal eigenvalues (min {lam_min}, max {lam_max}) but the formula "
+                    "magenpy's LDMatrix.get_lambda_min(min_max_ratio) applies to them could not be verified (magenpy is "
+                    "not available where this reader was written).  Pass a numeric lambda_min to VIPRS(...), or choose "
+                    "ZarrLDMatrix.lambda_min_formula = 'one_plus_r' | 'one_minus_r' (tools/check_store.py tells which one "
+                    "a magenpy installation agrees with).")
+            den = 1.0 + r if formula == "one_plus_r" else 1.0 - r
+            return max((r * lam_max - lam_min) / den, 0.0)
         return abs(min(lam_min, 0.0))
+
+
+class UnpinnedLambdaMinError(NotImplementedError):
+    """`lambda_min='infer'` on a store with spectral attributes: the formula is unverified (ZarrLDMatrix.get_lambda_min)."""
 
 
 def write_ld_store(path, ld_indptr, ld_data, attrs=None, chunks=None, cname="zstd", clevel=5, shuffle=1,

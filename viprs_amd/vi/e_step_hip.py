@@ -4,7 +4,7 @@ update contract and dtype/layout errors, executed by the HIP kernels of ``libvip
 
 The LD arrays are uploaded to the GPU the first time a given ``(ld_left_bound, ld_indptr,
 ld_data, low_memory)`` combination is seen and stay resident (``plan_for``); later calls move
-only the per-SNP vectors.  ``threads`` is accepted and ignored: results always follow the
+only the per-SNP vectors (and re-upload when a content fingerprint of the arrays has changed).  ``threads`` is accepted and ignored: results always follow the
 reference's ``threads=1`` semantics.
 """
 from collections import OrderedDict
@@ -34,12 +34,12 @@ def set_default_math_mode(mode):
     if mode not in ("exact", "fast"):
         raise ValueError("math mode must be 'exact' or 'fast'")
     _DEFAULT_MATH = mode
-    for plan, _, _ in _PLAN_CACHE.values():
+    for plan, _, _, _ in _PLAN_CACHE.values():
         plan.set_math_mode(mode)
 
 
 def clear_plan_cache():
-    for plan, _, _ in _PLAN_CACHE.values():
+    for plan, _, _, _ in _PLAN_CACHE.values():
         plan.close()
     _PLAN_CACHE.clear()
 
@@ -52,41 +52,71 @@ def set_plan_cache_budget(n_bytes):
 
 
 def _evict(keep):
-    total = sum(b for _, _, b in _PLAN_CACHE.values())
+    total = sum(b for _, _, b, _ in _PLAN_CACHE.values())
     for key in list(_PLAN_CACHE):
         if total <= _PLAN_CACHE_BYTES:
             break
         if key == keep:
             continue
-        plan, _, nbytes = _PLAN_CACHE.pop(key)
+        plan, _, nbytes, _ = _PLAN_CACHE.pop(key)
         plan.close()
         total -= nbytes
 
 
 def invalidate(ld_data=None):
     """Forget the device copy of `ld_data` (all cached plans when None).  The cache is keyed on the IDENTITY of the
-    host buffers, so an in-place edit of an LD array is not noticed: call this after one."""
+    host buffers; `plan_for` also fingerprints a sample of their contents on every call (`_fingerprint`), which catches
+    an in-place edit unless it misses every sampled byte: call this after one to be certain."""
     if ld_data is None:
         clear_plan_cache()
         return
     addr = ld_data.__array_interface__["data"][0]
     for key in [k for k in _PLAN_CACHE if k[3] == addr]:
-        plan, _, _ = _PLAN_CACHE.pop(key)
+        plan, _, _, _ = _PLAN_CACHE.pop(key)
         plan.close()
 
 
+_FP_EDGE = 4096          # bytes hashed at both ends of every array
+_FP_SAMPLES = 256        # + this many 64-byte windows spread evenly over the array
+
+
+def _fingerprint(*arrays):
+    """Cheap content fingerprint of the LD arrays (a few tens of KB hashed per call, whatever the array size): the first
+    and last 4 KB and 256 evenly spaced 64-byte windows of each.  The reference's Cython function reads the caller's
+    memory on every call (e_step_cpp.pyx:91-122); the resident device copy can only notice edits this way."""
+    import zlib
+    h = 0
+    for a in arrays:
+        b = a.reshape(-1).view(np.uint8)
+        n = b.shape[0]
+        h = zlib.crc32(n.to_bytes(8, "little"), h)
+        if n <= 2 * _FP_EDGE + 64 * _FP_SAMPLES:
+            h = zlib.crc32(b.tobytes(), h)
+            continue
+        h = zlib.crc32(b[:_FP_EDGE].tobytes(), h)
+        h = zlib.crc32(b[n - _FP_EDGE:].tobytes(), h)
+        starts = (np.arange(_FP_SAMPLES, dtype=np.int64) * ((n - 64) // _FP_SAMPLES))
+        idx = (starts[:, None] + np.arange(64, dtype=np.int64)[None, :]).reshape(-1)
+        h = zlib.crc32(b[idx].tobytes(), h)
+    return h
+
+
 def plan_for(ld_left_bound, ld_indptr, ld_data, low_memory):
-    """The cached device plan for these LD arrays (identity of the buffers is the key; the arrays
-    are kept alive by the cache so the identity cannot be recycled)."""
+    """The cached device plan for these LD arrays.  The key is the identity of the buffers (the arrays are kept alive
+    by the cache so the identity cannot be recycled); a content fingerprint taken on every call replaces the plan when
+    the caller has edited the arrays in place since the upload."""
     key = (ld_left_bound.__array_interface__["data"][0], ld_left_bound.shape[0],
            ld_indptr.__array_interface__["data"][0], ld_data.__array_interface__["data"][0],
            ld_data.shape[0], str(ld_data.dtype), bool(low_memory), _DEFAULT_DEVICE)
+    fp = _fingerprint(ld_left_bound, ld_indptr, ld_data)
     hit = _PLAN_CACHE.get(key)
     if hit is not None:
-        _PLAN_CACHE.move_to_end(key)
-        return hit[0]
+        if hit[3] == fp:
+            _PLAN_CACHE.move_to_end(key)
+            return hit[0]
+        _PLAN_CACHE.pop(key)[0].close()           # edited in place since the upload: the device copy is stale
     plan = LDPlan(ld_left_bound, ld_indptr, ld_data, low_memory, device=_DEFAULT_DEVICE, math_mode=_DEFAULT_MATH)
-    _PLAN_CACHE[key] = (plan, (ld_left_bound, ld_indptr, ld_data), int(plan.info(L.INFO_LD_BYTES_DEVICE)))
+    _PLAN_CACHE[key] = (plan, (ld_left_bound, ld_indptr, ld_data), int(plan.info(L.INFO_LD_BYTES_DEVICE)), fp)
     _evict(keep=key)
     return plan
 
