@@ -294,6 +294,22 @@ int viprs_plan_timing_history(viprs_plan* plan, int which, double* ms, int capac
 /* Number of SNPs of the last sweep that took the skip branch (e_step.hpp:410-413).            */
 int viprs_plan_last_skipped(viprs_plan* plan, int64_t* n_skipped);
 
+/* ---- measurement support: synthetic LD generated on the device (bench.py, tests) --------------
+ * The "longrange" LD blocks of viprs_amd/utils/synthetic.py (the workload of BASELINE.json's configs, SURVEY.md 8d: the
+ * reference gets its LD from magenpy stores, VIPRS.py:151-172, none of which exists here) written straight into a plan's
+ * device memory: a rank of a multi-GPU run has its genome-scale workload in milliseconds instead of generating 3.8 GB on
+ * the host and uploading it.  `sizes`: n_blocks block sizes; pw / uf0 / uf1 / sa / sf: per-SNP float32 parameter
+ * vectors (m = sum of sizes entries each; synthetic.longrange_device_params): entry (i, j) of a block is
+ *   (uf0[i] uf0[j] + uf1[i] uf1[j]) + (pw[|i - j|] sa[i]) sf[j]  off the diagonal, 1 on it,
+ * every operation rounded to float32; int8 / int16 LD stores rint(127 x) / rint(32767 x).  Layout, validation, block
+ * discovery and re-lay-out are those of viprs_plan_create.  viprs_synthetic_ld_host runs the SAME function on the host
+ * into the caller's row-concatenated array of `capacity` elements (the CPU test of the generator). */
+int viprs_plan_create_synthetic(viprs_plan** plan, int64_t n_blocks, const int64_t* sizes, const float* pw,
+                                const float* uf0, const float* uf1, const float* sa, const float* sf, int ld_dtype,
+                                int low_memory, int device);
+int viprs_synthetic_ld_host(int64_t n_blocks, const int64_t* sizes, const float* pw, const float* uf0, const float* uf1,
+                            const float* sa, const float* sf, int ld_dtype, int low_memory, void* out, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,8 +56,13 @@ for k, v in per_kernel.items():
 summary = {"tag": tag, "key": key, "hbm_bytes_per_sweep": int(total), "kernels": per_kernel,
            "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes (MI355X_MICROARCH.md)"}
 json.dump(summary, open(os.path.join(here, f"{tag}_pmc_summary.json"), "w"), indent=1)
+# bench.py quotes the figure only while the sources of the kernel family it was collected on are unchanged
+sys.path.insert(0, os.path.dirname(here))
+from viprs_amd.utils import kernel_id  # noqa: E402
 tp = os.path.join(here, "pmc_traffic.json")
 traffic = json.load(open(tp)) if os.path.exists(tp) else {}
-traffic[key] = int(total)
+fam = kernel_id.family_of(key)
+traffic[key] = {"hbm_bytes_per_sweep": int(total), "family": fam, "src_hash": kernel_id.source_hash(fam),
+                "kernels": sorted(per_kernel), "collected": tag}
 json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps(summary, indent=1))

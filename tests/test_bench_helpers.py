@@ -122,6 +122,10 @@ _lib.check = lambda rc: None
 class FakePlan:
     def __init__(self, lb, ip, data, low_memory, device=0, math_mode="exact"):
         self.m = int(lb.shape[0]); self.n = 0
+    @classmethod
+    def synthetic(cls, ld, device=0, math_mode="exact"):
+        assert ld.ld_data is None and ld.kind == "longrange" and len(ld.params) == len(ld.block_start) - 1   # a skeleton: nothing built on the host
+        return cls(ld.ld_left_bound, ld.ld_indptr, None, ld.low_memory, device, math_mode)
     def timing_reset(self): self.n = 0
     def timing_history(self, which=0, capacity=256): return [0.5 + 0.01 * int(os.environ["RANK"])] * max(self.n, 1)
     def last_skipped(self): return 7
@@ -143,12 +147,13 @@ print("RANK_DONE", os.environ["RANK"])
 """
 
 
-@pytest.mark.parametrize("extra", [["--scaling", "strong"], []], ids=["strong", "weak"])
+@pytest.mark.parametrize("extra", [[], ["--scaling", "weak"]], ids=["strong-default", "weak"])
 def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra):
     """bench.py's N > 1 path run for real with two processes (torch.distributed.run-style environment,
     VIPRS_BENCH_COMM=file, device layer stubbed): ONE JSON line from rank 0 whose `n_gpus`, `comm`, `snps_total`,
-    `scaling` and per-rank vectors describe the default run (weak: one workload per rank, the strong figure beside it)
-    or, with --scaling strong, a run of ONE sharded workload (the weak figure beside it)."""
+    `scaling` and per-rank vectors describe the default run (strong = BASELINE configs[2]: ONE workload sharded by LD block,
+    the weak figure beside it under its own metric text) or, with --scaling weak, one workload per rank (the strong figure
+    beside it)."""
     import json
     import os
     import subprocess
@@ -167,11 +172,12 @@ def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra
     assert len(lines) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]   # rank 0 only, one line
     out = json.loads(lines[0])
     sizes = bench.config_sizes("cfg2", 7209)
-    weak = "strong" not in extra
+    weak = "weak" in extra
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
     assert out["scaling"] == ("weak" if weak else "strong")
     assert "file transport" in out["config"]["comm"]
     pr = out["per_rank"]
+    assert ("1M SNPs, ~1700 LD blocks" in out["metric"]) and (("independent" in out["metric"]) == weak)
     if weak:
         assert out["config"]["snps_total"] == 2 * int(sizes.sum()) and pr["snps"] == [int(sizes.sum())] * 2
         assert "weak_scaling" not in out
@@ -186,8 +192,13 @@ def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra
         parts = bench.shard_blocks_lpt(sizes, 2)
         assert pr["snps"] == [int(sizes[p].sum()) for p in parts]
         assert pr["algorithmic_bytes"] == [int(4 * (sizes[p] ** 2).sum() + 68 * sizes[p].sum()) for p in parts]
-        assert out["weak_scaling"]["snps_per_gpu"] == int(sizes.sum())
+        assert out["metric"] == "SNP-updates/sec/E-step (1M SNPs, ~1700 LD blocks)"          # BASELINE's metric, one workload
+        assert out["weak_scaling"]["snps_per_gpu"] == int(sizes.sum()) and "INDEPENDENT" in out["weak_scaling"]["metric"]
         assert len(out["weak_scaling"]["kernel_ms_avg_per_rank"]) == 2
+        c = out["strong_scaling_ceiling"]
+        assert c["largest_block_snps"] == int(sizes.max()) and c["max_speedup_over_one_gpu"] >= 1.0
+        assert c["largest_block_chain_ms"] == pytest.approx(int(sizes.max()) * 135e-6)
+        assert out["startup_s_rank0"]["ld_entries"] == "generated on the device"
     assert out["value"] == pytest.approx(out["config"]["snps_total"] * 3 / (out["ms_per_step"] * 3e-3), rel=1e-6)
     assert pr["kernel_ms_avg"] == pytest.approx([0.5, 0.51]) and len(pr["time_model_ms"]) == 2
     assert out["roofline"]["kernel_ms_avg"] == pytest.approx(0.51)            # slowest rank
@@ -214,6 +225,10 @@ if "RANK" in os.environ:
     class FakePlan:
         def __init__(self, lb, ip, data, low_memory, device=0, math_mode="exact"):
             self.m = int(lb.shape[0]); self.n = 0
+        @classmethod
+        def synthetic(cls, ld, device=0, math_mode="exact"):
+            assert ld.ld_data is None and ld.kind == "longrange"
+            return cls(ld.ld_left_bound, ld.ld_indptr, None, ld.low_memory, device, math_mode)
         def timing_reset(self): self.n = 0
         def timing_history(self, which=0, capacity=256): return [0.5 + 0.01 * int(os.environ["RANK"])] * max(self.n, 1)
         def last_skipped(self): return 7
@@ -256,9 +271,9 @@ def test_bare_bench_gpus_2_starts_two_ranks_itself(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["rccl_ranks"] is None
     assert "file transport" in out["config"]["comm"]
     pr = out["per_rank"]
-    # the default series over N is weak: every rank its own workload; the sharded (strong) figure sits beside it
-    assert out["scaling"] == "weak" and pr["snps"] == [int(sizes.sum())] * 2
-    assert out["strong_scaling"]["snps_total"] == int(sizes.sum())
+    # the default series over N is strong (BASELINE configs[2]): ONE workload sharded over the ranks; the weak figure sits beside it
+    assert out["scaling"] == "strong" and sum(pr["snps"]) == int(sizes.sum()) == out["config"]["snps_total"]
+    assert out["weak_scaling"]["snps_total"] == 2 * int(sizes.sum())
     assert pr["kernel_ms_avg"] == pytest.approx([0.5, 0.51])                 # each rank reported under its own RANK
     assert out["roofline"]["peak"] == 2 * bench.HBM_PEAK_GBS
 

@@ -458,3 +458,20 @@ def test_in_place_edit_of_ld_data_is_noticed_by_the_drop_in_call(gpu):
     H.assert_state_equal(got, ref)
     ld.ld_data[...] = off
     H.assert_state_equal(H.run_hip(ld, inp, st0), H.run_oracle(ld, inp, st0))
+
+
+@pytest.mark.parametrize("team0, size", [("1", 12900), ("7", 6100), ("5", 3000)])
+def test_forced_team_sizes_and_the_lds_budget_path(gpu, monkeypatch, team0, size):
+    """VIPRS_TEAM0 forces team sizes the planner never picks (5, 7), and with VIPRS_TEAM0=1 an int8
+    upper-triangular block of 12 900 SNPs does not fit one workgroup's 160 KB (q + second-pass sums + the off-diagonal
+    tile integer LD stages in LDS): the launcher grows the team until it fits (launch_panel.inc).  Same bits as the
+    oracle in every case."""
+    from viprs_amd.vi import e_step_hip as S
+    monkeypatch.setenv("VIPRS_TEAM0", team0)
+    S.clear_plan_cache()
+    try:
+        ld, ss, inp = syn.make_problem(sizes=[size, 130, 64], low_memory=True, ld_dtype=np.int8, seed=23, kind="longrange")
+        st0 = inp.state_copy()
+        H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=2), H.run_oracle(ld, inp, st0, sweeps=2))
+    finally:
+        S.clear_plan_cache()

@@ -4,6 +4,7 @@ import os
 import threading
 
 import numpy as np
+import pytest
 
 from viprs_amd import parallel as P
 
@@ -120,3 +121,39 @@ def test_root_broadcast_survives_glob_characters_and_fails_fast(tmp_path):
     t0 = time.time()
     t = threading.Thread(target=waiter); t.start(); t.join(30)
     assert "rank 0 reported a failure" in err.get("e", "") and time.time() - t0 < 10
+
+
+def test_root_broadcast_failure_marker_does_not_outlive_its_launch(tmp_path, monkeypatch):
+    """on a FIXED base (VIPRS_COMM_ID_FILE, or a reused port / run id / parent) a failed launch must not fail
+    the next one: failure markers are keyed by the requester's nonce, rank 0 clears stale ones when it starts, and a
+    second launch on the same base goes through while the first one's rank 0 is still in its failure grace period."""
+    import threading
+    import time
+    from viprs_amd.parallel import _RootBroadcast
+    monkeypatch.setattr(_RootBroadcast, "FAIL_GRACE_S", 1.0)
+    base = str(tmp_path / "fixed.id")
+    # launch 1: rank 0 fails; a waiting rank and a late rank both fail fast
+    root1 = _RootBroadcast(0, base, lambda: b"a" * 128)
+    root1.fail()
+    root1.finish()                                           # (RcclComm's `finally`): must not hide the failure
+    for _ in range(2):
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="rank 0 reported a failure"):
+            _RootBroadcast(1, base, timeout_s=20)
+        assert time.time() - t0 < 5
+    # a stale marker as a crashed process would leave it (old scheme: base-wide `.err`; new scheme: somebody else's nonce)
+    for stale in (base + ".err", base + ".err.1.deadbeefdeadbeef"):
+        open(stale, "wb").close()
+    time.sleep(1.3)                                          # launch 1's grace period ends; its helper sweeps and exits
+    root1._thread.join(5)
+    assert not root1._thread.is_alive()
+    open(base + ".err", "wb").close()
+    # launch 2 on the same base
+    root2 = _RootBroadcast(0, base, lambda: b"b" * 128)
+    assert not os.path.exists(base + ".err")
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("p", _RootBroadcast(1, base, timeout_s=20).payload))
+    t.start(); t.join(30)
+    assert got.get("p") == b"b" * 128
+    root2.finish()
+    assert [f for f in os.listdir(tmp_path) if f.startswith("fixed.id")] == []

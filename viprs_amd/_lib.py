@@ -100,6 +100,8 @@ _PROTOS = {
     "viprs_comm_barrier": (_i, [_vp]),
     "viprs_state_set_comm": (_i, [_vp, _vp]),
     "viprs_device_synchronize": (_i, [_i]),
+    "viprs_plan_create_synthetic": (_i, [ctypes.POINTER(_vp), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    "viprs_synthetic_ld_host": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64]),
     "viprs_plan_last_kernel_ms": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "viprs_plan_last_skipped": (_i, [_vp, _pi64]),
     "viprs_plan_timing_reset": (_i, [_vp]),

@@ -125,7 +125,8 @@ static int widen_indptr(int64_t m, const void* indptr, int indptr_dtype, std::ve
 }
 
 static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, const std::vector<int64_t>& ip64,
-                            const void* ld_data, int ld_dtype, int low_memory, int device, const ExpandSource* ex) {
+                            const void* ld_data, int ld_dtype, int low_memory, int device, const ExpandSource* ex,
+                            const std::function<int(void*)>* fill = nullptr) {
     const size_t es = ld_elem_size(ld_dtype);
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
@@ -150,7 +151,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     int rc = plan_blocks(m, lb, ip64.data(), low_memory != 0, P->blocks, err);
     if (rc != VIPRS_OK) return fail(rc, err);
     P->nnz = m > 0 ? ip64[(size_t)m] : 0;
-    if (P->nnz > 0 && !ld_data && !ex) return fail(VIPRS_EINVAL, "ld_data is null");
+    if (P->nnz > 0 && !ld_data && !ex && !fill) return fail(VIPRS_EINVAL, "ld_data is null");
 
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -272,7 +273,11 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     }
     if (P->nnz > 0) {
         HIP_TRY(P->d_ld_raw.alloc((size_t)P->nnz * es + 64));      // + slack: the band kernel clamps empty rows to their start
-        if (!ex) {
+        if (fill) {
+            // the rows are produced on the device (synth.hip), in the caller's row-concatenated layout
+            rc = (*fill)(P->d_ld_raw.p);
+            if (rc != VIPRS_OK) return rc;
+        } else if (!ex) {
             HIP_TRY(hipMemcpy(P->d_ld_raw.p, ld_data, (size_t)P->nnz * es, hipMemcpyHostToDevice));
         } else {
             // upload the compact store, mirror it into the symmetric rows on the device, drop it
@@ -388,6 +393,36 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     *out = P.release();
     return VIPRS_OK;
 }
+
+namespace viprs {
+namespace {
+std::mutex g_gate_mutex;
+std::map<int, hipEvent_t> g_gate_event;        // per device: completion of the last launch with co-resident teams
+hipStream_t g_gate_stream[64] = {};             // ... and the stream it went to (same stream: already ordered)
+}  // namespace
+int team_launch_gate(viprs_plan* P) {
+    std::lock_guard<std::mutex> lock(g_gate_mutex);
+    auto it = g_gate_event.find(P->device);
+    if (it != g_gate_event.end() && g_gate_stream[P->device & 63] != P->stream) HIP_TRY(hipStreamWaitEvent(P->stream, it->second, 0));
+    return VIPRS_OK;
+}
+int team_launch_done(viprs_plan* P) {
+    std::lock_guard<std::mutex> lock(g_gate_mutex);
+    auto it = g_gate_event.find(P->device);
+    if (it == g_gate_event.end()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        it = g_gate_event.emplace(P->device, e).first;
+    }
+    HIP_TRY(hipEventRecord(it->second, P->stream));
+    g_gate_stream[P->device & 63] = P->stream;
+    return VIPRS_OK;
+}
+int plan_create_generated(viprs_plan** out, int64_t m, const int32_t* lb, const std::vector<int64_t>& ip64, int ld_dtype,
+                          int low_memory, int device, const std::function<int(void*)>& fill) {
+    return plan_create_impl(out, m, lb, ip64, nullptr, ld_dtype, low_memory, device, nullptr, &fill);
+}
+}  // namespace viprs
 
 extern "C" {
 

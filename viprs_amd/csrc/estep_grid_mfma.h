@@ -758,6 +758,9 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                     if (lane == 0) atomicExch(A.error, 1);
                     break;
                 }
+                // a wait has timed out somewhere (this wave's earlier chunk included): the launch is lost and reported; every
+                // later wait returns at once instead of spinning out its own timeout (64 chunks x panels = minutes)
+                if ((spins & 255u) == 0u && __hip_atomic_load(A.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                 __builtin_amdgcn_s_sleep(16);
             }
 #pragma unroll

@@ -778,6 +778,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                 if (lane == 0) atomicExch(A.error, 1);
                                 break;
                             }
+                            // somebody has given up already: the launch is lost, no further wait may cost another timeout
+                            if ((spins & 1023u) == 1023u &&
+                                __hip_atomic_load(A.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
                         qc = __uint_as_float((unsigned)g);

@@ -8,6 +8,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -181,6 +182,20 @@ struct viprs_state {
 };
 
 namespace viprs {
+
+// abi_plan.hip: a plan whose LD rows (the caller's row-concatenated layout, `ip64[m]` elements) are written by `fill`
+// into device memory instead of being uploaded from the host (synth.hip)
+int plan_create_generated(viprs_plan** out, int64_t m, const int32_t* lb, const std::vector<int64_t>& ip64, int ld_dtype,
+                          int low_memory, int device, const std::function<int(void*)>& fill);
+
+// Launches whose workgroups wait for each other (team hand-offs: the panel sweep, the batched grid kernel) size their grid to
+// the workgroups the WHOLE device can hold at once.  Two such launches in flight on one device (several plans of one
+// process on their own streams: unmerged chromosomes, VIPRSGrid's per-plan sweeps) would each find only part of the device
+// and could leave a team member undispatched while its peers spin.  `team_launch_gate` orders them: the stream of the plan
+// waits for the previous gated launch on this device, `team_launch_done` records this one.  (Other PROCESSES on the
+// same device cannot be ordered from here: the bounded spins report VIPRS_EDEVICE instead of hanging.)
+int team_launch_gate(viprs_plan* P);
+int team_launch_done(viprs_plan* P);
 
 // after a synchronisation point: did a team hand-off give up (bounded spin)?
 int check_device_error(viprs_plan* P);

@@ -157,9 +157,12 @@ def _launch_key():
 class _RootBroadcast:
     """Rank 0's small byte string reaches the other ranks of the node through files, WITHOUT any rank ever accepting
     a file of an earlier (crashed) run: rank r > 0 drops a request `<base>.req.<r>.<nonce>` with a fresh random nonce
-    and accepts only `<base>.rsp.<r>.<nonce>`; rank 0 answers every request it sees from a helper thread until
-    `finish()`, which also removes whatever requests / responses (its own run's and stale ones) carry this base.
-    No PyTorch, no extra port."""
+    and accepts only `<base>.rsp.<r>.<nonce>` -- or the failure marker `<base>.err.<r>.<nonce>`; rank 0 answers every
+    request it sees from a helper thread until `finish()`, which also removes whatever requests / responses / markers
+    (its own run's and stale ones) carry this base.  Every file a waiter acts on is keyed by ITS nonce: nothing a
+    failed launch leaves behind can fail (or satisfy) a later launch on the same base.  No PyTorch, no extra port."""
+
+    FAIL_GRACE_S = 30.0          # after fail(): how long rank 0 keeps telling late requesters about the failure
 
     def __init__(self, rank, base, payload_fn=None, timeout_s=300.0):
         import glob
@@ -167,79 +170,104 @@ class _RootBroadcast:
         import threading
         self.rank, self.base = rank, base
         self._thread = None
+        self._failed_at = None
         if rank == 0:
+            for f in glob.glob(f"{glob.escape(base)}.err*"):      # markers of an earlier failed launch on this base
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
             self.payload = payload_fn()
             self._stop = threading.Event()
-            answered = set()
-
-            def serve():
-                while not self._stop.is_set():
-                    for req in glob.glob(f"{glob.escape(base)}.req.*"):
-                        if req in answered:
-                            continue
-                        rsp = f"{base}.rsp." + req[len(base) + 5:]
-                        tmp = f"{rsp}.{os.getpid()}.tmp"
-                        try:
-                            with open(tmp, "wb") as f:
-                                f.write(self.payload)
-                            os.replace(tmp, rsp)
-                        except OSError:
-                            continue
-                        answered.add(req)
-                    self._stop.wait(0.005)
-
-            self._thread = threading.Thread(target=serve, daemon=True)
-            self._thread.start()
+            self._start_server()
             return
         nonce = secrets.token_hex(8)
-        req, rsp = f"{base}.req.{rank}.{nonce}", f"{base}.rsp.{rank}.{nonce}"
+        req, rsp, err = (f"{base}.{kind}.{rank}.{nonce}" for kind in ("req", "rsp", "err"))
         with open(req, "wb"):
             pass
         t0 = time.time()
-        while True:
-            try:
-                with open(rsp, "rb") as f:
-                    self.payload = f.read()
-                break
-            except FileNotFoundError:
-                pass
-            if os.path.exists(f"{base}.err"):
-                raise RuntimeError(f"rank {rank}: rank 0 reported a failure while this rank waited for {rsp}")
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"rank {rank}: rank 0 did not answer {req} within {timeout_s:.0f} s")
-            time.sleep(0.005)
-        for f in (req, rsp):
-            try:
-                os.remove(f)
-            except OSError:
-                pass
+        try:
+            while True:
+                try:
+                    with open(rsp, "rb") as f:
+                        self.payload = f.read()
+                    break
+                except FileNotFoundError:
+                    pass
+                if os.path.exists(err):
+                    raise RuntimeError(f"rank {rank}: rank 0 reported a failure while this rank waited for {rsp}")
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError(f"rank {rank}: rank 0 did not answer {req} within {timeout_s:.0f} s")
+                time.sleep(0.005)
+        finally:
+            for f in (req, rsp, err):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+
+    def _start_server(self):
+        import glob
+        import threading
+        base = self.base
+        answered = set()
+
+        def serve():
+            while not self._stop.is_set():
+                failed = self._failed_at is not None
+                if failed and time.time() - self._failed_at > self.FAIL_GRACE_S:
+                    break
+                for req in glob.glob(f"{glob.escape(base)}.req.*"):
+                    if (req, failed) in answered:
+                        continue
+                    out = f"{base}.{'err' if failed else 'rsp'}." + req[len(base) + 5:]
+                    tmp = f"{out}.{os.getpid()}.tmp"
+                    try:
+                        with open(tmp, "wb") as f:
+                            f.write(b"" if failed else self.payload)
+                        os.replace(tmp, out)
+                    except OSError:
+                        continue
+                    answered.add((req, failed))
+                self._stop.wait(0.005)
+            if self._failed_at is not None:
+                self._sweep_litter()
+
+        self._thread = threading.Thread(target=serve, daemon=True)
+        self._thread.start()
+
+    def _sweep_litter(self):
+        import glob
+        for kind in ("req", "rsp", "err"):
+            for f in glob.glob(f"{glob.escape(self.base)}.{kind}.*"):
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
 
     def fail(self):
-        """Rank 0, when what follows the broadcast failed on it (e.g. its communicator did not come up): leave a marker
-        so that ranks still waiting for their response raise at once instead of waiting out the timeout.  (The marker
-        carries this launch's key like every other file of the base, so no other launch ever sees it; it is one empty
-        file left behind by a failed launch.)"""
-        if self.rank == 0:
-            try:
-                with open(f"{self.base}.err", "wb"):
-                    pass
-            except OSError:
-                pass
+        """Rank 0, when what follows the broadcast failed on it (e.g. its communicator did not come up): from now on every
+        request -- those already waiting and those that still arrive within FAIL_GRACE_S -- is answered with the failure
+        marker of ITS nonce, so that the ranks raise at once instead of waiting out the timeout.  (A rank that files its
+        request after rank 0's process is gone waits for its timeout: nothing is left to answer it, and nothing stale to
+        mislead it.)"""
+        if self.rank != 0:
+            return
+        self._failed_at = time.time()
+        if self._thread is None or not self._thread.is_alive():
+            self._stop.clear()
+            self._start_server()
 
     def finish(self):
         """Rank 0, once every rank is known to hold the payload (a collective has completed): stop answering and
-        remove the litter of this base, stale files of crashed runs included."""
-        if self._thread is None:
+        remove the litter of this base, stale files of crashed runs included.  After fail() the helper thread is left
+        to its grace period (it removes the litter itself when that ends)."""
+        if self._thread is None or self._failed_at is not None:
             return
-        import glob
         self._stop.set()
         self._thread.join()
         self._thread = None
-        for f in glob.glob(f"{glob.escape(self.base)}.req.*") + glob.glob(f"{glob.escape(self.base)}.rsp.*"):
-            try:
-                os.remove(f)
-            except OSError:
-                pass
+        self._sweep_litter()
 
 
 def _exchange_unique_id(rank, world_size, make_id, timeout_s=300.0):

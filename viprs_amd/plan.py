@@ -108,6 +108,33 @@ class LDPlan:
         self.set_math_mode(math_mode)
         return self
 
+    @classmethod
+    def synthetic(cls, ld, device=0, math_mode="exact"):
+        """Plan of a `viprs_amd.utils.synthetic` "longrange" workload whose LD entries are GENERATED ON THE DEVICE
+        (`viprs_plan_create_synthetic`): `ld` is the `SyntheticLD` skeleton (`make_ld(..., kind="longrange",
+        data=False)`; a full one works too, its `ld_data` is ignored).  Bit-identical to `LDPlan(ld.ld_left_bound,
+        ld.ld_indptr, make_ld(...).ld_data, ...)` (tests/test_synth_device.py); measurement support, not on the
+        reference's path."""
+        from .utils import synthetic as syn
+        if ld.kind != "longrange" or ld.params is None:
+            raise ValueError("LDPlan.synthetic: a 'longrange' SyntheticLD with its block parameters is needed")
+        dt = np.dtype(ld.ld_dtype if ld.ld_data is None else ld.ld_data.dtype)
+        if dt not in (np.dtype(np.float32), np.dtype(np.int8), np.dtype(np.int16)):
+            raise ValueError("LDPlan.synthetic: float32, int8 or int16 LD")
+        sizes = np.ascontiguousarray(np.diff(ld.block_start), dtype=np.int64)
+        vecs = syn.longrange_device_params(sizes, ld.rho, ld.params)
+        self = cls.__new__(cls)
+        self.m = int(sizes.sum())
+        self.low_memory = bool(ld.low_memory)
+        self.ld_dtype = dt
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        L.check(L.lib.viprs_plan_create_synthetic(ctypes.byref(self._h), int(sizes.shape[0]), _ptr(sizes),
+                                                  *[_ptr(v) for v in vecs], _LD_CODE[dt], int(self.low_memory),
+                                                  self.device))
+        self.set_math_mode(math_mode)
+        return self
+
     def windows(self):
         """``(ld_left_bound int32, ld_indptr int64)`` of the plan's rows."""
         lb = np.zeros(self.m, dtype=np.int32)

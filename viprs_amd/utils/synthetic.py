@@ -53,10 +53,19 @@ class SyntheticLD:
     meta: dict = field(default_factory=dict)
     kind: str = "ar1"
     params: list = None            # "longrange": per block (alpha, U (b, r) with the signs folded in, signs (b,))
+    ld_dtype: np.dtype = None      # element type when `ld_data` is None (a skeleton: the entries exist on the device only)
 
     @property
     def m(self):
         return int(self.ld_left_bound.shape[0])
+
+    @property
+    def itemsize(self):
+        return int(np.dtype(self.ld_dtype).itemsize if self.ld_data is None else self.ld_data.dtype.itemsize)
+
+    @property
+    def nnz(self):
+        return int(self.ld_indptr[-1])
 
 
 def _ar1_row(b, rho, dtype, quant_max):
@@ -155,12 +164,34 @@ def longrange_params(sizes, seed=SEED):
     return [_longrange_params(prng, int(b)) for b in sizes]
 
 
+def longrange_device_params(sizes, rho, params):
+    """The per-SNP float32 vectors `viprs_plan_create_synthetic` / `viprs_synthetic_ld_host` take (include/viprs_hip.h):
+    exactly the float32 intermediates of `_longrange_block`, concatenated over the blocks --
+    pw[k] = float32(rho^k), uf0 / uf1 = float32(U sqrt(1 - alpha)), sa = float32(signs) * float32(alpha), sf = float32(signs)."""
+    f32 = np.float32
+    m = int(np.sum(sizes))
+    pw, uf0, uf1, sa, sf = (np.empty(m, dtype=f32) for _ in range(5))
+    o = 0
+    for b, r, (alpha, U, signs) in zip(sizes, rho, params):
+        b = int(b)
+        assert U.shape == (b, 2), "the device generator implements the two-factor blocks of `_longrange_params`"
+        pw[o:o + b] = np.power(np.float64(r), np.arange(b)).astype(f32)
+        Uf = (U * np.sqrt(1.0 - alpha)).astype(f32)
+        uf0[o:o + b], uf1[o:o + b] = Uf[:, 0], Uf[:, 1]
+        s = signs.astype(f32)
+        sa[o:o + b] = s * f32(alpha)
+        sf[o:o + b] = s
+        o += b
+    return pw, uf0, uf1, sa, sf
+
+
 def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64, seed=SEED, rho_range=(0.3, 0.8),
-            rho=None, kind="ar1", params=None):
+            rho=None, kind="ar1", params=None, data=True):
     """Block-diagonal LD in symmetric (`low_memory=False`: every row of a block stores the whole
     block, diagonal included) or upper-triangular form (`low_memory=True`: row j stores columns
     j+1 .. block_end-1, left bound j+1) -- the two layouts e_step.hpp:389-392,423-440 consumes.
-    `kind`: "ar1" | "longrange" | "sample" (module docstring)."""
+    `kind`: "ar1" | "longrange" | "sample" (module docstring).  `data=False`: the skeleton only (index arrays, block
+    parameters, `ld_data = None`) -- for plans whose entries are generated on the device (`LDPlan.synthetic`)."""
     if kind not in LD_KINDS:
         raise ValueError(f"unknown LD kind {kind!r}")
     sizes = np.asarray(sizes, dtype=np.int64)
@@ -178,7 +209,7 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
         nnz = int((sizes * (sizes - 1) // 2).sum())
     else:
         nnz = int((sizes * sizes).sum())
-    data = np.empty(nnz, dtype=ld_dtype)
+    data = np.empty(nnz, dtype=ld_dtype) if data else None
     lb = np.empty(m, dtype=np.int32)
     rowlen = np.empty(m, dtype=np.int64)
     off = 0
@@ -217,7 +248,9 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
         else:
             _store_dense_block(data, o, _sample_block(params[bi], b, rho[bi]), low_memory, ld_dtype, quant_max)
 
-    if nnz > (1 << 24):
+    if data is None:
+        pass
+    elif nnz > (1 << 24):
         from concurrent.futures import ThreadPoolExecutor
         import os
         with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
@@ -227,7 +260,7 @@ def make_ld(sizes, low_memory=False, ld_dtype=np.float32, indptr_dtype=np.int64,
             _job(j)
     indptr = np.concatenate([[0], np.cumsum(rowlen)]).astype(indptr_dtype)
     return SyntheticLD(lb, indptr, data, starts, rho, bool(low_memory), dq_scale, kind=kind,
-                       params=params if kind == "longrange" else None)
+                       params=params if kind == "longrange" else None, ld_dtype=ld_dtype)
 
 
 def dense_block(ld, bi):
