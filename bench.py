@@ -414,6 +414,7 @@ def measure_secondary(name, sw, steps, barrier, math_mode="exact", traffic_key=N
            "kernel_ms_avg": k_avg, "kernel_ms_p50": pct(k, 50), "all_kernels_ms_avg": float(np.mean(k_all)) if k_all else None,
            "roofline_frac": by / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": int(by), "steps": steps, "math_mode": math_mode,
+           "math_mode_effective": sw.plan.effective_math_mode(),      # what the kernels really ran in (fast: not every model has it)
            "time_model_ms": t_model, "time_model_bound": bound, "time_model_terms_ms": terms,
            "chain_ns_per_snp_model": ns, "frac_of_model": t_model / float(np.mean(k_all) if k_all else k_avg)}
     tr, tr_note = pmc_traffic(traffic_key) if traffic_key else (None, None)
@@ -689,6 +690,7 @@ def main():
     my_elapsed = sw.run(args.steps, args.warmup, barrier)
     elapsed = float(comm.allreduce_max(np.array([my_elapsed]))[0])
     skipped = sw.plan.last_skipped()
+    sw_math_effective = sw.plan.effective_math_mode() if hasattr(sw.plan, "effective_math_mode") else None
     k_ms = sw.plan.timing_history(which=1)
     sweep_ms = sw.plan.timing_history(which=0)
     es = ld_dtype.itemsize
@@ -835,7 +837,7 @@ def main():
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
                 "primary": "`value` is the " + ("upper-triangular" if ld.low_memory else "symmetric") + " LD form; the other "
                            "form (the reference's default is low_memory=True) is in `secondary`",
-                "math_mode": args.math, "skipped_snps_last_sweep_rank0": int(skipped),
+                "math_mode": args.math, "math_mode_effective": sw_math_effective, "skipped_snps_last_sweep_rank0": int(skipped),
                 "comm": comm_kind, "rccl_ranks": int(comm_ranks) if comm_kind == "rccl" else None,
                 "ranks": int(comm_ranks),
                 "parallelism": (f"ld-blocks x{n_gpus} (strong: chain-aware LPT, no data-path collective; RCCL barrier / max only)"

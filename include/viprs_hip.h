@@ -291,6 +291,11 @@ int viprs_plan_last_kernel_ms(viprs_plan* plan, int which, double* ms);
  * sweeps, oldest first.                                                                       */
 int viprs_plan_timing_reset(viprs_plan* plan);
 int viprs_plan_timing_history(viprs_plan* plan, int which, double* ms, int capacity, int* n);
+/* Arithmetic the kernels of the last sweep on this plan really ran in: bit 0 = exact, bit 1 = fast.
+ * viprs_plan_set_math_mode(FAST) applies where a fast instantiation exists (spike-and-slab, grid, mixtures of up to 8
+ * components, fp32 state); mixtures of 9+ components, the mixture / grid kernels of windowed blocks with K > 8 and
+ * every float64 state run exact whatever was asked for -- this is how a caller (bench.py) finds out.          */
+int viprs_plan_last_math_modes(const viprs_plan* plan, int* mask);
 /* Number of SNPs of the last sweep that took the skip branch (e_step.hpp:410-413).            */
 int viprs_plan_last_skipped(viprs_plan* plan, int64_t* n_skipped);
 

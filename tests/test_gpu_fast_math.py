@@ -185,3 +185,52 @@ def test_fast_math_windowed_components(gpu, fast_mode, model, low_memory):
         fast = _run_grid(fast_mode, ld, inp, g, st0, active, 2)
     assert not all(np.array_equal(fast[k], ref[k]) for k in H.STATE), "fast mode did not run (results are bit-identical)"
     assert_within_one_ulp_yardstick(fast, ref, ulp, f"band kernel, {model}, {'upper' if low_memory else 'symmetric'}")
+
+
+def test_effective_math_mode_is_reported(gpu):
+    """math_mode='fast' exists for spike-and-slab / grid / K <= 8 mixtures on an fp32 state only; wider mixtures
+    and float64 states run exact kernels whatever was asked for, and the plan says so (viprs_plan_last_math_modes)."""
+    import warnings
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld, ss, inp = syn.make_problem(sizes=[300, 90], seed=3)
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False, math_mode="fast")
+    assert plan.effective_math_mode() is None
+    st = DeviceState(plan, "float32", "spike_slab", 1)
+    for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+        st.upload(name, getattr(inp, name))
+    st.reset(inp.pi)
+    st.e_step(ld.dq_scale, None, sync=True)
+    assert plan.effective_math_mode() == "fast"
+    plan.set_math_mode("exact")
+    st.e_step(ld.dq_scale, None, sync=True)
+    assert plan.effective_math_mode() == "exact"
+    plan.set_math_mode("fast")
+    st.close()
+    for K, want in ((4, "fast"), (10, "exact")):
+        x = syn.make_mixture_inputs(ss, K)
+        pi0 = x.pop("pi")
+        sm = DeviceState(plan, "float32", "mixture", K)
+        sm.upload("std_beta", inp.std_beta)
+        for name, arr in x.items():
+            sm.upload(name, arr)
+        sm.reset(pi0)
+        sm.e_step(ld.dq_scale, None, sync=True)
+        assert plan.effective_math_mode() == want, (K, plan.effective_math_mode())
+        sm.close()
+    sd = DeviceState(plan, "float64", "spike_slab", 1)
+    for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+        sd.upload(name, getattr(inp, name).astype(np.float64))
+    sd.reset(inp.pi)
+    sd.e_step(ld.dq_scale, None, sync=True)
+    assert plan.effective_math_mode() == "exact"
+    sd.close()
+    plan.close()
+    # the model classes say it up front
+    from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
+    from viprs_amd.model import VIPRS
+    gdl = ArrayDataLoader({1: LDArrays(symmetric=(ld.ld_left_bound, ld.ld_indptr, ld.ld_data), dq_scale=ld.dq_scale)},
+                          {1: SumstatsArrays(ss.std_beta, ss.n_per_snp)}, n=float(ss.n))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        VIPRS(gdl, low_memory=False, math_mode="fast", float_precision="float64")
+    assert any("EXACT arithmetic" in str(x.message) for x in w)

@@ -104,6 +104,7 @@ _PROTOS = {
     "viprs_synthetic_ld_host": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64]),
     "viprs_plan_last_kernel_ms": (_i, [_vp, _i, ctypes.POINTER(_d)]),
     "viprs_plan_last_skipped": (_i, [_vp, _pi64]),
+    "viprs_plan_last_math_modes": (_i, [_vp, ctypes.POINTER(_i)]),
     "viprs_plan_timing_reset": (_i, [_vp]),
     "viprs_plan_timing_history": (_i, [_vp, _i, ctypes.POINTER(_d), _i, ctypes.POINTER(_i)]),
 }

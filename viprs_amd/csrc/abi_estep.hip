@@ -124,6 +124,7 @@ int run_spike_slab(viprs_state* S, double dq) {
     } else {
         HIP_TRY(clear_stale_skip_count(P));
     }
+    P->math_used = 0;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = dense_only;
     if (!dense_only) HIP_TRY(hipEventRecord(ev[0], P->stream));
@@ -200,6 +201,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
     int rc = panel_only ? VIPRS_OK : sweep_prologue(P, model == kGenGrid ? n_active : 1);
     if (rc != VIPRS_OK) return rc;
     if (panel_only) HIP_TRY(clear_stale_skip_count(P));
+    P->math_used = 0;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = true;      // [2] .. [3] bracket all kernels of the call
     HIP_TRY(hipEventRecord(ev[2], P->stream));
@@ -430,6 +432,12 @@ int viprs_plan_timing_history(viprs_plan* P, int which, double* ms, int capacity
         if (rc != VIPRS_OK) return rc;
     }
     *n = count;
+    return VIPRS_OK;
+}
+
+int viprs_plan_last_math_modes(const viprs_plan* P, int* mask) {
+    if (!P || !mask) return fail(VIPRS_EINVAL, "null argument");
+    *mask = P->math_used;
     return VIPRS_OK;
 }
 

@@ -85,6 +85,7 @@ struct viprs_plan {
     int device = 0;
     int n_cu = 0;
     int math_mode = VIPRS_MATH_EXACT;
+    int math_used = 0;                      // kernels of the last sweep: bit 0 = exact arithmetic ran, bit 1 = fast arithmetic ran
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;             // float64 state: the big-block class of estep_tile.h runs beside the rest
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

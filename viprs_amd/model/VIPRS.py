@@ -72,6 +72,11 @@ class VIPRS:
         self.order = order
         self.low_memory = low_memory
         self.math_mode = math_mode
+        if math_mode == "fast" and (self._T == np.float64 or getattr(self, "K", 1) > 8):
+            # (LDPlan.effective_math_mode() reports what a sweep really ran in)
+            import warnings
+            warnings.warn("math_mode='fast' has no kernels for " + ("float_precision='float64'" if self._T == np.float64 else
+                          f"mixtures of {self.K} components (> 8)") + ": this model runs in EXACT arithmetic", stacklevel=2)
         self._e_step_fn = e_step_fn
 
         # ---- inputs + LD: load, shard at LD-block granularity, then make device-resident ---------

@@ -206,6 +206,14 @@ class LDPlan:
         L.check(L.lib.viprs_plan_timing_history(self.handle, int(which), buf, capacity, ctypes.byref(n)))
         return [buf[i] for i in range(n.value)]
 
+    def effective_math_mode(self):
+        """'exact' / 'fast' / 'mixed': what the kernels of the last sweep really computed in (fast has no instantiation for
+        mixtures of 9+ components or float64 states: those run exact whatever `set_math_mode` was given); None before
+        the first sweep."""
+        mask = ctypes.c_int(0)
+        L.check(L.lib.viprs_plan_last_math_modes(self.handle, ctypes.byref(mask)))
+        return {0: None, 1: "exact", 2: "fast", 3: "mixed"}[mask.value & 3]
+
     def last_skipped(self):
         n = ctypes.c_int64(0)
         L.check(L.lib.viprs_plan_last_skipped(self.handle, ctypes.byref(n)))
