@@ -316,9 +316,24 @@ class Sweep:
             if model == "grid":
                 self.active = np.arange(width, dtype=np.int32)
 
+    # Dry runs of the multi-rank logic with several ranks on ONE device (VIPRS_BENCH_COMM=file): the sweep kernels size
+    # their grids to the whole device and their team workgroups wait for each other, so kernels of different processes
+    # must not share the device -- the ranks take turns through a file lock (set by main()).  Never on a real run.
+    device_lock = None
+
     def step(self):
-        self.state.reset(self.pi0)
-        self.state.e_step(self.ld.dq_scale, self.active, sync=False)
+        if Sweep.device_lock is None:
+            self.state.reset(self.pi0)
+            self.state.e_step(self.ld.dq_scale, self.active, sync=False)
+            return
+        import fcntl
+        with open(Sweep.device_lock, "w") as f:
+            fcntl.flock(f, fcntl.LOCK_EX)
+            try:
+                self.state.reset(self.pi0)
+                self.state.e_step(self.ld.dq_scale, self.active, sync=True)
+            finally:
+                fcntl.flock(f, fcntl.LOCK_UN)
 
     def run(self, steps, warmup, barrier):
         """W untimed steps, barrier, exactly K timed steps, device idle; returns this rank's seconds."""
@@ -628,9 +643,15 @@ def main():
         raise SystemExit(f"bench.py: --gpus {n_gpus} but only {ndev} HIP device(s) visible: one rank per GPU, refusing to "
                          "oversubscribe (VIPRS_BENCH_COMM=file runs the multi-rank logic on fewer devices, labelled as such)")
     device = local_rank % ndev
+    shared_device = dry and world > ndev
+    if shared_device:
+        Sweep.device_lock = os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                         f"viprs_bench_device{device}_{os.environ.get('MASTER_PORT', '0')}.lock")
     comm_kind = "rccl" if world > 1 else "none"
     if world > 1 and os.environ.get("VIPRS_BENCH_COMM") == "file":
-        comm_kind = "file transport (VIPRS_BENCH_COMM=file)"
+        comm_kind = "file transport (VIPRS_BENCH_COMM=file)" + (
+            f"; DRY RUN: {world} ranks on {ndev} device(s), sweeps of ranks sharing a device serialised by a file lock -- "
+            "times are not multi-GPU times" if shared_device else "")
         from viprs_amd.parallel import FileComm        # dry runs of the multi-rank logic on a box RCCL cannot span
         comm = FileComm(rank, world)
     elif world > 1:
