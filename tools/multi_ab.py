@@ -1,5 +1,5 @@
 """A/B/C... of several builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
-    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix [K=n]] [uniform] [fast]
+    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix [K=n]] [uniform] [fast] [sizes=a,b,..] [shard=N]
 (each library runs in its own subprocess, 3 rounds)"""
 import os, subprocess, sys
 sep = sys.argv.index('--') if '--' in sys.argv else len(sys.argv)
@@ -12,6 +12,11 @@ from viprs_amd.plan import DeviceState, LDPlan
 from viprs_amd.utils import synthetic as syn
 upper = "upper" in sys.argv; dt = np.int8 if "int8" in sys.argv else np.int16 if "int16" in sys.argv else np.float32
 sizes = np.full(1700, 650) if "uniform" in sys.argv else None      # uniform: 1700 blocks of 650 SNPs (no large-block tail)
+for a in sys.argv:
+    if a.startswith("sizes="): sizes = np.array([int(x) for x in a[6:].split(",")])      # sizes=6000: one isolated block
+    if a.startswith("shard="):                                                           # shard=8: rank 0's share of cfg3 sharded 8 ways
+        from viprs_amd.parallel import shard_blocks
+        all_sizes = syn.block_sizes("cfg3"); sizes = all_sizes[shard_blocks(all_sizes, int(a[6:])) == 0]
 ld, ss, inp = syn.make_problem("cfg3", low_memory=upper, ld_dtype=dt, sizes=sizes)
 model = "grid" if "grid" in sys.argv else "mixture" if "mix" in sys.argv else "spike_slab"
 width = {"grid": 32, "mixture": 4, "spike_slab": 1}[model]

@@ -97,9 +97,39 @@ __device__ __forceinline__ double div_v4(double num, double den) {      // f32 r
     return __builtin_fma(rem, r, q0);
 }
 
+// EARLY SEED (round 5): an approximate reciprocal of the denominator from the hardware units, computed from x itself while the
+// exact expf runs -- v_exp_f32 of x log2(e), 1 + e in float, v_rcp_f32: ~2^-21 relative.  The exact denominator then only
+// corrects it: no v_rcp_f64 (20 clocks) on the dependent path.
+__device__ __forceinline__ double early_seed(float x) {
+    const float ea = __builtin_amdgcn_exp2f(-fabsf(x) * 0x1.715476p+0f);
+    return (double)__builtin_amdgcn_rcpf(1.0f + ea);
+}
+__device__ __forceinline__ double div_seed_newton(double num, double den, double r) {    // seed, one Newton step, quotient, one correction
+    const double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q0 = num * r;
+    const double rem = __builtin_fma(-den, q0, num);
+    return __builtin_fma(rem, r, q0);
+}
+__device__ __forceinline__ double div_seed_two_corr(double num, double den, double r) {  // seed, quotient, two residual corrections
+    double q = num * r;
+    double rem = __builtin_fma(-den, q, num);
+    q = __builtin_fma(rem, r, q);
+    rem = __builtin_fma(-den, q, num);
+    return __builtin_fma(rem, r, q);
+}
+
 template <int V, int LOOKUP>
 __device__ __forceinline__ float sigmoid_var(float x, const ExpTab& tab, int sel = 0) {
     if (V == 0) return sigmoid_exact<LOOKUP>(x, tab, sel);
+    if (V == 7 || V == 8) {
+        const double r0 = early_seed(x);
+        const float e = expf_noselect<LOOKUP>(-fabsf(x), tab, sel);
+        const double ed = (double)e;
+        const double den = 1.0 + ed;
+        const double num = (x < 0.0f) ? ed : 1.0;
+        return (float)(V == 7 ? div_seed_newton(num, den, r0) : div_seed_two_corr(num, den, r0));
+    }
     const float e = (V == 6) ? expf_shift<LOOKUP>(-fabsf(x), tab, sel) : expf_noselect<LOOKUP>(-fabsf(x), tab, sel);
     const double ed = (double)e;
     const double den = 1.0 + ed;
@@ -113,7 +143,7 @@ __device__ __forceinline__ float sigmoid_var(float x, const ExpTab& tab, int sel
     return (float)q;
 }
 
-constexpr int kVariants = 7;
+constexpr int kVariants = 9;
 
 __global__ void check_all(unsigned long long* mism, unsigned* first_bad) {
     ExpTab tab;
@@ -137,7 +167,7 @@ __global__ void check_all(unsigned long long* mism, unsigned* first_bad) {
                 if (atomicAdd(&mism[V], 1ull) == 0) first_bad[V] = (unsigned)i;                    \
             }                                                                                      \
         }
-        CHK(1) CHK(2) CHK(3) CHK(4) CHK(5) CHK(6)
+        CHK(1) CHK(2) CHK(3) CHK(4) CHK(5) CHK(6) CHK(7) CHK(8)
 #undef CHK
     }
 }
@@ -171,7 +201,8 @@ int main() {
     hipMemcpy(hm, mism, sizeof(hm), hipMemcpyDeviceToHost); hipMemcpy(hb, first_bad, sizeof(hb), hipMemcpyDeviceToHost);
     const char* names[kVariants] = {"IEEE '/' vs shipped Newton divide", "no underflow select (clamp only), shipped divide",
                                     "+ one Newton step dropped", "+ rcp, two residual corrections", "+ rcp, one residual correction",
-                                    "+ f32 rcp seed, one Newton step", "one Newton step + glibc shift-trick k"};
+                                    "+ f32 rcp seed, one Newton step", "one Newton step + glibc shift-trick k",
+                                    "EARLY f32 seed (v_exp_f32, v_rcp_f32 of x) + Newton + corr", "EARLY f32 seed + two residual corrections"};
     for (int v = 0; v < kVariants; ++v)
         printf("variant %d  %-52s mismatches over all 2^32 inputs: %llu  (first bad bits 0x%08x)\n", v, names[v], hm[v], hb[v]);
 
@@ -185,6 +216,6 @@ int main() {
         unsigned long long w; hipMemcpy(&w, wall, 8, hipMemcpyDeviceToHost);                      \
         printf("variant %d: %.1f ns per dependent sigmoid (+1 fma), one wave per workgroup\n", V, w * 10.0 / iters / 16); \
     }
-    TIME(0) TIME(1) TIME(2) TIME(3) TIME(4) TIME(5) TIME(6)
+    TIME(0) TIME(1) TIME(2) TIME(3) TIME(4) TIME(5) TIME(6) TIME(7) TIME(8)
     return 0;
 }
