@@ -209,6 +209,72 @@ float oracle_expf_model(float x) {
     return (float)y;
 }
 
+/* Model of the host libm's DOUBLE exp for x <= 0 (glibc 2.35, sysdeps/ieee754/dbl-64/e_exp.c, the FMA ifunc variant; the
+ * operation sequence and the constants are in exp_glibc_f64_tab.h, generated from this host's libm by
+ * tools/extract_glibc_exp.py): what the device executes for a float64 state (viprs_amd/csrc/device_math.h).
+ * tests/test_oracle_vs_ref.py compares it with exp() here, bit for bit. */
+#include "exp_glibc_f64_tab.h"
+static const uint64_t kExp64Tab[256] = VIPRS_EXP64_TAB_INIT;
+static inline uint64_t d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+double oracle_exp_model(double x) {
+    const uint64_t ax = d2u(x) & 0x7fffffffffffffffull;
+    const unsigned abstop = (unsigned)(ax >> 52);
+    if (abstop - 0x3c9u > 0x3eu) {                       /* |x| < 2^-54, |x| >= 512, inf, nan */
+        if (abstop < 0x3c9u) return 1.0 + x;
+        if (abstop >= 0x409u) {                          /* |x| >= 1024 */
+            if (d2u(x) == 0xfff0000000000000ull) return 0.0;
+            if (abstop >= 0x7ffu) return 1.0 + x;        /* nan (+inf does not occur: x <= 0) */
+            return 0.0;                                   /* __math_uflow: x <= -1024 */
+        }
+    }
+    const double kds = fma(x, VIPRS_EXP64_INVLN2N, VIPRS_EXP64_SHIFT);
+    const uint64_t ki = d2u(kds);
+    const double kd = kds - VIPRS_EXP64_SHIFT;
+    double r = fma(kd, VIPRS_EXP64_NEGLN2HIN, x);
+    r = fma(kd, VIPRS_EXP64_NEGLN2LON, r);
+    const unsigned idx = 2u * (unsigned)(ki & 127u);
+    const double tail = u2d(kExp64Tab[idx]);
+    uint64_t sbits = kExp64Tab[idx + 1] + (ki << 45);
+    const double p23 = fma(r, VIPRS_EXP64_C3, VIPRS_EXP64_C2);
+    const double t0 = r + tail;
+    const double r2 = r * r;
+    const double p45 = fma(r, VIPRS_EXP64_C5, VIPRS_EXP64_C4);
+    double tmp = fma(p23, r2, t0);
+    tmp = fma(r2 * r2, p45, tmp);
+    if (abstop < 0x408u) {                               /* |x| < 512: the scale is a normal number */
+        const double scale = u2d(sbits);
+        return fma(scale, tmp, scale);
+    }
+    /* specialcase(), k < 0: x in (-1024, -512] -- the result may be subnormal */
+    sbits += 1022ull << 52;
+    const double scale = u2d(sbits);
+    const double st = scale * tmp;
+    double y = scale + st;
+    if (y < 1.0) {
+        double lo = scale - y + st;
+        const double hi = 1.0 + y;
+        lo = 1.0 - hi + y + lo;
+        y = (hi + lo) - 1.0;
+        if (y == 0.0) y = 0.0;                           /* no -0 */
+    }
+    return 0x1p-1022 * y;
+}
+/* bit mismatches against exp() over n doubles x_i = -(lo + i * step) and over their neighbours in the last place */
+int64_t oracle_exp_model_mismatches(double lo, double step, int64_t n) {
+    int64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double x0 = -(lo + (double)i * step);
+        for (int d = -1; d <= 1; ++d) {
+            const double x = u2d(d2u(x0) + (uint64_t)(int64_t)d);
+            const double a = exp(x), b = oracle_exp_model(x);
+            if (d2u(a) != d2u(b) && !(a != a && b != b)) ++bad;
+        }
+    }
+    return bad;
+}
+
 /* Sweep helper: counts bit mismatches of oracle_expf_model vs libm expf over the float bit
  * patterns [lo_bits, hi_bits] (inclusive) with the given stride. */
 int64_t oracle_expf_model_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {

@@ -206,3 +206,17 @@ def expf_model_mismatches(lo_bits, hi_bits, stride=1):
     lib.oracle_expf_model_mismatches.restype = ctypes.c_int64
     return lib.oracle_expf_model_mismatches(ctypes.c_uint32(lo_bits), ctypes.c_uint32(hi_bits),
                                             ctypes.c_uint32(stride))
+
+
+def exp_model(x):
+    """The model of the host libm's double exp, x <= 0 (estep_oracle.c: what the device executes for a float64 state)."""
+    lib = _lib("restated")
+    lib.oracle_exp_model.restype = ctypes.c_double
+    return lib.oracle_exp_model(ctypes.c_double(x))
+
+
+def exp_model_mismatches(lo, step, n):
+    """Bit mismatches of the model against exp() at x_i = -(lo + i step), i < n, and their two neighbours in the last place."""
+    lib = _lib("restated")
+    lib.oracle_exp_model_mismatches.restype = ctypes.c_int64
+    return lib.oracle_exp_model_mismatches(ctypes.c_double(lo), ctypes.c_double(step), ctypes.c_int64(n))

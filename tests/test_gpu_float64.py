@@ -1,9 +1,12 @@
-"""GPU: float64 state (float_precision='float64', VIPRS.py:72) -- the panel-walking kernels of estep_tile.h against
-the oracle run in double.  A float64 state is NOT a bit-for-bit contract (the device's double exp is ocml's, the
-reference's is glibc's; the second pass of the upper form sums in lane order).  The tolerance, 1e-10 relative (with the
-floor described at `assert_state_close_f64`), is THIS REPOSITORY'S CHOICE: BASELINE.json's north_star states a tolerance for
-fp32 only (1e-5 relative); 1e-10 is ~5 decimal orders above double rounding (what the two `exp` implementations and the
-summation order can differ by after a few sweeps) and 5 below the fp32 contract."""
+"""GPU: float64 state (float_precision='float64', VIPRS.py:72) -- the panel-walking kernels of estep_tile.h (and the row-by-row
+kernels of estep_generic.h) against the oracle run in double.
+
+SYMMETRIC LD form (`low_memory=False`): BIT-IDENTICAL (`==` on all five state arrays, round 5) -- the device evaluates
+glibc's own double exp (device_math.h: exp_glibc_f64_*, constants read from the host's libm; the model is pinned against
+exp() on the CPU, tests/test_oracle_vs_ref.py) and IEEE divides, every fma where the reference has one.
+UPPER-TRIANGULAR form: the float64 second pass (update_q_factor, e_step.hpp:331-337) sums a row's products in lane order,
+not in column order, so q differs from the reference in the last bits: compared at 1e-10 relative (with the floor described
+at `assert_state_close_f64`) -- THIS REPOSITORY'S CHOICE: BASELINE.json's north_star states a tolerance for fp32 only."""
 import numpy as np
 import pytest
 
@@ -27,6 +30,14 @@ def assert_state_close_f64(got, ref, rtol=RTOL_F64):
         assert_close_f64(got[k], ref[k], k, rtol)
 
 
+def check_state_f64(got, ref, low_memory):
+    """`==` for the symmetric form, 1e-10 for the upper-triangular one (module docstring)."""
+    if low_memory:
+        assert_state_close_f64(got, ref)
+    else:
+        H.assert_state_equal(got, ref)
+
+
 def assert_close_f64(got, ref, what, rtol=RTOL_F64):
     scale = float(np.max(np.abs(ref)))
     tol = rtol * np.maximum(np.abs(ref), 1e-4 * scale)
@@ -45,7 +56,7 @@ def test_float64_spike_slab_matches_oracle_on_far_field_ld(gpu, low_memory, ld_d
     ref = H.run_oracle(ld, inp, st0, sweeps=3)
     got = H.run_hip(ld, inp, st0, sweeps=3)
     assert got["q"].dtype == np.float64
-    assert_state_close_f64(got, ref)
+    check_state_f64(got, ref, low_memory)
     cut = H.run_oracle(H.cut_far_field(ld), inp, st0, sweeps=3)
     assert np.max(np.abs(cut["q"] - ref["q"])) > 1e-4 * np.max(np.abs(ref["q"]))
 
@@ -58,7 +69,7 @@ def test_float64_tile_kernel_equals_row_by_row_kernel(gpu, low_memory, monkeypat
     tile = H.run_hip(ld, inp, st0, sweeps=2)
     monkeypatch.setenv("VIPRS_F64_ROW_BY_ROW", "1")
     rows = H.run_hip(ld, inp, st0, sweeps=2)
-    assert_state_close_f64(tile, rows)
+    check_state_f64(tile, rows, low_memory)
 
 
 @pytest.mark.parametrize("ld_dtype", [np.float32, np.int8])
@@ -74,7 +85,7 @@ def test_float64_windowed_components(gpu, m, wl, wr, jitter, low_memory, ld_dtyp
     st0 = inp.state_copy()
     ref = H.run_oracle(ld, inp, st0, sweeps=2)
     got = H.run_hip(ld, inp, st0, sweeps=2)
-    assert_state_close_f64(got, ref)
+    check_state_f64(got, ref, low_memory)
 
 
 @pytest.mark.parametrize("low_memory", [False, True])
@@ -92,7 +103,7 @@ def test_float64_grid_matches_oracle(gpu, low_memory):
                                 st["eta"], st["q"], st["eta_diff"], g["u_logs"], g["hvt"], g["mu_mult"], ld.dq_scale,
                                 active, 1, low_memory)
         out[name] = st
-    assert_state_close_f64(out["hip"], out["ref"])
+    check_state_f64(out["hip"], out["ref"], low_memory)
     untouched = [c for c in range(12) if c not in active]
     assert np.all(out["hip"]["eta"][:, untouched] == 0)
 
@@ -107,16 +118,14 @@ def test_float64_skip_branch_counts(gpu):
     skipped = ref["eta_diff"] == 0
     assert 0.3 < np.mean(skipped) < 0.9                    # both branches are exercised
     assert np.array_equal(got["eta_diff"] == 0, skipped)
-    for k in ("eta", "q", "var_gamma", "var_mu"):
-        assert_close_f64(got[k], ref[k], k)
-    # eta_diff = gamma * mu - eta cancels to ~1e-8 here: absolute tolerance (a few ulp of eta)
-    np.testing.assert_allclose(got["eta_diff"], ref["eta_diff"], rtol=0, atol=1e-15)
+    H.assert_state_equal(got, ref)
 
 
-def test_float64_chain_sigmoid_against_an_80_bit_reference(gpu):
-    """The chain's own exp / divide (estep_tile.h: 64-entry table, degree-6 polynomial, v_rcp_f64 + one Newton step +
-    residual correction): 1-SNP blocks with mu_mult = std_beta = 1, sqrt_half_var_tau = 0 make var_gamma =
-    sigmoid(u_logs) and eta_diff = var_gamma -- compared with numpy's long double over the whole argument range."""
+def test_float64_chain_sigmoid_equals_the_host_and_an_80_bit_reference(gpu):
+    """The chain's own exp / divide (estep_tile.h: glibc's double exp with the table across the lanes, IEEE divide): 1-SNP
+    blocks with mu_mult = std_beta = 1, sqrt_half_var_tau = 0 make var_gamma = sigmoid(u_logs) and eta_diff = var_gamma --
+    `==` the oracle (the host's exp and `/`) over the whole argument range, subnormal results of exp (x < -708) and the
+    special ranges included, and within 1 ulp of numpy's long double."""
     if np.finfo(np.longdouble).eps > 1e-18:
         pytest.skip("no extended-precision long double on this host")
     rng = np.random.default_rng(9)
@@ -131,6 +140,7 @@ def test_float64_chain_sigmoid_against_an_80_bit_reference(gpu):
     inp.sqrt_half_var_tau[:] = 0.0
     inp.u_logs[:] = x
     got = H.run_hip(ld, inp, inp.state_copy(), sweeps=1)
+    H.assert_state_equal(got, H.run_oracle(ld, inp, inp.state_copy(), sweeps=1))
     xl = x.astype(np.longdouble)
     e = np.exp(-np.abs(xl))
     ref = np.where(xl < 0, e, np.longdouble(1)) / (1 + e)
@@ -138,7 +148,7 @@ def test_float64_chain_sigmoid_against_an_80_bit_reference(gpu):
     assert np.array_equal(applied, np.abs(ref.astype(T)) >= 1e-8)          # the skip branch (|eta_diff| < 1e-8)
     g = got["var_gamma"][applied].astype(np.longdouble)
     err = np.abs(g - ref[applied]) / ref[applied]
-    assert float(err.max()) < 4 * np.finfo(T).eps, float(err.max())
+    assert float(err.max()) < 2 * np.finfo(T).eps, float(err.max())       # exp: < 1 ulp, the divide: 0.5 ulp
     np.testing.assert_array_equal(got["eta_diff"][applied], got["var_gamma"][applied])
     assert np.all(got["var_mu"][applied] == 1.0) and np.all(got["q"] == 0)
 
@@ -179,7 +189,7 @@ def test_float64_cfg3_full_size(gpu, low_memory):
             O.cpp_e_step(sub.ld_left_bound, sub.ld_indptr, sub.ld_data, inp.std_beta[s:e].copy(), st["var_gamma"],
                          st["var_mu"], st["eta"], st["q"], st["eta_diff"], inp.u_logs[s:e].copy(),
                          inp.sqrt_half_var_tau[s:e].copy(), inp.mu_mult[s:e].copy(), ld.dq_scale, 1, low_memory)
-        assert_state_close_f64({k: got[k][s:e] for k in H.STATE}, st)
+        check_state_f64({k: got[k][s:e] for k in H.STATE}, st, low_memory)
     state.close()
     plan.close()
 
@@ -198,7 +208,10 @@ def test_float64_mixture_matches_oracle(gpu, K, low_memory):
     got = _run_mix(S, ld, inp, mix, st0, 2)
     assert got["var_gamma"].dtype == np.float64 and got["var_gamma"].shape == (ld.m, K)
     for k in H.STATE:
-        assert_close_f64(got[k], ref[k], k)
+        if low_memory:
+            assert_close_f64(got[k], ref[k], k)
+        else:
+            assert np.array_equal(got[k], ref[k]), f"{k}: {int((got[k] != ref[k]).sum())} entries differ"
     cut = _run_mix(O, H.cut_far_field(ld), inp, mix, st0, 2)
     assert np.max(np.abs(cut["q"] - ref["q"])) > 1e-4 * np.max(np.abs(ref["q"]))
 
@@ -211,4 +224,4 @@ def test_float64_block_classes(gpu, sizes, low_memory):
     class empty it is a single launch."""
     ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=low_memory, ld_dtype=np.int8, seed=44, kind="longrange", float_precision=T)
     st0 = inp.state_copy()
-    assert_state_close_f64(H.run_hip(ld, inp, st0, sweeps=3), H.run_oracle(ld, inp, st0, sweeps=3))
+    check_state_f64(H.run_hip(ld, inp, st0, sweeps=3), H.run_oracle(ld, inp, st0, sweeps=3), low_memory)

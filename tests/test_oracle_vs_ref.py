@@ -166,3 +166,30 @@ def test_expf_model_matches_host_libm_on_a_sweep():
     x = float.fromhex("-0x1.f8cbb2p+5")
     xb = struct.unpack("<I", struct.pack("<f", x))[0]
     assert O.expf_model_mismatches(xb, xb, 1) == 0
+
+
+def test_exp_model_matches_host_libm():
+    """The model of glibc's DOUBLE exp the device executes for a float64 state (viprs_amd/csrc/device_math.h:
+    exp_glibc_f64_*, mirrored in oracle/estep_oracle.c; constants read from this host's libm by tools/extract_glibc_exp.py)
+    against this host's exp(): dense and coarse sweeps of x <= 0 with both neighbours in the last place of every point --
+    the normal range, the subnormal results of x in (-745.2, -708.4), the special path (-1024, -512], |x| < 2^-54, and
+    beyond -1024."""
+    assert O.exp_model_mismatches(0.0, 1.000001 / (1 << 16), 3_000_000) == 0           # [0, 45.8) dense
+    assert O.exp_model_mismatches(1e-3, 760.0 / 2_000_000, 2_000_000) == 0            # [0, 760) coarse
+    assert O.exp_model_mismatches(511.9, 0.0003, 2_000_000) == 0                      # the special-case path
+    assert O.exp_model_mismatches(0.0, 2.0 ** -60, 100_000) == 0 and O.exp_model_mismatches(2.0 ** -54 - 2.0 ** -70, 2.0 ** -80, 100_000) == 0
+    assert O.exp_model_mismatches(1023.9, 0.001, 1000) == 0
+    import math
+    for x in (0.0, -0.0, float("-inf"), -745.13321910194122, -745.2, -708.3964185322641, -1e308, -512.0, -1024.0):
+        assert struct.pack("<d", math.exp(x)) == struct.pack("<d", O.exp_model(x)), x
+    assert math.isnan(O.exp_model(float("nan")))
+
+
+def test_generated_exp_tables_are_in_sync():
+    """oracle/exp_glibc_f64_tab.h (the checker's copy) and viprs_amd/csrc/exp_glibc_f64_tab.h (the device's) are the same
+    generated file (tools/extract_glibc_exp.py)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = open(os.path.join(root, "oracle", "exp_glibc_f64_tab.h")).read()
+    b = open(os.path.join(root, "viprs_amd", "csrc", "exp_glibc_f64_tab.h")).read()
+    assert a == b and "VIPRS_EXP64_TAB_INIT" in a

@@ -34,6 +34,7 @@ EStepArgs<T> make_args(viprs_state* S, double dq) {
     A.rowlen = P->d_rowlen.p;
     A.ld_rows = P->d_ld_raw.p;
     A.ld_dense = P->d_ld_dense.p;
+    A.ld_zero_off = P->dense_elems;          // (abi_plan.hip: zeroed slack of >= 4 * kStrip elements behind the last block)
     A.std_beta = (const T*)S->f[VIPRS_FIELD_STD_BETA].p;
     A.u_logs = (const T*)S->f[VIPRS_FIELD_U_LOGS].p;
     A.shvt = (const T*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "exp_glibc_f64_tab.h"
+
 namespace viprs {
 
 // ---------------------------------------------------------------------------------------------
@@ -145,9 +147,98 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
     return num * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-// double state (float_precision='float64'): ocml exp (<= 1 ulp, not bit-identical to glibc exp).
+// ---------------------------------------------------------------------------------------------
+// double state (float_precision='float64'): exp for x <= 0, bit-identical to the host libm's (glibc 2.35,
+// sysdeps/ieee754/dbl-64/e_exp.c, the FMA ifunc variant): exp(x) = 2^(k/128) exp(r) with 2^(k/128) = scale (1 + tail) from
+// a 2 x 128-entry table and a degree-5 polynomial.  The operation sequence (which products are fused is part of the
+// contract) and the constants -- read from the library itself by tools/extract_glibc_exp.py -- are in
+// exp_glibc_f64_tab.h; oracle/estep_oracle.c holds the same model and tests/test_oracle_vs_ref.py compares it with the
+// host's exp() over 27 million arguments, subnormal results included (0 mismatches).
+//   exp_glibc_f64_core  : everything after the table lookup (shared by the per-lane and the wave-uniform lookups)
+//   exp_glibc_f64_nonpos: per-lane arguments, table in constant memory (row-by-row kernels of estep_generic.h)
+// (estep_tile.h holds the wave-uniform flavour of the chain: table across the lanes, two v_readlane per word)
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ const uint64_t kExp64Tab[256] = VIPRS_EXP64_TAB_INIT;
+
+struct Exp64Reduced { double r; long long ki; unsigned abstop; };
+__device__ __forceinline__ Exp64Reduced exp_glibc_f64_reduce(double x) {
+    Exp64Reduced o;
+    o.abstop = (unsigned)((unsigned long long)(__double_as_longlong(x) & 0x7fffffffffffffffll) >> 52);
+    const double kds = __builtin_fma(x, VIPRS_EXP64_INVLN2N, VIPRS_EXP64_SHIFT);
+    o.ki = __double_as_longlong(kds);
+    const double kd = kds - VIPRS_EXP64_SHIFT;
+    double r = __builtin_fma(kd, VIPRS_EXP64_NEGLN2HIN, x);
+    o.r = __builtin_fma(kd, VIPRS_EXP64_NEGLN2LON, r);
+    return o;
+}
+// `tail`, `sbits0` = T[2 (ki % 128)], T[2 (ki % 128) + 1].  The common range 2^-54 <= |x| < 512 runs straight through;
+// everything else (UNIFORM = the argument is wave-uniform: one scalar branch; otherwise selects) is patched afterwards.
+template <bool UNIFORM>
+__device__ __forceinline__ double exp_glibc_f64_core(double x, const Exp64Reduced& q, double tail, unsigned long long sbits0) {
+    const double r = q.r;
+    const unsigned long long sbits = sbits0 + ((unsigned long long)q.ki << 45);
+    const double p23 = __builtin_fma(r, VIPRS_EXP64_C3, VIPRS_EXP64_C2);
+    const double t0 = r + tail;
+    const double r2 = r * r;
+    const double p45 = __builtin_fma(r, VIPRS_EXP64_C5, VIPRS_EXP64_C4);
+    double tmp = __builtin_fma(p23, r2, t0);
+    tmp = __builtin_fma(r2 * r2, p45, tmp);
+    const double scale = __longlong_as_double((long long)sbits);
+    double y = __builtin_fma(scale, tmp, scale);          // |x| in [2^-54, 512): the scale is a normal number
+    auto special = [&]() {
+        double z;
+        if (q.abstop < 0x3c9u) {
+            z = 1.0 + x;                                  // |x| < 2^-54
+        } else if (q.abstop >= 0x409u) {
+            z = (x != x) ? 1.0 + x : 0.0;                 // nan; x = -inf, x <= -1024 (underflow)
+        } else {
+            // specialcase(), k < 0: x in (-1024, -512], subnormal results
+            const double sc = __longlong_as_double((long long)(sbits + (1022ull << 52)));
+            const double st = sc * tmp;
+            z = sc + st;
+            if (z < 1.0) {
+                double lo = sc - z + st;
+                const double hi = 1.0 + z;
+                lo = 1.0 - hi + z + lo;
+                z = (hi + lo) - 1.0;
+                if (z == 0.0) z = 0.0;
+            }
+            z = 0x1p-1022 * z;
+        }
+        return z;
+    };
+    const bool rare = q.abstop - 0x3c9u > 0x3eu;          // |x| < 2^-54 or |x| >= 512 (inf, nan)
+    if (UNIFORM) {
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)rare) != 0, 0)) y = special();
+    } else if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+        const double z = special();
+        y = rare ? z : y;
+    }
+    return y;
+}
+// num / den for den in [1, 2], 0 <= num <= 1 as an IEEE divide: the reciprocal refined to the last place by two Newton
+// steps, the quotient, its exact remainder and ONE correction whose rounding is the quotient's (Markstein) -- the sequence
+// the compiler emits for `/`, without v_div_scale / v_div_fmas / v_div_fixup: those only rescale operands near the
+// exponent limits and patch inf / nan / 0, none of which occurs here.  tools/ubench/div_f64_check.hip compares it with `/` on
+// 2^32 (num, 1 + e) pairs over every binade of e, subnormals included (0 mismatches); tests/test_gpu_float64.py holds the `==`
+// tests against the host.
+__device__ __forceinline__ double div_unit_range_f64(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    const double q0 = num * r;
+    const double rem = __builtin_fma(-den, q0, num);
+    return __builtin_fma(rem, r, q0);
+}
+__device__ __forceinline__ double exp_glibc_f64_nonpos(double x) {
+    const Exp64Reduced q = exp_glibc_f64_reduce(x);
+    const unsigned idx = 2u * ((unsigned)q.ki & 127u);
+    return exp_glibc_f64_core<false>(x, q, __longlong_as_double((long long)kExp64Tab[idx]), kExp64Tab[idx + 1]);
+}
+
+// sigmoid<double> (e_step.hpp:245-261): glibc's exp, IEEE add and divide -- bit-identical to the reference on the host.
 __device__ __forceinline__ double sigmoid_f64(double x) {
-    const double e = exp(-fabs(x));
+    const double e = exp_glibc_f64_nonpos(-fabs(x));
     const double num = (x < 0.0) ? e : 1.0;
     return num / (1.0 + e);
 }

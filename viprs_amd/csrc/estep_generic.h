@@ -113,7 +113,7 @@ template <typename T> __device__ __forceinline__ T exp_nonpos(T x, const ExpTab&
 template <> __device__ __forceinline__ float exp_nonpos<float>(float x, const ExpTab& tab) {
     return expf_glibc_nonpos<kLookupPerLane>(x, tab);
 }
-template <> __device__ __forceinline__ double exp_nonpos<double>(double x, const ExpTab&) { return exp(x); }
+template <> __device__ __forceinline__ double exp_nonpos<double>(double x, const ExpTab&) { return exp_glibc_f64_nonpos(x); }
 
 template <typename T, typename U, bool IN_LDS>
 __global__ __launch_bounds__(kGenericThreads) void estep_mixture_generic_kernel(EStepArgs<T> A) {

@@ -280,6 +280,26 @@ template <typename U> struct HalfTileRows {
             v[i] = load_raw<U, C>(col0 + (int64_t)row * stride + (lane % N) * C);
         }
     }
+    // The half tile ON THE DIAGONAL (column half `half` of tile R[pp, pp]): a 16-byte piece whose columns all lie on or
+    // left of the diagonal holds stored zeros -- those lanes read the plan's 16 zero bytes (`zero`, one hot cache line)
+    // instead: the zero half of every diagonal tile is never fetched from HBM.
+    __device__ __forceinline__ void load_co_diag(const U* __restrict__ col0, int64_t stride, int row0, int b, int lane, int half,
+                                                 const U* __restrict__ zero) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int rloc = i * kRowsPerLoad + lane / N;
+            const int row = min(row0 + rloc, b - 1);
+            const bool needed = half * (kPanel / 2) + (lane % N) * C + C - 1 > rloc;
+            v[i] = load_raw<U, C>(needed ? col0 + (int64_t)row * stride + (lane % N) * C : zero);
+        }
+    }
+    __device__ __forceinline__ void load_diag(const U* __restrict__ rowp, int lane, int half, const U* __restrict__ zero) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const bool needed = half * (kPanel / 2) + C * i + C - 1 > lane;
+            v[i] = load_raw<U, C>(needed ? rowp + C * i : zero);
+        }
+    }
     __device__ __forceinline__ void to_rows(char* __restrict__ buf, int lane) {
         static_assert(N == 2 || N == 4 || N == 8, "pieces per row");
         RawRow<U, C> out[N];
@@ -614,6 +634,14 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
+    // Upper-triangular form, integer LD: the pieces of a DIAGONAL tile that lie on or left of the diagonal hold stored zeros;
+    // the lanes that would load them read the plan's 16 zero bytes instead (one hot cache line), so the zero half of every
+    // diagonal tile is not fetched from HBM -- in the chain's tile staging and in the second pass.  int8 upper, cfg3:
+    // 0.517 -> 0.507 ms (builds alternating on one box).  NOT for fp32 LD: there the updater waves are bound by their
+    // instruction stream, not by bytes, and the address selects cost more than the bytes save (0.79 -> 0.87 ms; K = 4
+    // mixture 1.09 -> 1.33) -- measured, EXPERIMENTS.md round 5.
+    constexpr bool kSkipDiagZeros = !SYM && sizeof(U) < 4;
+    const U* __restrict__ zero16 = ldd + A0.ld_zero_off;
     ExpTab tab;
     tab.init();
     unsigned long long my_skipped = 0;
@@ -693,7 +721,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             // only ever meet a = 0)
             for (int i = tid; i < kPanel * kPanel / 4; i += NW * 64) {
                 const int row = i >> 4, tcol = (i & 15) * 4;
-                *reinterpret_cast<float4*>(lT + row * kPanel + tcol) = load4<U>(base + (int64_t)min(row, b - 1) * stride + tcol);
+                // (upper-triangular form: 4 columns on or left of the diagonal are stored zeros -- not fetched)
+                const bool needed = !kSkipDiagZeros || tcol + 3 > row;
+                *reinterpret_cast<float4*>(lT + row * kPanel + tcol) =
+                    load4<U>(needed ? base + (int64_t)min(row, b - 1) * stride + tcol : zero16);
             }
         }
         __syncthreads();
@@ -1168,7 +1199,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) {
                         const int row = 4 * min(uw + g * (NW - 1), kPanel / 4 - 1) + trow;
-                        v[g] = load4<U>(base + (int64_t)min(row_base + row, b - 1) * stride + (p + 1) * kPanel + tcol);
+                        // (upper-triangular form, diagonal tile: pieces on or left of the diagonal are stored zeros -- not fetched)
+                        const bool needed = !kSkipDiagZeros || !kStageDiag || tcol + 3 > row;
+                        v[g] = load4<U>(needed ? base + (int64_t)min(row_base + row, b - 1) * stride + (p + 1) * kPanel + tcol : zero16);
                     }
                     float4 w[kTileInLds ? kGroups : 1];
                     if (kTileInLds) {
@@ -1271,8 +1304,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                 // coalesced loads + transposition through the wave's LDS buffer; the K <= 8 mixture (whose
                                 // chain scratch takes that LDS) loads lane-per-row
                                 auto fetch = [&](HalfTileRows<U>& h, int rr) {
-                                    if constexpr (kSecondPassViaLds) h.load_co(col0, stride, rr * kPanel, b, lane);
-                                    else h.load(col0 + (int64_t)min(rr * kPanel + lane, b - 1) * stride);
+                                    if (kSkipDiagZeros && rr == pp) {          // the tile on the diagonal: its zero pieces are not fetched
+                                        if constexpr (kSecondPassViaLds) h.load_co_diag(col0, stride, rr * kPanel, b, lane, H, zero16);
+                                        else h.load_diag(col0 + (int64_t)min(rr * kPanel + lane, b - 1) * stride, lane, H, zero16);
+                                    } else {
+                                        if constexpr (kSecondPassViaLds) h.load_co(col0, stride, rr * kPanel, b, lane);
+                                        else h.load(col0 + (int64_t)min(rr * kPanel + lane, b - 1) * stride);
+                                    }
                                 };
                                 int r = r_first;
                                 if (r <= pp) fetch(h0, r);

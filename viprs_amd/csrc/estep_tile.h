@@ -35,52 +35,37 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The chain's sigmoid.  A float64 operation costs a wave ~20 clocks of dependent latency on gfx950, so the serial step
-// is priced in dependent operations: ocml's exp (no table, degree-11 polynomial, ldexp) and the IEEE divide sequence
-// make it 42; the versions below 27.
-//   exp(t), t <= 0: k = rint(t * 64/ln2), r = t - k ln2/64 (two-term Cody-Waite, |r| <= ln2/128), 2^(k/64) from a
-//   64-entry table held across the lanes (lane l: 2^(l/64); the argument is wave-uniform on the chain, so the lookup is
-//   two v_readlane), exp(r) - 1 by a degree-6 polynomial in Estrin form, the power of two added into the exponent
-//   field.  Error < 2 ulp (table entry 0.5 + polynomial 0.1 + roundings); arguments below -708 give 0.
-//   num / den, den in [1, 2]: v_rcp_f64, one Newton step, quotient and one residual correction.
-// Neither is bit-identical to glibc's exp / an IEEE divide -- nor is ocml's exp: the float64 state is compared to the
-// reference within 1e-10 (see the header); tests/test_gpu_float64.py checks the sigmoid against an 80-bit reference.
+// The chain's sigmoid: BIT-IDENTICAL to the reference's on the host (round 5) -- glibc's double exp (device_math.h:
+// exp_glibc_f64_*, the library's own constants) and an IEEE divide.  The chain evaluates wave-uniform scalars (every lane
+// the same numbers from the step's SNP), so the lookup in the table of 2^(k/128) = scale (1 + tail) is ONE broadcast
+// 16-byte LDS read per exp (the table, 2 KB, is copied to LDS when the kernel starts); the special ranges (|x| < 2^-54,
+// x <= -512: subnormal results, 0, nan) are one uniform branch behind the common path.
+// (Rounds 2-4 ran a shorter chain here -- a 64-entry table, a degree-6 polynomial, v_rcp_f64 + Newton + correction:
+//  < 2 ulp from the reference, compared at 1e-10.)
 // ---------------------------------------------------------------------------------------------------------------
 struct ExpTab64 {
-    double t;                                                // lane l: 2^((l & 63) / 64)
-    __device__ __forceinline__ void init() { t = exp2((double)(threadIdx.x & 63) * 0.015625); }
+    const unsigned long long* t;                             // the 2 x 128-entry table in LDS (2 KB)
+    // every thread of the workgroup takes part (the workgroups have 256 or 512 threads)
+    __device__ __forceinline__ void init(unsigned long long* lds) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = kExp64Tab[i];
+        __syncthreads();
+        t = lds;
+    }
 };
 
 __device__ __forceinline__ double exp_nonpos_f64_uniform(double t, const ExpTab64& tab) {
-    const double InvLn2N = 0x1.71547652b82fep+6;             // 64 / ln2
-    const double NegLn2hiN = -0x1.62e42fefa0000p-7;          // -ln2/64, high part (kd * hi is exact for |kd| < 2^17)
-    const double NegLn2loN = -0x1.cf79abc9e3b3ap-46;
-    const double kd = rint(t * InvLn2N);
-    double r = __builtin_fma(kd, NegLn2hiN, t);
-    r = __builtin_fma(kd, NegLn2loN, r);
-    // 2^(k/64): table entry of k mod 64, k div 64 added to its exponent (t >= -708: the result stays normal)
-    const int k = __builtin_amdgcn_readfirstlane((int)kd);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(tab.t), k & 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(tab.t), k & 63) + ((k >> 6) << 20);
-    const double scale = __hiloint2double(hi, lo);
-    const double r2 = r * r;
-    const double A = __builtin_fma(r, 0x1.5555555555555p-3, 0.5);                       // 1/2 + r/6
-    double B = __builtin_fma(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);            // 1/24 + r/120
-    const double r4 = r2 * r2;
-    B = __builtin_fma(r2, 0x1.6c16c16c16c17p-10, B);                                    // + r^2/720
-    const double p = __builtin_fma(r4, B, __builtin_fma(r2, A, r));                     // exp(r) - 1
-    const double e = __builtin_fma(scale, p, scale);
-    return t < -708.0 ? 0.0 : e;
+    const Exp64Reduced q = exp_glibc_f64_reduce(t);
+    // wave-uniform k: ONE 16-byte LDS read (a broadcast) brings tail and scale of entry k % 128; it is issued as soon as
+    // kd is known and lands while r and the polynomial's first terms are computed
+    const int k = __builtin_amdgcn_readfirstlane((int)(unsigned)q.ki);
+    const ulonglong2 e = *reinterpret_cast<const ulonglong2*>(tab.t + 2 * (k & 127));
+    return exp_glibc_f64_core<true>(t, q, __longlong_as_double((long long)e.x), e.y);
 }
 
 __device__ __forceinline__ double sigmoid_f64_uniform(double x, const ExpTab64& tab) {
     const double e = exp_nonpos_f64_uniform(-fabs(x), tab);
     const double num = (x < 0.0) ? e : 1.0;
-    const double den = 1.0 + e;
-    double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-    const double q0 = num * r;
-    return __builtin_fma(__builtin_fma(-den, q0, num), r, q0);
+    return div_unit_range_f64(num, 1.0 + e);                  // e_step.hpp:254-260: IEEE add and divide (device_math.h)
 }
 
 // spike-and-slab (e_step.hpp:401-413) / one model of the grid (e_step.hpp:613-620: no skip branch, half_var_tau, no fma)
@@ -173,8 +158,9 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
     __shared__ int s_cmin[2], s_cmax[2];                                   // union of the panel's row windows
     __shared__ unsigned long long s_applied[2];                            // rows of the panel that were not skipped
 
+    __shared__ __attribute__((aligned(16))) unsigned long long s_exp64[256];   // glibc's exp table (device_math.h)
     ExpTab64 tab;
-    tab.init();
+    tab.init(s_exp64);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;

@@ -204,6 +204,7 @@ struct EStepArgs {
     const void* ld_rows;
     // repacked dense blocks (panel kernels)
     const void* ld_dense;
+    int64_t ld_zero_off;  // element offset (from ld_dense) of >= 64 zero elements, 16-byte aligned: the slack behind the last block
     // per-SNP vectors
     const T* std_beta;
     const T* u_logs;
