@@ -694,8 +694,8 @@ def main():
     t_start = time.perf_counter()
     strong = world > 1 and args.scaling == "strong"
     # LD entries: on the device for every rank of a multi-GPU run; the N = 1 headline workload on the host (the CPU
-    # baseline and the fit() secondaries run on the host arrays)
-    on_host = world == 1
+    # baseline and the fit() secondaries run on the host arrays) unless neither is asked for (profiling runs)
+    on_host = world == 1 and (args.cpu_seconds > 0 or not args.no_secondary or args.host_ld)
     if strong:
         parts = shard_blocks_lpt(sizes_all, world)
         mine = parts[rank]

@@ -634,12 +634,13 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
-    // Upper-triangular form, integer LD: the pieces of a DIAGONAL tile that lie on or left of the diagonal hold stored zeros;
-    // the lanes that would load them read the plan's 16 zero bytes instead (one hot cache line), so the zero half of every
-    // diagonal tile is not fetched from HBM -- in the chain's tile staging and in the second pass.  int8 upper, cfg3:
-    // 0.517 -> 0.507 ms (builds alternating on one box).  NOT for fp32 LD: there the updater waves are bound by their
-    // instruction stream, not by bytes, and the address selects cost more than the bytes save (0.79 -> 0.87 ms; K = 4
-    // mixture 1.09 -> 1.33) -- measured, EXPERIMENTS.md round 5.
+    // Upper-triangular form, integer LD: the 16-byte pieces of a DIAGONAL tile that lie on or left of the diagonal hold stored
+    // zeros; the lanes that would request them read the plan's 16 zero bytes instead (one hot cache line) -- in the chain's
+    // tile staging and in the second pass.  int8 upper, cfg3: 0.517 -> 0.507 ms (builds alternating on one box).  What it
+    // saves are REQUESTS through the vector-memory path, not HBM bytes: an int8 tile row is 64 bytes, half a cache line, and
+    // the line is fetched for its non-zero part anyway (PMC traffic 1.873 -> 1.868 GB).  NOT for fp32 LD: there the updater
+    // waves are bound by their instruction stream and the address selects cost more than the requests save (0.79 -> 0.87 ms;
+    // K = 4 mixture 1.09 -> 1.33) -- measured, EXPERIMENTS.md round 5.
     constexpr bool kSkipDiagZeros = !SYM && sizeof(U) < 4;
     const U* __restrict__ zero16 = ldd + A0.ld_zero_off;
     ExpTab tab;
