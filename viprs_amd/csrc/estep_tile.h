@@ -18,6 +18,7 @@
 #pragma once
 #include "device_math.h"
 #include "estep_generic.h"
+#include "estep_panel.h"        // HalfTileRows: coalesced half-tile loads handed to lane-per-row chains through LDS
 #include "kernels_common.h"
 
 namespace viprs {
@@ -629,6 +630,113 @@ __global__ __launch_bounds__(kTileThreads, 3) void tile_f64_second_pass_kernel(E
         g = g_n;
         g_n = g_nn;
         bd = bd_n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The second pass in the REFERENCE'S ORDER (round 5; math_mode = exact): dot() of e_step.hpp:82-104 is a serial fma chain
+// over a row's columns in index order, so here a LANE owns a ROW and walks its columns in ascending order -- q of the
+// upper-triangular form then equals the reference's bit for bit (the kernels above and below sum per lane and across
+// lanes: 1e-10, kept for math_mode = fast).  One wave per group of 64 consecutive rows (the records of `groups` whose
+// first row is a multiple of 64).
+//   dense blocks, LD elements of 1 / 2 / 4 bytes: a tile of 64 rows x 32 columns is loaded coalesced and handed to the
+//     rows through the wave's LDS buffer (HalfTileRows, as the fp32 panel kernel's second pass does), eta_diff of the
+//     tile's 64 columns sits in LDS as doubles (broadcast reads); the next half tile's loads are in flight while the
+//     current one is accumulated; a tile whose eta_diff are all zero (skipped SNPs) is not read: fma(R, 0, s) == s.
+//   everything else (windowed components, 8-byte LD elements): element by element along the row.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename U, int C>
+__device__ __forceinline__ double raw_elem_f64(const RawRow<U, C>& v, int e) {
+    if constexpr (std::is_same<U, float>::value) return (double)__uint_as_float(v.w[e]);
+    else if constexpr (sizeof(U) == 4) return (double)(int)v.w[e];
+    else if constexpr (sizeof(U) == 1) return (double)static_cast<int8_t>(v.w[e >> 2] >> (8 * (e & 3)));
+    else return (double)static_cast<int16_t>(v.w[e >> 1] >> (16 * (e & 1)));
+}
+
+template <typename U, bool DENSE>
+__global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_exact_kernel(EStepArgs<double> A0,
+                                                                                    const int64_t* __restrict__ groups,
+                                                                                    int64_t n_groups) {
+    using T = double;
+    constexpr bool kTiled = DENSE && sizeof(U) <= 4;
+    constexpr int kWavesPerWg = kTileThreads / 64;
+    using H = HalfTileRows<typename std::conditional<kTiled, U, float>::type>;
+    __shared__ __attribute__((aligned(16))) char s_tbuf[kWavesPerWg][H::kBufBytes];
+    __shared__ __attribute__((aligned(16))) double s_ed[kWavesPerWg][kPanel];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerWg + wib;
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerWg;
+    const int n_models = max(1, A0.n_active);
+    const int64_t n_items = n_groups * n_models;
+    const U* __restrict__ ld = static_cast<const U*>(DENSE ? A0.ld_dense : A0.ld_rows);
+    char* __restrict__ tbuf = s_tbuf[wib];
+    double* __restrict__ edl = s_ed[wib];
+    for (int64_t item = wave; item < n_items; item += n_waves) {
+        const int64_t g = groups[item % n_groups];
+        const int r0 = (int)(uint32_t)g;
+        if (r0 & (kPanel - 1)) continue;                          // (records are per 8 rows: a 64-row group starts at every 8th)
+        const BlockDesc bd = A0.blocks[(int)(g >> 32)];
+        const EStepArgs<T> A = select_model(A0, (int)(item / n_groups));
+        const int b = bd.size;
+        const int64_t s0 = bd.start;
+        const T* __restrict__ ed = A.eta_diff + s0;
+        const bool live = r0 + lane < b;
+        T s = 0;
+        if constexpr (kTiled) {
+            const U* __restrict__ base = ld + bd.ld_off;
+            const int np = (b + kPanel - 1) / kPanel;
+            for (int ct = r0 / kPanel; ct < np; ++ct) {
+                const int c = ct * kPanel + lane;
+                const T e = c < b ? ed[c] : (T)0;
+                if (__ballot(e != (T)0) == 0) continue;            // all-zero eta_diff: every term is fma(R, 0, s) == s
+                __builtin_amdgcn_wave_barrier();
+                edl[lane] = e;
+                __builtin_amdgcn_wave_barrier();
+                H h0, h1;
+                const U* __restrict__ col0 = base + ct * kPanel;
+                h0.load_co(col0, bd.stride, r0, b, lane);
+                h1.load_co(col0 + kPanel / 2, bd.stride, r0, b, lane);
+                auto accumulate = [&](const H& h, int c0) {
+#pragma unroll
+                    for (int i = 0; i < H::N; ++i) {
+                        const double2* __restrict__ ep = reinterpret_cast<const double2*>(edl + c0 + H::C * i);
+#pragma unroll
+                        for (int x = 0; x < H::C; x += 2) {
+                            const double2 ee = ep[x >> 1];
+                            s = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x), ee.x, s);
+                            s = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x + 1), ee.y, s);
+                        }
+                    }
+                };
+                h0.to_rows(tbuf, lane);
+                accumulate(h0, 0);
+                h1.to_rows(tbuf, lane);
+                accumulate(h1, kPanel / 2);
+            }
+        } else {
+            // row r0 + lane: columns [ws, we) at ld[base + c]
+            int ws = 0, we = 0;
+            int64_t base = 0;
+            if (live) {
+                const int jj = r0 + lane;
+                if (DENSE) {
+                    ws = jj + 1; we = b; base = bd.ld_off + (int64_t)jj * bd.stride;
+                } else {
+                    const int64_t j = s0 + jj;
+                    ws = A.lb[j] - (int)s0; we = ws + A.rowlen[j]; base = A.rowstart[j] - ws;
+                }
+            }
+            // (wave-uniform column loop over the union of the rows' windows: eta_diff is one scalar load per column)
+            int cmin = we > ws ? ws : b, cmax = we > ws ? we : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { cmin = min(cmin, __shfl_xor(cmin, o)); cmax = max(cmax, __shfl_xor(cmax, o)); }
+            for (int c = cmin; c < cmax; ++c) {
+                const T e = ed[c];
+                if (c >= ws && c < we) s = __builtin_fma(static_cast<T>(ld[base + c]), e, s);
+            }
+        }
+        if (live) A.q[s0 + r0 + lane] += A.dq * s;                 // e_step.hpp:335
     }
 }
 
