@@ -1,7 +1,7 @@
 """Randomised parity runs (development tool, the oracle is the checker as in tests/): for SECONDS, draw a block-size mix
 (tiny, panel-edge, medium / large / very large team classes, many-block mixes), an LD form, an LD dtype, a model
 (spike-and-slab, mixture K, grid G with a scattered active list) and a state precision, run two sweeps through the C ABI
-shim and through the oracle, and require `==` (fp32 state) / 1e-10 (float64 state).  Prints one line per case and a summary;
+shim and through the oracle, and require `==` (fp32 AND float64 states).  Prints one line per case and a summary;
 exit code 1 on the first mismatch (the case's seed is printed: `python tools/fuzz_parity.py 0 SEED` re-runs it alone).
     python tools/fuzz_parity.py [SECONDS] [SEED]"""
 import os, sys, time
@@ -47,7 +47,7 @@ def draw_sizes(rng, budget):
 def one_case(seed):
     rng = np.random.default_rng(seed)
     model = rng.choice(["spike_slab", "spike_slab", "mixture", "grid"])
-    f64 = bool(rng.integers(0, 5) == 0) and model != "grid"
+    f64 = bool(rng.integers(0, 4) == 0) and model != "grid"
     low_memory = bool(rng.integers(0, 2))
     dt = [np.float32, np.float32, np.int8, np.int16][rng.integers(0, 4)]
     if f64 and rng.integers(0, 3) == 0:
@@ -85,14 +85,7 @@ def one_case(seed):
     bad = []
     for k in STATE:
         a, b = np.asarray(got[k]), np.asarray(ref[k])
-        if f64:
-            scale = float(np.max(np.abs(b)))               # (the tolerance of tests/test_gpu_float64.py)
-            if k == "eta_diff":                            # a difference of eta-sized numbers: on a one-SNP block in its second
-                scale = max(scale, float(np.max(np.abs(np.asarray(ref["eta"])))))    # sweep it is ALL cancellation (seed 8231)
-            tol = 1e-10 * np.maximum(np.abs(b), 1e-4 * scale)
-            if (np.abs(a - b) > tol).any():
-                bad.append(f"{k}: {int((np.abs(a - b) > tol).sum())} of {a.size} beyond 1e-10, worst {float(np.max(np.abs(a - b))):.3e}")
-        elif not np.array_equal(a, b):
+        if not np.array_equal(a, b):            # (float64 states too since round 5: glibc's exp and the reference's summation order)
             bad.append(f"{k}: {int((a != b).sum())} of {a.size} differ")
     return desc, bad
 
