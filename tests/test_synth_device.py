@@ -91,3 +91,34 @@ def test_generated_plan_equals_uploaded_plan(gpu, low_memory, ld_dtype):
         plan.close()
     H.assert_state_equal(outs[0], ref)
     H.assert_state_equal(outs[1], ref)
+
+
+@pytest.mark.gpu
+def test_generated_cfg3_workload_equals_the_host_built_one(gpu):
+    """bench.py's multi-GPU ranks (and its N = 1 secondaries) sweep LD that never existed on the host: at BASELINE configs[2]'s
+    full size (1.1 M SNPs, 1 700 blocks, 3.8 GB) the generated plan and the plan uploaded from `synthetic.make_ld` leave the
+    same state after a sweep, bit for bit -- and so do rank 0's blocks of an 8-way split."""
+    import bench
+    from viprs_amd.plan import DeviceState, LDPlan
+
+    class A:
+        math, ld_kind, host_ld = "exact", "longrange", False
+
+    sizes = bench.config_sizes("cfg3", 7209)
+    for mine in (None, bench.shard_blocks_lpt(sizes, 8)[0]):
+        outs = []
+        for data in (True, False):
+            ld, ss, inp, m_all = bench.build_workload(A, sizes, mine, 7209, False, np.dtype("float32"), data=data)
+            assert (ld.ld_data is None) == (not data) and m_all == int(sizes.sum())
+            plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, False) if data else LDPlan.synthetic(ld)
+            st = DeviceState(plan, "float32", "spike_slab", 1)
+            for name in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+                st.upload(name, getattr(inp, name))
+            st.reset(inp.pi)
+            st.e_step(ld.dq_scale, None, sync=True)
+            outs.append({k: st.download(k) for k in H.STATE})
+            st.close()
+            plan.close()
+            del ld
+        H.assert_state_equal(outs[0], outs[1])
+        assert np.count_nonzero(outs[0]["eta_diff"]) > 0.5 * outs[0]["eta_diff"].size
