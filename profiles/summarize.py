@@ -18,7 +18,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 
 
 def counters(d, name):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)     # (the newest run of the directory)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == name and ("viprs::estep" in r["Kernel_Name"] or "viprs::tile_f64" in r["Kernel_Name"]):
@@ -26,7 +26,7 @@ def counters(d, name):
     return agg
 
 
-stats = glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv")), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(stats))]
 with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys())
