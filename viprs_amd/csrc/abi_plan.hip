@@ -130,7 +130,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     const size_t es = ld_elem_size(ld_dtype);
     std::unique_ptr<viprs_plan> P(new viprs_plan());
     P->m = m;
-    // environment switches (EXPERIMENTS.md, "4.3 Environment switches" of rounds 1-3), re-read at every plan creation
+    // environment switches (docs/EXPERIMENTS_r1-r3.md, "4.3 Environment switches"), re-read at every plan creation
     if (const char* f = getenv("VIPRS_GRID_MFMA")) P->grid_mfma = atoi(f);
     {
         SchedConfig c;                          // defaults
