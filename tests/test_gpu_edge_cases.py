@@ -475,3 +475,71 @@ def test_forced_team_sizes_and_the_lds_budget_path(gpu, monkeypatch, team0, size
         H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=2), H.run_oracle(ld, inp, st0, sweeps=2))
     finally:
         S.clear_plan_cache()
+
+
+def _assert_equal_with_nonfinite(got, ref):
+    """Finite entries and infinities bit for bit, NaNs in the same places (a NaN's payload / sign is not part of the contract:
+    x86 and gfx950 generate different default NaNs)."""
+    for k in H.STATE:
+        a, b = got[k], ref[k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f"{k}: NaN in different places ({int(np.isnan(a).sum())} vs {int(np.isnan(b).sum())})"
+        ok = ~np.isnan(b)
+        assert np.array_equal(a[ok], b[ok]), f"{k}: {int((a[ok] != b[ok]).sum())} non-NaN entries differ"
+
+
+@pytest.mark.parametrize("precision", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("low_memory", [False, True], ids=["sym", "upper"])
+def test_nonfinite_inputs_propagate_as_in_the_reference(gpu, low_memory, precision):
+    """The reference has no input checks (`noexcept nogil`): a NaN in the summary statistics poisons its LD block (q of the
+    whole window becomes NaN: fma(R, NaN, q)), u_logs = -inf (pi = 0) gives gamma = exp(-inf) / (1 + exp(-inf)) = 0, an
+    overflowing effect runs through inf.  The device follows it entry for entry -- team blocks, single workgroups, both LD
+    forms, float32 and float64 states -- and leaves the other blocks untouched."""
+    ld, ss, inp = syn.make_problem(sizes=[1700, 300, 130, 64, 700], low_memory=low_memory, seed=29, kind="longrange",
+                                   float_precision=precision)
+    s = ld.block_start
+    inp.std_beta[s[0] + 1000] = np.nan                      # the team block, late in the block
+    inp.u_logs[s[1] + 5: s[1] + 9] = -np.inf                # pi = 0 for four SNPs of block 1
+    inp.std_beta[s[3] + 10] = 1e30 if precision == np.float32 else 1e300      # overflow in block 3
+    inp.mu_mult[s[4] + 3] = np.inf                          # inf times a finite residual in block 4
+    st0 = inp.state_copy()
+    with np.errstate(all="ignore"):
+        ref = H.run_oracle(ld, inp, st0, sweeps=2)
+    got = H.run_hip(ld, inp, st0, sweeps=2)
+    _assert_equal_with_nonfinite(got, ref)
+    assert np.isnan(ref["q"][s[0]:s[1]]).all() and np.isfinite(ref["q"][s[2]:s[3]]).all()     # poisoned block / untouched block
+    # (gamma = 0 there: d = -eta_old = 0 takes the skip branch, e_step.hpp:410-413 -- eta_diff 0, var_gamma keeps its start)
+    assert (ref["eta_diff"][s[1] + 5: s[1] + 9] == 0).all() and (ref["var_gamma"][s[1] + 5: s[1] + 9] == precision(inp.pi)).all()
+
+
+@pytest.mark.parametrize("low_memory", [False, True], ids=["sym", "upper"])
+@pytest.mark.parametrize("model", ["mixture4", "mixture10", "grid_mfma", "grid_items"])
+def test_nonfinite_inputs_mixture_and_grid(gpu, model, low_memory, monkeypatch):
+    """The same for the sparse mixture (lane-parallel chain K = 4, wide chain K = 10: a -inf logit is a component with
+    pi_k = 0, a NaN poisons the block through the softmax) and for the grid (batched matrix-core kernel and per-(block, model)
+    items): NaNs in the same places, everything else bit for bit."""
+    from tests.test_gpu_models import _run_grid, _run_mix
+    from tests.test_oracle_vs_ref import _grid_inputs, _mixture_inputs
+    from viprs_amd.vi import e_step_hip as S
+    ld, ss, inp = syn.make_problem(sizes=[1700, 300, 130, 64], low_memory=low_memory, seed=37, kind="longrange")
+    s = ld.block_start
+    inp.std_beta[s[0] + 900] = np.nan
+    inp.std_beta[s[3] + 10] = 1e30
+    with np.errstate(all="ignore"):
+        if model.startswith("mixture"):
+            K = int(model[7:])
+            mix, st0 = _mixture_inputs(ld, ss, K)
+            mix["u_logs"][s[1] + 5: s[1] + 9, 0] = -np.inf          # component 0 switched off for four SNPs
+            mix["u_logs"][s[1] + 20, :] = -np.inf                  # every component off: all the mass on the null
+            ref = _run_mix(O, ld, inp, mix, st0, 2)
+            got = _run_mix(S, ld, inp, mix, st0, 2)
+        else:
+            monkeypatch.setenv("VIPRS_GRID_MFMA", "1" if model == "grid_mfma" else "0")
+            S.clear_plan_cache()
+            g, st0 = _grid_inputs(ld, ss, 12)
+            g["u_logs"][s[1] + 5: s[1] + 9, 3] = -np.inf
+            active = np.array([11, 0, 3, 8], dtype=np.int32)
+            ref = _run_grid(O, ld, inp, g, st0, active)
+            got = _run_grid(S, ld, inp, g, st0, active)
+            S.clear_plan_cache()
+    _assert_equal_with_nonfinite(got, ref)
+    assert np.isnan(ref["q"][s[0]:s[1]]).any() and np.isfinite(ref["q"][s[2]:s[3]]).all()
