@@ -240,3 +240,32 @@ def test_selected_model_reports_its_own_elbo_and_continues_from_its_own_state(gp
     e0 = best.elbo()
     best.fit(continued=True, max_iter=3)
     assert best.history["ELBO"][-1] == pytest.approx(e0, rel=1e-5)       # already converged: stays where it was
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mfma", ["1", "0"], ids=["batched-mfma-teams", "panel-item-teams"])
+def test_unmerged_plans_with_team_blocks_in_flight_together(gpu, monkeypatch, mfma):
+    """with `merge_chromosomes=False` the batched fit enqueues one sweep per chromosome plan on its own stream.
+    Both plans hold a block served by a TEAM of workgroups that wait for each other's hand-offs and size their grid to the
+    whole device: the launches are ordered per device (`team_launch_gate`), no hand-off times out, and the fit ends where
+    the merged one does."""
+    from viprs_amd.data import ArrayDataLoader
+    from viprs_amd.model import VIPRSGrid
+    from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
+    monkeypatch.setenv("VIPRS_GRID_MFMA", mfma)
+    gdl = ArrayDataLoader.synthetic({21: [1700, 90], 22: [64, 2400, 130]}, seed=93, forms=("symmetric",))
+    grid = HyperparameterGrid(n_snps=gdl.m)
+    grid.generate_pi_grid(steps=3)
+    grid.generate_sigma_epsilon_grid(steps=2)
+    runs = []
+    for merge in (True, False):
+        m = VIPRSGrid(gdl, grid, low_memory=False, merge_chromosomes=merge)
+        m.fit(batched=True, max_iter=25)
+        runs.append(m)
+    a, b = runs
+    assert a._merged and not b._merged and set(b._grid_state) == {21, 22}
+    ea = a.to_validation_table()["ELBO"].to_numpy().astype(np.float64)
+    eb = b.to_validation_table()["ELBO"].to_numpy().astype(np.float64)
+    np.testing.assert_allclose(ea, eb, rtol=1e-7, atol=1e-3)
+    for c in a.chromosomes:
+        np.testing.assert_allclose(a.pip[c], b.pip[c], rtol=1e-4, atol=1e-6)
