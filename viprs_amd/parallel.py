@@ -171,6 +171,7 @@ class _RootBroadcast:
         self.rank, self.base = rank, base
         self._thread = None
         self._failed_at = None
+        self._mode_lock = threading.Lock()
         if rank == 0:
             for f in glob.glob(f"{glob.escape(base)}.err*"):      # markers of an earlier failed launch on this base
                 try:
@@ -214,21 +215,24 @@ class _RootBroadcast:
 
         def serve():
             while not self._stop.is_set():
-                failed = self._failed_at is not None
-                if failed and time.time() - self._failed_at > self.FAIL_GRACE_S:
+                if self._failed_at is not None and time.time() - self._failed_at > self.FAIL_GRACE_S:
                     break
                 for req in glob.glob(f"{glob.escape(base)}.req.*"):
-                    if (req, failed) in answered:
-                        continue
-                    out = f"{base}.{'err' if failed else 'rsp'}." + req[len(base) + 5:]
-                    tmp = f"{out}.{os.getpid()}.tmp"
-                    try:
-                        with open(tmp, "wb") as f:
-                            f.write(b"" if failed else self.payload)
-                        os.replace(tmp, out)
-                    except OSError:
-                        continue
-                    answered.add((req, failed))
+                    # (the mode is read and the answer written under the lock fail() takes: no request that is filed after
+                    #  fail() has returned can still be answered with the payload)
+                    with self._mode_lock:
+                        failed = self._failed_at is not None
+                        if (req, failed) in answered:
+                            continue
+                        out = f"{base}.{'err' if failed else 'rsp'}." + req[len(base) + 5:]
+                        tmp = f"{out}.{os.getpid()}.tmp"
+                        try:
+                            with open(tmp, "wb") as f:
+                                f.write(b"" if failed else self.payload)
+                            os.replace(tmp, out)
+                        except OSError:
+                            continue
+                        answered.add((req, failed))
                 self._stop.wait(0.005)
             if self._failed_at is not None:
                 self._sweep_litter()
@@ -253,7 +257,8 @@ class _RootBroadcast:
         mislead it.)"""
         if self.rank != 0:
             return
-        self._failed_at = time.time()
+        with self._mode_lock:
+            self._failed_at = time.time()
         if self._thread is None or not self._thread.is_alive():
             self._stop.clear()
             self._start_server()
