@@ -814,6 +814,8 @@ def main():
             weak = other
             sw_w.close()
 
+    # the reference's DEFAULT LD form (low_memory=True) first among the secondaries: `value` is the symmetric form
+    secondary.sort(key=lambda e: 0 if str(e.get("name", "")).startswith("upper-triangular fp32") else 1)
     if rank == 0:
         traffic, traffic_src = None, None
         if world == 1:
@@ -857,7 +859,7 @@ def main():
                 "largest_block": int(np.max(sizes_all)),
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
                 "primary": "`value` is the " + ("upper-triangular" if ld.low_memory else "symmetric") + " LD form; the other "
-                           "form (the reference's default is low_memory=True) is in `secondary`",
+                           "form (the reference's default is low_memory=True) is the FIRST entry of `secondary`",
                 "math_mode": args.math, "math_mode_effective": sw_math_effective, "skipped_snps_last_sweep_rank0": int(skipped),
                 "comm": comm_kind, "rccl_ranks": int(comm_ranks) if comm_kind == "rccl" else None,
                 "ranks": int(comm_ranks),
