@@ -94,7 +94,9 @@ static hipError_t launch_expand(const void* up, const int64_t* ipu, const int32_
 
 }  // namespace
 
+namespace viprs { void team_launch_forget(const viprs_plan* P); }
 viprs_plan::~viprs_plan() {
+    viprs::team_launch_forget(this);           // (a later plan may get this address or this stream handle)
     delete scratch;
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -398,13 +400,21 @@ namespace viprs {
 namespace {
 std::mutex g_gate_mutex;
 std::map<int, hipEvent_t> g_gate_event;        // per device: completion of the last launch with co-resident teams
-hipStream_t g_gate_stream[64] = {};             // ... and the stream it went to (same stream: already ordered)
+std::map<int, const viprs_plan*> g_gate_plan;  // ... and the plan whose stream it went to (the same plan again: already
+                                               //     ordered by its own stream; forgotten when that plan is destroyed)
 }  // namespace
 int team_launch_gate(viprs_plan* P) {
     std::lock_guard<std::mutex> lock(g_gate_mutex);
     auto it = g_gate_event.find(P->device);
-    if (it != g_gate_event.end() && g_gate_stream[P->device & 63] != P->stream) HIP_TRY(hipStreamWaitEvent(P->stream, it->second, 0));
+    auto last = g_gate_plan.find(P->device);
+    if (it != g_gate_event.end() && (last == g_gate_plan.end() || last->second != P))
+        HIP_TRY(hipStreamWaitEvent(P->stream, it->second, 0));
     return VIPRS_OK;
+}
+void team_launch_forget(const viprs_plan* P) {
+    std::lock_guard<std::mutex> lock(g_gate_mutex);
+    auto last = g_gate_plan.find(P->device);
+    if (last != g_gate_plan.end() && last->second == P) g_gate_plan.erase(last);
 }
 int team_launch_done(viprs_plan* P) {
     std::lock_guard<std::mutex> lock(g_gate_mutex);
@@ -415,7 +425,7 @@ int team_launch_done(viprs_plan* P) {
         it = g_gate_event.emplace(P->device, e).first;
     }
     HIP_TRY(hipEventRecord(it->second, P->stream));
-    g_gate_stream[P->device & 63] = P->stream;
+    g_gate_plan[P->device] = P;
     return VIPRS_OK;
 }
 int plan_create_generated(viprs_plan** out, int64_t m, const int32_t* lb, const std::vector<int64_t>& ip64, int ld_dtype,

@@ -91,13 +91,14 @@ def _fingerprint(*arrays):
         n = b.shape[0]
         h = zlib.crc32(n.to_bytes(8, "little"), h)
         if n <= 2 * _FP_EDGE + 64 * _FP_SAMPLES:
-            h = zlib.crc32(b.tobytes(), h)
+            h = zlib.crc32(np.ascontiguousarray(b), h)
             continue
-        h = zlib.crc32(b[:_FP_EDGE].tobytes(), h)
-        h = zlib.crc32(b[n - _FP_EDGE:].tobytes(), h)
-        starts = (np.arange(_FP_SAMPLES, dtype=np.int64) * ((n - 64) // _FP_SAMPLES))
-        idx = (starts[:, None] + np.arange(64, dtype=np.int64)[None, :]).reshape(-1)
-        h = zlib.crc32(b[idx].tobytes(), h)
+        h = zlib.crc32(b[:_FP_EDGE], h)
+        h = zlib.crc32(b[n - _FP_EDGE:], h)
+        # window i starts at i * step (a strided view: one 16 KB copy, no index array)
+        step = (n - 64) // _FP_SAMPLES
+        win = np.lib.stride_tricks.as_strided(b, shape=(_FP_SAMPLES, 64), strides=(step, 1), writeable=False)
+        h = zlib.crc32(np.ascontiguousarray(win), h)
     return h
 
 
