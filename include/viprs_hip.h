@@ -83,6 +83,11 @@ int viprs_device_count(int* count);
 int viprs_check_blas_support(void);
 int viprs_check_omp_support(void);
 
+/* Content fingerprint of a HOST array: length + first / last 4 KB + 256 evenly spaced 64-byte windows (pure host code, a few
+ * microseconds).  The Cython entry points read the caller's LD arrays on every call (e_step_cpp.pyx:91-122); a binding that
+ * keeps them resident on the device uses this to notice an in-place edit (viprs_amd/vi/e_step_hip.py::plan_for).            */
+int viprs_host_fingerprint(const void* data, int64_t n_bytes, uint64_t* fingerprint);
+
 /* ---- planner (pure host code; usable without a GPU) -------------------------------------- */
 /* Validates the LD index arrays (bit-exact integer checks: indptr[0] == 0, indptr monotone,
  * 0 <= left_bound[j], left_bound[j] + len_j <= m; symmetric form: window contains j;

@@ -55,6 +55,7 @@ _PROTOS = {
     "viprs_version": (ctypes.c_char_p, []),
     "viprs_build_flags": (ctypes.c_char_p, []),
     "viprs_device_count": (_i, [ctypes.POINTER(_i)]),
+    "viprs_host_fingerprint": (_i, [_vp, _i64, ctypes.POINTER(ctypes.c_uint64)]),
     "viprs_check_blas_support": (_i, []),
     "viprs_check_omp_support": (_i, []),
     "viprs_plan_blocks": (_i, [_i64, _vp, _vp, _i, _i, _pi64, _vp, _vp]),

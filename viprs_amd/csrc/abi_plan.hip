@@ -449,6 +449,36 @@ int viprs_device_count(int* count) {
     return VIPRS_OK;
 }
 
+// Content fingerprint of a host array (viprs_amd/vi/e_step_hip.py::plan_for: has the caller edited its LD arrays in place since
+// they were uploaded?): the length, the first and last 4 KB and 256 evenly spaced 64-byte windows, mixed 8 bytes at a time --
+// a few microseconds whatever the array size.  Pure host code.
+int viprs_host_fingerprint(const void* data, int64_t n_bytes, uint64_t* out) {
+    if (!out || n_bytes < 0 || (n_bytes > 0 && !data)) return fail(VIPRS_EINVAL, "bad argument");
+    const unsigned char* b = static_cast<const unsigned char*>(data);
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n_bytes;
+    auto mix = [&](const unsigned char* p, int64_t n) {
+        int64_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            std::memcpy(&w, p + i, 8);
+            h = (h ^ w) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+        for (; i < n; ++i) { h = (h ^ p[i]) * 0x100000001b3ull; }
+    };
+    constexpr int64_t kEdge = 4096, kSamples = 256, kWin = 64;
+    if (n_bytes <= 2 * kEdge + kSamples * kWin) {
+        mix(b, n_bytes);
+    } else {
+        mix(b, kEdge);
+        mix(b + n_bytes - kEdge, kEdge);
+        const int64_t step = (n_bytes - kWin) / kSamples;
+        for (int64_t k = 0; k < kSamples; ++k) mix(b + k * step, kWin);
+    }
+    *out = h;
+    return VIPRS_OK;
+}
+
 int viprs_check_blas_support(void) { return 0; }
 int viprs_check_omp_support(void) { return 0; }
 

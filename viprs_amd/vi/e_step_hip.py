@@ -77,28 +77,22 @@ def invalidate(ld_data=None):
 
 
 _FP_EDGE = 4096          # bytes hashed at both ends of every array
-_FP_SAMPLES = 256        # + this many 64-byte windows spread evenly over the array
+_FP_SAMPLES = 256        # + this many 64-byte windows spread evenly over the array (viprs_host_fingerprint, abi_plan.hip)
 
 
 def _fingerprint(*arrays):
-    """Cheap content fingerprint of the LD arrays (a few tens of KB hashed per call, whatever the array size): the first
-    and last 4 KB and 256 evenly spaced 64-byte windows of each.  The reference's Cython function reads the caller's
-    memory on every call (e_step_cpp.pyx:91-122); the resident device copy can only notice edits this way."""
-    import zlib
+    """Cheap content fingerprint of the LD arrays (a few microseconds per call, whatever the array size): per array its
+    length, the first and last 4 KB and 256 evenly spaced 64-byte windows (`viprs_host_fingerprint`, host code of the
+    library).  The reference's Cython function reads the caller's memory on every call (e_step_cpp.pyx:91-122); the
+    resident device copy can only notice edits this way."""
+    import ctypes
+    out = ctypes.c_uint64(0)
     h = 0
     for a in arrays:
-        b = a.reshape(-1).view(np.uint8)
-        n = b.shape[0]
-        h = zlib.crc32(n.to_bytes(8, "little"), h)
-        if n <= 2 * _FP_EDGE + 64 * _FP_SAMPLES:
-            h = zlib.crc32(np.ascontiguousarray(b), h)
-            continue
-        h = zlib.crc32(b[:_FP_EDGE], h)
-        h = zlib.crc32(b[n - _FP_EDGE:], h)
-        # window i starts at i * step (a strided view: one 16 KB copy, no index array)
-        step = (n - 64) // _FP_SAMPLES
-        win = np.lib.stride_tricks.as_strided(b, shape=(_FP_SAMPLES, 64), strides=(step, 1), writeable=False)
-        h = zlib.crc32(np.ascontiguousarray(win), h)
+        if not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a)
+        L.check(L.lib.viprs_host_fingerprint(a.ctypes.data_as(ctypes.c_void_p), a.nbytes, ctypes.byref(out)))
+        h = (h * 0x100000001b3 + out.value) & 0xFFFFFFFFFFFFFFFF
     return h
 
 
