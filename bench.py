@@ -888,6 +888,14 @@ def main():
                         "kernels' own streams); percentiles are rank 0's per-sweep kernel times",
             },
         }
+        if secondary and str(secondary[0].get("name", "")).startswith("upper-triangular fp32"):
+            # the same workload in the LD form VIPRS() runs by default (low_memory=True, VIPRS.py:75), at the top level too
+            d0 = secondary[0]
+            out["default_ld_form"] = {"ld_form": "upper-triangular (low_memory=True, the reference's default)",
+                                      "value": d0["value"], "unit": d0["unit"], "ms_per_step": d0["ms_per_step"],
+                                      "kernel_ms_avg": d0["kernel_ms_avg"], "roofline_frac": d0["roofline_frac"],
+                                      "traffic_over_algorithmic": d0.get("traffic_over_algorithmic"),
+                                      "note": "`value` above is the symmetric form (low_memory=False); details of this entry: config.secondary[0]"}
         if n_gpus > 1:
             # self-diagnosing multi-GPU line: what every rank held and how long its kernel took, next to the model
             out["per_rank"] = {
