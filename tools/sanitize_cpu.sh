@@ -22,4 +22,4 @@ make -C viprs_amd/csrc OBJDIR=$OUT/obj OUT=$OUT/libviprs_hip_asan.so \
     EXTRA_CXXFLAGS="-Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -g"
 RT=$(/opt/rocm/lib/llvm/bin/clang --print-file-name=libclang_rt.asan-x86_64.so)
 VIPRS_HIP_LIB=$OUT/libviprs_hip_asan.so ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT \
-    python -m pytest tests/test_planner.py tests/test_abi.py tests/test_zarr_ld.py tests/test_parallel.py -x -q -m "not gpu"
+    python -m pytest tests/test_planner.py tests/test_abi.py tests/test_zarr_ld.py tests/test_parallel.py tests/test_synth_device.py -x -q -m "not gpu"
