@@ -54,7 +54,12 @@ __global__ void repack_dense_kernel(const U* __restrict__ src, const int64_t* __
         const int64_t rs = ip[bd.start + r];
         U* __restrict__ drow = dst + bd.ld_off + (int64_t)r * bd.stride;
         if (upper) {
-            for (int c = r + 1 + threadIdx.x; c < b; c += blockDim.x) drow[c] = src[rs + (c - r - 1)];
+            // upper == 2: mirrored into the lower triangle as well (kFormMirror, estep_panel.h; the diagonal stays 0)
+            for (int c = r + 1 + threadIdx.x; c < b; c += blockDim.x) {
+                const U v = src[rs + (c - r - 1)];
+                drow[c] = v;
+                if (upper == 2) dst[bd.ld_off + (int64_t)c * bd.stride + r] = v;
+            }
         } else {
             for (int c = threadIdx.x; c < b; c += blockDim.x) drow[c] = src[rs + c];
         }
@@ -147,6 +152,10 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         sched_config() = c;
     }
     P->low_memory = low_memory != 0;
+    {
+        const char* e = getenv("VIPRS_UPPER_MIRROR");
+        P->mirror = (P->low_memory && e && *e && atoi(e) != 0) ? 1 : 0;
+    }
     P->ld_dtype = ld_dtype;
     P->device = device;
     std::string err;
@@ -319,7 +328,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         HIP_TRY(P->d_ld_dense.alloc(bytes));
         HIP_TRY(hipMemset(P->d_ld_dense.p, 0, bytes));
         dim3 grid(64, (unsigned)P->dense_h.size());
-        const int upper = P->low_memory;
+        const int upper = P->low_memory ? (P->mirror ? 2 : 1) : 0;
         switch (ld_dtype) {
             case VIPRS_LD_F32:
                 repack_dense_kernel<float><<<grid, 256>>>((const float*)P->d_ld_raw.p, P->d_ip.p, (float*)P->d_ld_dense.p, P->d_dense.p, upper);

@@ -211,9 +211,12 @@ constexpr int kStripRowsInFlight = PANEL_STRIP_DEPTH;   // row loads in flight p
 // loads next to their uses, leaving two in flight), and there is no runtime guard around any load
 // (a guard makes hipcc wait vmcnt(0) per row).  FULL = false (partial last panel of a block): rows
 // past its end are clamped to its last row; their a is 0, so fma(R, 0, q) == q leaves q untouched.
-template <typename U, int CPL, bool FULL, int DEPTH = kStripRowsInFlight>
+// MIXED (mirrored upper form, a strip with columns on both sides of the chain): the multiplier of row j is per lane,
+// fvec * avec[j] -- avec = eta_diff of the panel, fvec = 1 for a column left of the chain (a term of its second-pass sum),
+// dq right of it (dq * eta_diff[j] IS a_j, the same product the chain formed): one v_mul per row more.
+template <typename U, int CPL, bool FULL, int DEPTH = kStripRowsInFlight, bool MIXED = false>
 __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int stride, int last_row, float avec,
-                                             float* __restrict__ lq_c) {
+                                             float* __restrict__ lq_c, float fvec = 1.0f) {
     static_assert(kPanel % DEPTH == 0, "panel must be a whole number of prefetch groups");
     float qv[CPL];
 #pragma unroll
@@ -229,7 +232,7 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
             const RawRow<U, CPL> v = buf[k];
             const int rn = DEPTH * (g + 1) + k;
             buf[k] = load_raw<U, CPL>(rowp + (int64_t)(FULL ? rn : min(rn, last_row)) * stride);
-            const float a = rl(avec, DEPTH * g + k);
+            const float a = MIXED ? fvec * rl(avec, DEPTH * g + k) : rl(avec, DEPTH * g + k);
 #pragma unroll
             for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.get(i), a, qv[i]);
             __builtin_amdgcn_sched_barrier(0);
@@ -238,12 +241,38 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) {
         const RawRow<U, CPL> v = buf[k];
-        const float a = rl(avec, kPanel - DEPTH + k);
+        const float a = MIXED ? fvec * rl(avec, kPanel - DEPTH + k) : rl(avec, kPanel - DEPTH + k);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) qv[i] = __builtin_fmaf(v.get(i), a, qv[i]);
     }
 #pragma unroll
     for (int i = 0; i < CPL; ++i) lq_c[i] = qv[i];
+}
+
+// Mirrored upper form: the terms of the second-pass sums that lie INSIDE a diagonal tile -- s[i] += R[i, j] ed[j] for the
+// SNPs i < j of one panel, read as R[j, i] from row j (lane = column i), rows in ascending order.  One wave per panel and
+// phase (the one that owns the panel's strip), the tile comes from L2 (the chain's staging fetched it a phase earlier).
+// Rows past a partial last panel are clamped; their eta_diff is 0.
+template <typename U>
+__device__ __forceinline__ float diag_lower_update(const U* __restrict__ colp, int stride, int last_row, float edvec, float sv,
+                                                   int lane) {
+    constexpr int DEPTH = 16;
+    float buf[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) buf[k] = static_cast<float>(colp[(int64_t)min(k, last_row) * stride]);
+#pragma unroll 1
+    for (int g = 0; g < kPanel / DEPTH; ++g) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const float v = buf[k];
+            const int rn = min(DEPTH * (g + 1) + k, kPanel - 1);
+            buf[k] = static_cast<float>(colp[(int64_t)min(rn, last_row) * stride]);      // (last group: reloads, unused)
+            const int jr = DEPTH * g + k;
+            const float t = __builtin_fmaf(v, rl(edvec, jr), sv);
+            sv = lane < jr ? t : sv;
+        }
+    }
+    return sv;
 }
 
 // Upper-triangular form, the reference's second pass (update_q_factor, e_step.hpp:331-337:
@@ -574,7 +603,18 @@ template <typename M> struct is_wide_mixture<M, std::enable_if_t<M::kWide>> { st
 
 // One role of the sweep kernel below: a workgroup either works as member `wg % team_size` of team `wg / team_size`
 // on the statically assigned blocks of a team class (TEAM), or pulls blocks from the small-block queue.
-template <typename U, typename MODEL, bool SYM, int NW, bool TEAM, int CPL>
+// FORM: what the LD buffer holds and which arithmetic runs over it --
+//   kFormUpper   rows of the upper triangle (zeros on and left of the diagonal), the reference's low_memory = True arithmetic:
+//                trailing updates to the right of the chain + the second pass as per-row running sums (HalfTileRows)
+//   kFormSym     the symmetric matrix, the reference's low_memory = False arithmetic
+//   kFormMirror  the upper triangle MIRRORED into the lower one (zero diagonal), low_memory = True arithmetic: the second
+//                pass q[i] += dq * sum_{j > i} R[i, j] ed[j] reads R[i, j] as R[j, i] -- row j of the buffer, lane = column i,
+//                coalesced, the same strip update that carries the trailing updates, into the sums s instead of q (the
+//                sum of a row still takes its terms in ascending j: the reference's dot, bit for bit).  No transposition,
+//                no second kind of tile traffic: the instruction stream and the memory traffic of the symmetric form.
+constexpr int kFormUpper = 0, kFormSym = 1, kFormMirror = 2;
+
+template <typename U, typename MODEL, int FORM, int NW, bool TEAM, int CPL>
 __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int qcap, float* __restrict__ smem, const int wg) {
     // q[qcap] | a[2][64] | tiles[2][64 x 64] | mixture chain scratch.  The two tile buffers hold
     //   lane-per-SNP models: the DIAGONAL tiles R[p, p] / R[p+1, p+1] (staged by the updaters one phase ahead; the
@@ -583,6 +623,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     //     phase ahead of its use);
     //   mixtures (rolled chain loop): the same since round 4 (before: the off-diagonal tiles R[p-1, p] / R[p, p+1] here and the
     //     diagonal rows streamed from global memory by the chain wave; -DPANEL_MIX_UPPER_REGS keeps that for the upper form).
+    constexpr bool SYM = FORM != kFormUpper;        // the buffer holds both triangles: strips left and right of the chain
+    constexpr bool MIR = FORM == kFormMirror;       // ... but the arithmetic is the upper-triangular form's
+    constexpr bool SUMS = FORM != kFormSym;         // second-pass sums s[] and eta_diff of the last two panels in LDS
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
     // The off-diagonal tile of the chain's next phase goes through LDS too (below) in the SYMMETRIC form.  The upper-
     // triangular form keeps the chain's own register prefetch for fp32 / int16 LD: measured with nothing else changed
@@ -714,7 +757,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             const int c = glob(li);
             const bool in = (!TEAM || li < n_own * kSW) && c < b;
             lq[li] = in ? A.q[s0 + c] : 0.0f;
-            if (!SYM) ls[li] = 0.0f;
+            if (SUMS) ls[li] = 0.0f;
         }
         if (tid == 0) s_tdone = 0;
         if (kStageDiag) {
@@ -791,6 +834,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     const U* __restrict__ nptr = base + (int64_t)rn0 * stride + rn0 + lane;
 
                     float qc;
+                    // mirrored upper form: lane j keeps the q_j its own update consumed (what the upper form leaves in q[j] until
+                    // the second pass is added)
+                    float q_own = 0.0f;
                     if (own(r0)) qc = lq[loc(r0 + lane)];
                     else qc = (r0 + lane < b) ? A.q[s0 + r0 + lane] : 0.0f;       // (panels 0 / 1 of another member: no update has reached them yet)
                     if (TEAM && p >= 2 && (((p * kPanel) / kSW) % TS) != member) {
@@ -961,8 +1007,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             const bool me = (l == jj);
                             dvec = me ? d : dvec;
                             avec = me ? a : avec;
+                            // (mirrored storage: row jj of the diagonal tile is non-zero left of jj too -- the lanes <= jj keep no
+                            //  valid q in qc from here on, theirs is captured at their own step)
+                            if (MIR) q_own = me ? qc : q_own;
                             qc = __builtin_fmaf(drow_jj, a, qc);
-                            if (SYM) qc = (me && livej) ? qc - d : qc;                         // :527
+                            if (SYM && !MIR) qc = (me && livej) ? qc - d : qc;                 // :527
                         }
                         }
                         if (!kMixLds) {
@@ -974,7 +1023,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             if (TEAM) stage_store(A.eta_out + j, in.eta_old + dvec); else A.eta[j] = in.eta_old + dvec;   // :536
                         }
                         a_prev = avec;
-                        if (!SYM) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
+                        if (SUMS) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
                     } else if constexpr (MODEL::kLaneParallel) {
                         // Mixture chain: the K components (and the null component, lane K) of ONE SNP
                         // are evaluated on K + 1 lanes -- one expf, one divide per SNP instead of K + 1
@@ -1094,8 +1143,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             const bool me = (l == jj);
                             dvec = me ? d : dvec;
                             avec = me ? a : avec;
+                            // (mirrored storage: row jj of the diagonal tile is non-zero left of jj too -- the lanes <= jj keep no
+                            //  valid q in qc from here on, theirs is captured at their own step)
+                            if (MIR) q_own = me ? qc : q_own;
                             qc = __builtin_fmaf(drow_jj, a, qc);
-                            if (SYM) qc = (me && livej) ? qc - d : qc;                         // :527
+                            if (SYM && !MIR) qc = (me && livej) ? qc - d : qc;                 // :527
                             cmm = nmm; csv = nsv; cul = nul;
                         }
                         }
@@ -1121,7 +1173,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             }
                         }
                         a_prev = avec;
-                        if (!SYM) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
+                        if (SUMS) led[(p & 1) * kPanel + lane] = live ? dvec : 0.0f;
                     } else {
                         // The 64 serial SNP updates.  Lane j carries SNP j (its own inputs, its own q[j]);
                         // every lane evaluates the update on its own values, but at step j only lane j's
@@ -1162,9 +1214,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             const float sdz = rl(dz, jj);
                             qcap_v = sel_mask(qcap_v, qc, lane_bit);
                             qf = __builtin_fmaf(dr, sa, qc);
-                            qc = SYM ? sel_mask(qf, qf - sdz, lane_bit) : qf;   // e_step.hpp:427 (own lane only)
+                            // (mirrored storage: qc of the lanes <= jj is no longer a q after this -- theirs was captured in qcap_v)
+                            qc = (SYM && !MIR) ? sel_mask(qf, qf - sdz, lane_bit) : qf;   // e_step.hpp:427 (own lane only)
                             asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(lane_bit) : : "scc");
                         }
+                        q_own = qcap_v;
 
                         PPROF(3, true);
                         // lane-parallel replay of the 64 updates (same operations, same inputs ->
@@ -1173,10 +1227,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         float d_lane = 0.0f;
                         a_prev = MODEL::template finish<TEAM>(A, j, in, qcap_v, tab, live, member == 0, skipped_lane, &d_lane);
                         my_skipped += __popcll(__ballot(skipped_lane));
-                        if (!SYM) led[(p & 1) * kPanel + lane] = d_lane;
+                        if (SUMS) led[(p & 1) * kPanel + lane] = d_lane;
                     }
                     la[(p & 1) * kPanel + lane] = a_prev;
-                    if (own(r0)) lq[loc(r0 + lane)] = qc;
+                    if (own(r0)) lq[loc(r0 + lane)] = MIR ? q_own : qc;
                     PPROF(4, true);
                 }
             }
@@ -1238,6 +1292,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                 const float avec = p > 0 ? la[(pp & 1) * kPanel + lane] : 0.0f;
                 const int nstrips = (bpad + kSW - 1) / kSW;
                 const bool any_a = __ballot(avec != 0.0f) != 0;
+                // mirrored upper form: eta_diff of panel pp, the multiplier of the second-pass sums (a = dq * eta_diff is the
+                // trailing update's)
+                const float edvec = (MIR && p > 0) ? led[(pp & 1) * kPanel + lane] : 0.0f;
+                const bool any_ed = MIR && __ballot(edvec != 0.0f) != 0;
                 const int s_pri = ((p + 1) * kPanel) / kSW;
                 const int n_mine = (nstrips - member + TS - 1) / TS;       // strips member, member+TS, ...
                 auto do_strip = [&](int k) {
@@ -1256,27 +1314,70 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     // sweep); upper-triangular form: right of the chain only (the rest is the
                     // reference's second pass)
                     const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
-                    if (any_a && active) {
-                        if (last_row == kPanel - 1)
-                            strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
-                        else
-                            strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
-                    }
-                    if (k == uw) PPROF(6, wave == 1);
-                    if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
-                        // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
-                        __builtin_amdgcn_wave_barrier();
-                        const float v = lq[loc((p + 1) * kPanel + lane)];
-                        const unsigned long long g =
-                            ((unsigned long long)(A.tag_base + (unsigned)(p + 2)) << 32) | (unsigned long long)__float_as_uint(v);
-                        __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                    auto hand_off = [&]() {
+                        if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
+                            // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
+                            __builtin_amdgcn_wave_barrier();
+                            const float v = lq[loc((p + 1) * kPanel + lane)];
+                            const unsigned long long g =
+                                ((unsigned long long)(A.tag_base + (unsigned)(p + 2)) << 32) | (unsigned long long)__float_as_uint(v);
+                            __hip_atomic_store(gran + (int64_t)(p + 1) * kPanel + lane, g, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    };
+                    if constexpr (MIR) {
+                        // rows of panel pp, lane = column: right of the chain q[c] = fma(R[j, c], a_j, q[c]) (the trailing update),
+                        // left of it s[c] = fma(R[j, c], ed_j, s[c]) -- R[j, c] = R[c, j], the term of row c's second-pass sum
+                        // (update_q_factor, e_step.hpp:331-337), rows j ascending.  A strip lies on one side of the chain (one
+                        // wave-uniform multiplier vector, the per-lane target picks q or s) unless panels pp and p sit in its
+                        // middle: then the multiplier is per lane too (strip_update<MIXED>).
+                        const bool left = cp < pp;
+                        float* __restrict__ tgt = left ? ls + (TEAM ? kl * kSW + CPL * lane : c) : lq_c;
+                        const bool any_l = __ballot(active && left) != 0, any_r = __ballot(active && !left) != 0;
+                        if (any_l && any_r) {
+                            const float fvec = left ? 1.0f : dq;
+                            if (any_ed && active) {
+                                if (last_row == kPanel - 1)
+                                    strip_update<U, CPL, true, kDepth, true>(base + (int64_t)rr0 * stride + c, stride, last_row, edvec, tgt, fvec);
+                                else
+                                    strip_update<U, CPL, false, kDepth, true>(base + (int64_t)rr0 * stride + c, stride, last_row, edvec, tgt, fvec);
+                            }
+                        } else {
+                            // (pinned in a register under the full exec mask: strip_update reads it across lanes with v_readlane
+                            //  inside the divergent region below, and a select the compiler sinks into that region would be
+                            //  written for its active lanes only)
+                            float mvec = any_l ? edvec : avec;
+                            asm volatile("" : "+v"(mvec));
+                            if ((any_l ? any_ed : any_a) && active) {
+                                if (last_row == kPanel - 1)
+                                    strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, mvec, tgt);
+                                else
+                                    strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, mvec, tgt);
+                            }
+                        }
+                        hand_off();
+                    } else {
+                        if (any_a && active) {
+                            if (last_row == kPanel - 1)
+                                strip_update<U, CPL, true, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
+                            else
+                                strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, avec, lq_c);
+                        }
+                        if (k == uw) PPROF(6, wave == 1);
+                        hand_off();
                     }
                 };
                 stage_tiles();
                 PPROF(5, wave == 1);
                 if (p > 0) {
                     for (int k = uw; k < n_mine; k += NW - 1) do_strip(k);
+                    if (MIR && any_ed && uw == NW - 2 && own(rr0)) {
+                        // the diagonal tile of panel pp: its rows' sums over the later SNPs of the same panel -- by the member that
+                        // owns the panel's strip, on its last updater wave (the first one carries the priority strip and the
+                        // hand-off the rest of the team waits for)
+                        float* __restrict__ sp = ls + loc(rr0 + lane);
+                        *sp = diag_lower_update<U>(base + (int64_t)rr0 * stride + rr0 + lane, stride, last_row, edvec, *sp, lane);
+                    }
 #ifdef PANEL_TIMING_NO_SECOND_PASS           // (traffic experiments only: wrong results)
                     if (false) {
 #else
@@ -1358,7 +1459,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             for (int li = tid; li < (TEAM ? n_own * kSW : b); li += NW * 64) {
                 const int i = glob(li);
                 if (i < b) {
-                    const float v = SYM ? lq[li] : lq[li] + A.dq * ls[li];   // upper form: q[j] += dq * dot (e_step.hpp:335)
+                    const float v = SUMS ? lq[li] + A.dq * ls[li] : lq[li];   // upper form: q[j] += dq * dot (e_step.hpp:335)
                     if (TEAM) stage_store(A.q_out + s0 + i, v); else A.q[s0 + i] = v;
                 }
             }
@@ -1419,8 +1520,9 @@ struct SweepArgs {
     unsigned long long* skipped_last;
 };
 
-template <typename U, typename MODEL, bool SYM, int NW, int CPL>
+template <typename U, typename MODEL, int FORM, int NW, int CPL>
 __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(SweepArgs S) {
+    constexpr bool SYM = FORM != kFormUpper;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wg = blockIdx.x;
     const int team_cls = wg < S.n_wg[0] ? 0 : (wg < S.n_wg[0] + S.n_wg[1] ? 1 : 2);
@@ -1431,15 +1533,18 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(S
         // +1 %), a block shared by 4 workgroups (the medium class; a populous large class) is bandwidth-bound and loses
         // 5-12 % with the 8-byte loads (tools/mixed_blocks_bench.py: 300 x 2 400 SNPs 1.65 -> 1.85 ms), and the mixture
         // chains, 3-4 x longer per step, never wait for their updaters (2.5 % slower): all of those keep the wide strips.
-        constexpr int CPL_N = (MODEL::kLaneParallel || SYM) ? CPL : panel_team_cols<U>();
+        // (mirrored upper form: integer LD -- a chain-bound sweep whose teams wait for the hand-off behind the priority strip --
+        //  takes the narrow strips as well; fp32 LD, bound by the stream, keeps the 16-byte loads like the symmetric form)
+        constexpr bool kNarrowForm = FORM == kFormUpper || (FORM == kFormMirror && sizeof(U) < 4);
+        constexpr int CPL_N = (MODEL::kLaneParallel || !kNarrowForm) ? CPL : panel_team_cols<U>();
         const int wg_t = wg - (team_cls ? S.n_wg[0] : 0);
         if (CPL_N != CPL && team_cls == 0 && S.narrow0)
-            panel_role<U, MODEL, SYM, NW, true, CPL_N>(S.cls[0], S.qcap[0], smem, wg_t);
+            panel_role<U, MODEL, FORM, NW, true, CPL_N>(S.cls[0], S.qcap[0], smem, wg_t);
         else
-            panel_role<U, MODEL, SYM, NW, true, CPL>(S.cls[team_cls], S.qcap[team_cls], smem, wg_t);
+            panel_role<U, MODEL, FORM, NW, true, CPL>(S.cls[team_cls], S.qcap[team_cls], smem, wg_t);
         __syncthreads();
     }
-    if (S.cls[2].n_blocks > 0) panel_role<U, MODEL, SYM, NW, false, CPL>(S.cls[2], S.qcap[2], smem, wg);
+    if (S.cls[2].n_blocks > 0) panel_role<U, MODEL, FORM, NW, false, CPL>(S.cls[2], S.qcap[2], smem, wg);
     __syncthreads();
     if (threadIdx.x == 0) {
         // (this workgroup's skip count and queue claims are atomics at L2, issued before this one)

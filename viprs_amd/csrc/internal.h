@@ -81,6 +81,7 @@ struct viprs_plan {
     int64_t m = 0;
     int64_t nnz = 0;
     int low_memory = 0;
+    int mirror = 0;                  // upper-triangular form: the dense blocks hold the upper triangle mirrored into the lower one (kFormMirror)
     int ld_dtype = 0;
     int device = 0;
     int n_cu = 0;

@@ -147,6 +147,8 @@ constexpr int kPanelUpperTransposeBytes = 32 * 128;         // per updater wave:
 __host__ __device__ constexpr int panel_upper_lds_floats(int qcap, int n_waves = 4) {
     return 2 * kPanel + qcap + (n_waves - 1) * kPanelUpperTransposeBytes / 4;
 }
+// ... over mirrored storage (kFormMirror): eta_diff of the last two panels and the sums, no transposition buffers
+__host__ __device__ constexpr int panel_mirror_lds_floats(int qcap) { return 2 * kPanel + qcap; }
 constexpr int kPanelMaxK = 8;       // mixture components the lane-parallel panel chain handles with its inputs staged in LDS
 constexpr int kPanelWideMaxK = 31;  // ... and with scalar chains over v_readlane values (MixtureWideModel)
 // LDS of the lane-parallel mixture chain: mu_mult | sqrt_half_var_tau | u_logs | var_mu | var_gamma, [64 SNPs][K]
