@@ -54,15 +54,42 @@ __global__ void repack_dense_kernel(const U* __restrict__ src, const int64_t* __
         const int64_t rs = ip[bd.start + r];
         U* __restrict__ drow = dst + bd.ld_off + (int64_t)r * bd.stride;
         if (upper) {
-            // upper == 2: mirrored into the lower triangle as well (kFormMirror, estep_panel.h; the diagonal stays 0)
-            for (int c = r + 1 + threadIdx.x; c < b; c += blockDim.x) {
-                const U v = src[rs + (c - r - 1)];
-                drow[c] = v;
-                if (upper == 2) dst[bd.ld_off + (int64_t)c * bd.stride + r] = v;
-            }
+            for (int c = r + 1 + threadIdx.x; c < b; c += blockDim.x) drow[c] = src[rs + (c - r - 1)];
         } else {
             for (int c = threadIdx.x; c < b; c += blockDim.x) drow[c] = src[rs + c];
         }
+    }
+}
+
+// Upper-triangular form: the lower triangle of every dense block (a padded square whose upper triangle the repack filled)
+// becomes the mirror image of the upper one (fill = 1: what the panel kernels sweep, kFormMirror in estep_panel.h) or
+// zeros again (fill = 0: what the batched grid kernel and the float64 kernels rely on).  One 64 x 64 tile pair per
+// workgroup step, transposed through LDS; the diagonal stays 0.  Pure data movement.
+template <typename U>
+__global__ __launch_bounds__(256) void mirror_lower_kernel(U* __restrict__ dense, const BlockDesc* __restrict__ blocks, int fill) {
+    __shared__ U t[kPanel][kPanel + 1];
+    const BlockDesc bd = blocks[blockIdx.y];
+    const int b = bd.size, np = (b + kPanel - 1) / kPanel;
+    U* __restrict__ base = dense + bd.ld_off;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 columns x 4 rows per step
+    // tile pairs (I <= J) of the block, I the row panel of the SOURCE tile
+    const int n_pairs = np * (np + 1) / 2;
+    for (int item = blockIdx.x; item < n_pairs; item += gridDim.x) {
+        int I = 0, rem = item;
+        while (rem >= np - I) { rem -= np - I; ++I; }
+        const int J = I + rem;
+        if (fill) {
+            for (int r = ty; r < kPanel; r += 4) {
+                const int row = I * kPanel + r, col = J * kPanel + tx;
+                t[r][tx] = (row < b && col < b && col > row) ? base[(int64_t)row * bd.stride + col] : (U)0;
+            }
+        }
+        __syncthreads();
+        for (int r = ty; r < kPanel; r += 4) {
+            const int row = J * kPanel + r, col = I * kPanel + tx;          // target (row > col only)
+            if (row < b && col < row) base[(int64_t)row * bd.stride + col] = fill ? t[tx][r] : (U)0;
+        }
+        __syncthreads();
     }
 }
 
@@ -153,8 +180,9 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     }
     P->low_memory = low_memory != 0;
     {
+        // (VIPRS_UPPER_MIRROR=0: the panel kernels keep the packed upper form -- kFormUpper, estep_panel.h)
         const char* e = getenv("VIPRS_UPPER_MIRROR");
-        P->mirror = (P->low_memory && e && *e && atoi(e) != 0) ? 1 : 0;
+        P->use_mirror = (e && *e) ? (atoi(e) != 0) : true;
     }
     P->ld_dtype = ld_dtype;
     P->device = device;
@@ -328,7 +356,7 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         HIP_TRY(P->d_ld_dense.alloc(bytes));
         HIP_TRY(hipMemset(P->d_ld_dense.p, 0, bytes));
         dim3 grid(64, (unsigned)P->dense_h.size());
-        const int upper = P->low_memory ? (P->mirror ? 2 : 1) : 0;
+        const int upper = P->low_memory;
         switch (ld_dtype) {
             case VIPRS_LD_F32:
                 repack_dense_kernel<float><<<grid, 256>>>((const float*)P->d_ld_raw.p, P->d_ip.p, (float*)P->d_ld_dense.p, P->d_dense.p, upper);
@@ -406,6 +434,24 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
 }
 
 namespace viprs {
+// The dense blocks of an upper-triangular plan in the form the coming launch sweeps (see mirror_lower_kernel); the
+// conversion runs on the plan's stream, once per change of kernel family (a fit keeps to one).
+int ensure_upper_storage(viprs_plan* P, bool mirrored) {
+    if (!P->low_memory || P->dense_h.empty() || (P->mirror != 0) == mirrored) return VIPRS_OK;
+    int max_np = 0;
+    for (const BlockDesc& d : P->dense_h) max_np = std::max(max_np, (d.size + kPanel - 1) / kPanel);
+    const dim3 grid((unsigned)std::min(max_np * (max_np + 1) / 2, 512), (unsigned)P->dense_h.size());
+    switch (P->ld_dtype) {
+        case VIPRS_LD_F32: mirror_lower_kernel<float><<<grid, 256, 0, P->stream>>>((float*)P->d_ld_dense.p, P->d_dense.p, mirrored ? 1 : 0); break;
+        case VIPRS_LD_I8: mirror_lower_kernel<int8_t><<<grid, 256, 0, P->stream>>>((int8_t*)P->d_ld_dense.p, P->d_dense.p, mirrored ? 1 : 0); break;
+        case VIPRS_LD_I16: mirror_lower_kernel<int16_t><<<grid, 256, 0, P->stream>>>((int16_t*)P->d_ld_dense.p, P->d_dense.p, mirrored ? 1 : 0); break;
+        default: return fail(VIPRS_EINVAL, "dense blocks with unsupported LD dtype");
+    }
+    HIP_TRY(hipGetLastError());
+    P->mirror = mirrored ? 1 : 0;
+    return VIPRS_OK;
+}
+
 namespace {
 std::mutex g_gate_mutex;
 std::map<int, hipEvent_t> g_gate_event;        // per device: completion of the last launch with co-resident teams

@@ -81,7 +81,8 @@ struct viprs_plan {
     int64_t m = 0;
     int64_t nnz = 0;
     int low_memory = 0;
-    int mirror = 0;                  // upper-triangular form: the dense blocks hold the upper triangle mirrored into the lower one (kFormMirror)
+    int mirror = 0;                  // upper-triangular form: the dense blocks currently hold the upper triangle mirrored into the lower one
+    bool use_mirror = true;          // ... which the panel kernels ask for (kFormMirror, estep_panel.h) unless VIPRS_UPPER_MIRROR=0
     int ld_dtype = 0;
     int device = 0;
     int n_cu = 0;
@@ -196,6 +197,7 @@ int plan_create_generated(viprs_plan** out, int64_t m, const int32_t* lb, const 
 // and could leave a team member undispatched while its peers spin.  `team_launch_gate` orders them: the stream of the plan
 // waits for the previous gated launch on this device, `team_launch_done` records this one.  (Other PROCESSES on the
 // same device cannot be ordered from here: the bounded spins report VIPRS_EDEVICE instead of hanging.)
+int ensure_upper_storage(viprs_plan* P, bool mirrored);
 int team_launch_gate(viprs_plan* P);
 int team_launch_done(viprs_plan* P);
 
