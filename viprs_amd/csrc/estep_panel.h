@@ -250,27 +250,13 @@ __device__ __forceinline__ void strip_update(const U* __restrict__ rowp, int str
 }
 
 // Mirrored upper form: the terms of the second-pass sums that lie INSIDE a diagonal tile -- s[i] += R[i, j] ed[j] for the
-// SNPs i < j of one panel, read as R[j, i] from row j (lane = column i), rows in ascending order.  One wave per panel and
-// phase (the one that owns the panel's strip), the tile comes from L2 (the chain's staging fetched it a phase earlier).
-// Rows past a partial last panel are clamped; their eta_diff is 0.
-template <typename U>
-__device__ __forceinline__ float diag_lower_update(const U* __restrict__ colp, int stride, int last_row, float edvec, float sv,
-                                                   int lane) {
-    constexpr int DEPTH = 16;
-    float buf[DEPTH];
-#pragma unroll
-    for (int k = 0; k < DEPTH; ++k) buf[k] = static_cast<float>(colp[(int64_t)min(k, last_row) * stride]);
-#pragma unroll 1
-    for (int g = 0; g < kPanel / DEPTH; ++g) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; ++k) {
-            const float v = buf[k];
-            const int rn = min(DEPTH * (g + 1) + k, kPanel - 1);
-            buf[k] = static_cast<float>(colp[(int64_t)min(rn, last_row) * stride]);      // (last group: reloads, unused)
-            const int jr = DEPTH * g + k;
-            const float t = __builtin_fmaf(v, rl(edvec, jr), sv);
-            sv = lane < jr ? t : sv;
-        }
+// SNPs i < j of one panel, read as R[j, i] from row j (lane = column i), rows in ascending order.  The tile is the one the
+// chain has just swept, still in LDS (fp32, staged rows past a partial last panel clamped; their eta_diff is 0).
+__device__ __forceinline__ float diag_lower_update(const float* __restrict__ tile, float edvec, float sv, int lane) {
+#pragma unroll 16
+    for (int jr = 0; jr < kPanel; ++jr) {
+        const float t = __builtin_fmaf(tile[jr * kPanel + lane], rl(edvec, jr), sv);
+        sv = lane < jr ? t : sv;
     }
     return sv;
 }
@@ -672,6 +658,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #endif
     __shared__ int s_blk;
     __shared__ int s_tdone;        // phases whose off-diagonal tile the chain has consumed (gate of the single lTo buffer)
+    __shared__ int s_ddone;        // mirrored upper form: phases whose diagonal-tile sums are done (gate of the tile buffer they read)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -759,7 +746,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             lq[li] = in ? A.q[s0 + c] : 0.0f;
             if (SUMS) ls[li] = 0.0f;
         }
-        if (tid == 0) s_tdone = 0;
+        if (tid == 0) { s_tdone = 0; s_ddone = 0; }
         if (kStageDiag) {
             // diagonal tile of panel 0 (rows past the end of a short block are clamped: finite values that
             // only ever meet a = 0)
@@ -1268,6 +1255,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             w[g] = load4<U>(base + (int64_t)min(p * kPanel + row, b - 1) * stride + (p + 1) * kPanel + tcol);
                         }
                     }
+                    if (MIR && p > 0) {
+                        // the buffer still holds the diagonal tile of panel p-1 until its rows' sums are done (below)
+                        while (*reinterpret_cast<volatile int*>(&s_ddone) < p) __builtin_amdgcn_s_sleep(1);
+                    }
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) {
                         const int i = uw + g * (NW - 1);
@@ -1367,17 +1358,21 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         hand_off();
                     }
                 };
+                if (MIR && p > 0 && uw == NW - 2) {
+                    // the diagonal tile of panel pp, still in LDS from the chain's last phase: its rows' sums over the later SNPs
+                    // of the same panel -- by the member that owns the panel's strip, on its last updater wave (the first one
+                    // carries the priority strip and the hand-off the rest of the team waits for).  The staging of the next
+                    // diagonal tile into the same buffer waits for it (s_ddone; LDS executes a wave's operations in order).
+                    if (any_ed && own(rr0)) {
+                        float* __restrict__ sp = ls + loc(rr0 + lane);
+                        *sp = diag_lower_update(lT + (pp & 1) * kPanel * kPanel, edvec, *sp, lane);
+                    }
+                    if (lane == 0) *reinterpret_cast<volatile int*>(&s_ddone) = p;
+                }
                 stage_tiles();
                 PPROF(5, wave == 1);
                 if (p > 0) {
                     for (int k = uw; k < n_mine; k += NW - 1) do_strip(k);
-                    if (MIR && any_ed && uw == NW - 2 && own(rr0)) {
-                        // the diagonal tile of panel pp: its rows' sums over the later SNPs of the same panel -- by the member that
-                        // owns the panel's strip, on its last updater wave (the first one carries the priority strip and the
-                        // hand-off the rest of the team waits for)
-                        float* __restrict__ sp = ls + loc(rr0 + lane);
-                        *sp = diag_lower_update<U>(base + (int64_t)rr0 * stride + rr0 + lane, stride, last_row, edvec, *sp, lane);
-                    }
 #ifdef PANEL_TIMING_NO_SECOND_PASS           // (traffic experiments only: wrong results)
                     if (false) {
 #else
