@@ -1,6 +1,6 @@
 """A/B/C... of several builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
     python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix [K=n]] [uniform] [fast] [sizes=a,b,..] [shard=N]
-(each library runs in its own subprocess, 3 rounds)"""
+(each library runs in its own subprocess, 3 rounds; LIB may carry environment switches: path,VIPRS_UPPER_MIRROR=0)"""
 import os, subprocess, sys
 sep = sys.argv.index('--') if '--' in sys.argv else len(sys.argv)
 libs = sys.argv[1:sep]
@@ -43,6 +43,7 @@ print("%.4f %.4f %.4f  wall ms/step %.4f" % (np.median(t), np.percentile(t, 10),
 '''
 for rnd in range(3):
     for name, lib in zip("ABCDEFGH", libs):
-        env = dict(os.environ, VIPRS_HIP_LIB=os.path.abspath(lib))
+        path, *switches = lib.split(",")
+        env = dict(os.environ, VIPRS_HIP_LIB=os.path.abspath(path), **dict(x.split("=", 1) for x in switches))
         out = subprocess.run([sys.executable, "-c", code] + args, env=env, capture_output=True, text=True)
         print(rnd, name, os.path.basename(lib), out.stdout.strip() or out.stderr[-300:], flush=True)

@@ -111,15 +111,18 @@ __device__ __forceinline__ void tile_store_acc(const f32x16& acc0, const f32x16&
 }
 
 // 64 MFMAs: rows (kr, kr + 1) of the panel per pair, k ascending
+// (SCALED: the LDS array holds eta_diff, the A operand is scale * eta_diff -- the mirrored upper form, grid_block_resident)
+template <bool SCALED = false>
 __device__ __forceinline__ void tile_compute(f32x16& acc0, f32x16& acc1, const float (&R)[kPanel],
-                                             const float* __restrict__ a_lds, int lane) {
+                                             const float* __restrict__ a_lds, int lane, float scale = 1.0f) {
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int kr = 0; kr < kPanel; kr += 2) {
         // [row kr : cols 0..31 | row kr+1 : cols 0..31]  and  [row kr : cols 32..63 | row kr+1 : cols 32..63]
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(R[kr]), __float_as_uint(R[kr + 1]), false, false);
         const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);
-        const float aop = a_lds[(kr + half) * kGridModels + l31];    // A[model = lane & 31][k = lane >> 5]
+        const float a_raw = a_lds[(kr + half) * kGridModels + l31];  // A[model = lane & 31][k = lane >> 5]
+        const float aop = SCALED ? scale * a_raw : a_raw;
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, b1, acc1, 0, 0, 0);
     }
@@ -215,6 +218,29 @@ __device__ __forceinline__ void wtile_store_acc(const f32x16 (&acc)[4], const ES
     }
 }
 
+// q[model][column] += dq * acc (the second pass of the upper-triangular form, e_step.hpp:300: q[j] += dq * dot)
+template <bool FULL>
+__device__ __forceinline__ void wtile_add_to_q(const f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act, int64_t s0,
+                                               int b, int c0, bool lane_ok, int n_models, int lane, float dq) {
+    const int half = lane >> 5, c = c0 + 4 * (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (lane_ok && g < n_models) {
+            const unsigned off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0 + c;
+            if (FULL) {
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(A.q + off);
+                *reinterpret_cast<f32x4u*>(A.q + off) =
+                    f32x4u{v[0] + dq * acc[0][r], v[1] + dq * acc[1][r], v[2] + dq * acc[2][r], v[3] + dq * acc[3][r]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < b) A.q[off + j] = A.q[off + j] + dq * acc[j][r];
+            }
+        }
+    }
+}
+
 // 128 MFMAs: rows (2i, 2i + 1) per step, k ascending
 __device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
                                               const float* __restrict__ a_lds, int lane, int a_pitch = kGridModels) {
@@ -228,7 +254,9 @@ __device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)
 }
 
 // ---- the chain wave's work for one panel: 64 serial SNP updates for all models ------------------------------
-template <bool SYM, bool EXACT = true>
+// (STORE_D: `la` receives eta_diff itself instead of a = dq * eta_diff -- the mirrored upper form, whose updater waves need
+//  both: eta_diff for the second-pass sums, dq * eta_diff, formed again from the same operands, for the trailing updates)
+template <bool SYM, bool EXACT = true, bool STORE_D = false>
 __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, float* io, float* la, float* dg, float* qx, int p, int b,
                                                  int64_t s0, int lane, int n_models, float dq, const ExpTab& tab
 #ifdef VIPRS_GRID_PROFILE
@@ -325,7 +353,7 @@ __device__ __forceinline__ void grid_chain_panel(const EStepArgs<float>& A, floa
             iog[1 * kGridIoArr + k] = gamma;
             iog[2 * kGridIoArr + k] = d;
             iog[3 * kGridIoArr + k] = eta_old + d;                        // :633
-            lag[k * kGridModels] = a;
+            lag[k * kGridModels] = STORE_D ? ((live && has_model) ? d : 0.0f) : a;
             mm = mm_n; ulog = ulog_n; hvt = hvt_n; eta_old = eta_n;
 #pragma unroll
             for (int c = 0; c < 16; ++c) rw[c] = rn[c];
@@ -615,18 +643,36 @@ template <> struct RawCols4<float> {
     f32x4 v;
     static constexpr int kDwords = 4;
     __device__ __forceinline__ void mask(bool on) { v = on ? v : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    // keep column j (of the four) iff row > col0 + j: the part of a mirrored diagonal tile BELOW the diagonal
+    __device__ __forceinline__ void mask_below(int row, int col0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = row > col0 + j ? v[j] : 0.0f;
+    }
     template <int J> __device__ __forceinline__ float get() const { return v[J]; }
 };
 template <> struct RawCols4<int8_t> {
     unsigned w;
     static constexpr int kDwords = 1;
     __device__ __forceinline__ void mask(bool on) { w = on ? w : 0u; }
+    __device__ __forceinline__ void mask_below(int row, int col0) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m |= row > col0 + j ? 0xFFu << (8 * j) : 0u;
+        w &= m;
+    }
     template <int J> __device__ __forceinline__ float get() const { return static_cast<float>(static_cast<int8_t>(w >> (8 * J))); }
 };
 template <> struct RawCols4<int16_t> {
     unsigned w[2];
     static constexpr int kDwords = 2;
     __device__ __forceinline__ void mask(bool on) { w[0] = on ? w[0] : 0u; w[1] = on ? w[1] : 0u; }
+    __device__ __forceinline__ void mask_below(int row, int col0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned m = (row > col0 + 2 * h ? 0xFFFFu : 0u) | (row > col0 + 2 * h + 1 ? 0xFFFF0000u : 0u);
+            w[h] &= m;
+        }
+    }
     template <int J> __device__ __forceinline__ float get() const { return static_cast<float>(static_cast<int16_t>(w[J >> 1] >> (16 * (J & 1)))); }
 };
 template <typename U> __device__ __forceinline__ RawCols4<U> load_cols4(const char* p);
@@ -642,12 +688,20 @@ template <> __device__ __forceinline__ RawCols4<int16_t> load_cols4<int16_t>(con
 }
 // (`after_first_issue` runs once the first chunk's loads are out and before the first MFMA: the streaming form finishes
 // the tile's accumulator loads there, so that they and the first rows share one memory round trip)
-template <typename U, int DEPTH, typename HOOK = NoHook>
+// MIRV (mirrored upper form): the LDS array holds eta_diff and the A operand is scale * eta_diff (scale = dq: a trailing
+// update; 1: a second-pass sum); `tri` = 0 / 1: the left / right 64 columns are the panel's OWN diagonal tile and take only
+// its part below the diagonal (row > column: R[j, i] = R[i, j] for the SNPs i < j of the panel), -1: neither.
+template <typename U, int DEPTH, typename HOOK = NoHook, bool MIRV = false>
 __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __restrict__ base, int stride, int pp, int c0,
                                                int lane, bool on_l, bool on_r, const float* __restrict__ a_lds,
-                                               HOOK after_first_issue = HOOK()) {
+                                               HOOK after_first_issue = HOOK(), float scale = 1.0f, int tri = -1) {
     const int half = lane >> 5, l31 = lane & 31;
     const bool lane_on = (lane & 16) ? on_r : on_l;
+    const bool lane_tri = MIRV && tri >= 0 && ((lane & 16) != 0) == (tri == 1);
+    // first column of this lane inside its panel; opaque, so that the 32 x 4 row-against-column tests of the triangular half
+    // are made where they are used and not hoisted out of the phase loop into as many mask registers
+    int tri_col0 = 4 * (l31 & 15);
+    if (MIRV) asm volatile("" : "+v"(tri_col0));
     int col = c0 + 4 * l31;
     if (col >= stride) col = c0;                      // right half of the last (odd) tile: masked by the caller
     const unsigned voff = (unsigned)((half * stride + (col - c0)) * (int)sizeof(U));
@@ -687,7 +741,9 @@ __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __rest
         for (int i = 0; i < CH; ++i) {
             RawCols4<U> v = ring[RING == 2 ? (c & 1) : 0][i];
             v.mask(lane_on);
-            const float aop = a_lds[(2 * (c * CH + i) + half) * kGridModels + l31];      // A[model = lane & 31][k = lane >> 5]
+            if (MIRV && tri >= 0) { if (lane_tri) v.mask_below(2 * (c * CH + i) + half, tri_col0); }
+            const float a_raw = a_lds[(2 * (c * CH + i) + half) * kGridModels + l31];    // A[model = lane & 31][k = lane >> 5]
+            const float aop = MIRV ? scale * a_raw : a_raw;
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<0>(), acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<1>(), acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v.template get<2>(), acc[2], 0, 0, 0);
@@ -712,10 +768,21 @@ struct GridTeam {
 };
 constexpr int kGridTeamPanels = 2 * kGridResOwners * kGridResSlots;       // 24 panels (12 tiles) per member
 
-template <typename U, bool SYM, bool EXACT>
+// MIR (upper-triangular form over MIRRORED storage, abi_plan.hip: mirror_lower_kernel): the reference's second pass
+//     q[g, i] += dq * sum_{j > i} R[i, j] eta_diff[g, j]                     (update_q_factor_matrix, e_step.hpp:266-303)
+// runs inside the sweep, on the same accumulators: once a panel has gone to the chain, its owner's registers start again
+// at 0 and collect the SUMS -- R[i, j] read as R[j, i] from the later rows j, in ascending order (the reference's dot, bit
+// for bit), with eta_diff as the A operand where the trailing updates right of the chain take dq * eta_diff (`la` holds
+// eta_diff; the owners form dq * eta_diff from the same two operands as the chain does).  The rows of a panel reach its own
+// columns through the part of the diagonal tile below the diagonal (res_tile_apply `tri`).  At the end of the block
+// q = q_chain + dq * sum (q_chain: what the chain's flush left in the state).  No epilogue kernel, every LD entry of the
+// mirrored block read once.
+template <typename U, bool SYM, bool EXACT, bool MIR = false>
 __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, float* io, float* la, float* dg, f32x4* cy,
                                                     float* qx, const int* s_act, const BlockDesc& bd, int wave, int lane,
                                                     int n_models, float dq, const ExpTab& tab, const GridTeam tm = GridTeam()) {
+    static_assert(!(SYM && MIR), "the mirrored form is the upper-triangular arithmetic");
+    constexpr bool LEFT = SYM || MIR;          // the tiles left of the chain keep receiving the later rows
     constexpr int NU = kGridNU;
     const int64_t s0 = bd.start;
     const int b = bd.size, stride = bd.stride;
@@ -729,7 +796,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     const int T_lo = tm.member * kGridResOwners * kGridResSlots;
     auto mine = [&](int p) { return !team || (p >= p_lo && p < p_hi); };
     // upper-triangular form: a member whose panels the chain has passed has nothing left to receive
-    const int p_end = (team && !SYM) ? min(np, p_hi) : np;
+    const int p_end = (team && !LEFT) ? min(np, p_hi) : np;
     // the a-vector of panel p: published by the holder's carry wave, received by the other members' chain wave
     auto publish_a = [&](int p) {
         const float* src = la + (p & 1) * kGridAFloats;
@@ -803,7 +870,8 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
 #pragma unroll
         for (int i = 0; i < kGridDiagPerWave; ++i) {
             const int t = wave - 1 + NU * i;
-            if (t < kPanel) dd[t * kPanel + lane] = dv[i];
+            // (mirrored storage: the chain applies a row to the columns RIGHT of its SNP only)
+            if (t < kPanel) dd[t * kPanel + lane] = (MIR && lane <= t) ? 0.0f : dv[i];
         }
     };
     auto flush_outputs = [&](int pp) {
@@ -837,13 +905,13 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
 #ifdef VIPRS_GRID_MFMA_CHAIN
                 grid_chain_panel_mfma<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
 #else
-                grid_chain_panel<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
+                grid_chain_panel<SYM, EXACT, MIR>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
 #ifdef VIPRS_GRID_PROFILE
                                       , 1, nullptr
 #endif
                                       );
 #endif
-            } else if (p < np && (SYM || p < p_hi)) {
+            } else if (p < np && (LEFT || p < p_hi)) {
                 receive_a(p);                                       // another member holds the chain: its a-vector -> la
             }
             __syncthreads();                                        // end
@@ -868,7 +936,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
 #pragma unroll
                     for (int e = 0; e < 4; ++e) R1[4 * i + e] = v[e];
                 }
-                tile_compute(c0v, c1v, R1, la + ((p - 1) & 1) * kGridAFloats, lane);
+                tile_compute<MIR>(c0v, c1v, R1, la + ((p - 1) & 1) * kGridAFloats, lane, dq);
                 float* qd = qx + (p & 1) * kGridQxFloats + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -896,7 +964,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                 if (p > 0) {
                     float R0[kPanel];
                     tile_load_rows<U>(R0, base, stride, b, p - 1, p + 1, lane);
-                    tile_compute(c0v, c1v, R0, la + ((p - 1) & 1) * kGridAFloats, lane);
+                    tile_compute<MIR>(c0v, c1v, R0, la + ((p - 1) & 1) * kGridAFloats, lane, dq);
                     asm volatile("" : "+v"(c0v), "+v"(c1v) :: "memory");
                 }
                 float R1[kPanel];
@@ -951,6 +1019,15 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                 }
             }
         };
+        // mirrored form: the 64 columns of panel `e` start again at 0 -- from here on they collect the panel's second-pass sums
+        auto restart = [&](f32x16 (&acc)[4], int e) {
+            if ((n >= 16) == ((e & 1) != 0)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            }
+        };
         auto tile_of = [&](int panel) { return panel >> 1; };
         if (np > 1) {
             if (tile_of(1) == TA) extract(accA, 1);                 // (tile 0 is wave 2's first tile)
@@ -967,19 +1044,33 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                     if (tile_of(pp) == TA) take_back(accA, pp);
                     else if (tile_of(pp) == TB) take_back(accB, pp);
                 }
+                if (MIR) {
+                    // (the panel left for the chain two phases ago -- panel 0 / 1: from the state / before the loop; nothing has
+                    //  been applied to its columns since)
+                    if (tile_of(pp) == TA) restart(accA, pp);
+                    else if (tile_of(pp) == TB) restart(accB, pp);
+                }
                 const float* a_lds = la + (pp & 1) * kGridAFloats;
                 auto panel_on = [&](int c) {
                     if (c >= np) return false;
-                    return SYM ? (c < p - 1 || c > p + 1) : (c > p + 1);
+                    // (mirrored form: the panel's own columns too -- below the diagonal of its tile)
+                    return LEFT ? (c < p - 1 || c > p + 1 || (MIR && c == p - 1)) : (c > p + 1);
                 };
-                if (hasA) {
-                    const bool l = panel_on(2 * TA), r = panel_on(2 * TA + 1);
-                    if (l || r) res_tile_apply<U, 1>(accA, base, stride, pp, cA, lane, l, r, a_lds);
-                }
-                if (hasB) {
-                    const bool l = panel_on(2 * TB), r = panel_on(2 * TB + 1);
-                    if (l || r) res_tile_apply<U, 1>(accB, base, stride, pp, cB, lane, l, r, a_lds);
-                }
+                auto apply = [&](f32x16 (&acc)[4], int T, int c0) {
+                    const bool l = panel_on(2 * T), r = panel_on(2 * T + 1);
+                    if (!(l || r)) return;
+                    if constexpr (MIR) {
+                        // a tile is never on both sides of the chain at once: left of it (or on it) -- sums, eta_diff as it is;
+                        // right of it -- trailing updates, dq * eta_diff
+                        const int tri = 2 * T == pp ? 0 : (2 * T + 1 == pp ? 1 : -1);
+                        res_tile_apply<U, 1, NoHook, true>(acc, base, stride, pp, c0, lane, l, r, a_lds, NoHook(),
+                                                           2 * T <= pp ? 1.0f : dq, tri);
+                    } else {
+                        res_tile_apply<U, 1>(acc, base, stride, pp, c0, lane, l, r, a_lds);
+                    }
+                };
+                if (hasA) apply(accA, TA, cA);
+                if (hasB) apply(accB, TB, cB);
             }
             if (p + 2 < np) {
                 const int e = p + 2;                                // (a_0 .. a_{p-1} applied) -> the carry's next panel
@@ -987,6 +1078,17 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                 else if (tile_of(e) == TB) extract(accB, e);
             }
             __syncthreads();                                        // end
+        }
+        if (MIR) {
+            // q = q_chain + dq * sum (e_step.hpp:300): q_chain is what the chain's flush wrote for the panel (this workgroup,
+            // phases ago, barriers in between)
+            auto add_tile = [&](const f32x16 (&acc)[4], int c0) {
+                const bool lane_ok = (n < 16) || (c0 + kPanel < b);
+                if (c0 + 2 * kPanel <= b) wtile_add_to_q<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane, dq);
+                else wtile_add_to_q<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane, dq);
+            };
+            if (hasA) add_tile(accA, cA);
+            if (hasB) add_tile(accB, cB);
         }
         if (SYM) {
             auto store_tile = [&](const f32x16 (&acc)[4], int c0) {
@@ -1013,7 +1115,9 @@ struct GridTeams {
     uint32_t tag_base = 0;
 };
 
-template <typename U, bool SYM, bool EXACT>
+// (MIR: every block of the launch takes the resident form or a team -- the host checks; the streaming form below, with its
+//  epilogue kernel, reads the packed upper-triangular storage)
+template <typename U, bool SYM, bool EXACT, bool MIR = false>
 __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, int resident_max, GridTeams teams) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* io = smem;                                   // [2][4][32][65]: mm, ulog, hvt, eta -> mu, gamma, d, eta'
@@ -1042,7 +1146,7 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
         tm.size = teams.size[blockIdx.x];
         tm.gran = teams.gran + teams.goff[tb];
         tm.tag_base = teams.tag_base;
-        grid_block_resident<U, SYM, EXACT>(A, io, la, dg, cy, qx, s_act, A.blocks[tb], wave, lane, n_models, dq, tab, tm);
+        grid_block_resident<U, SYM, EXACT, MIR>(A, io, la, dg, cy, qx, s_act, A.blocks[tb], wave, lane, n_models, dq, tab, tm);
         __syncthreads();
     }
     for (;;) {
@@ -1052,9 +1156,9 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
         __syncthreads();
         if (blk >= A.n_blocks) break;
         const BlockDesc bd = A.blocks[blk];
-        if (bd.size <= resident_max) {
+        if (MIR || bd.size <= resident_max) {
             // q of the whole block fits the updater waves' accumulator registers: resident form (above)
-            grid_block_resident<U, SYM, EXACT>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
+            grid_block_resident<U, SYM, EXACT, MIR>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
             continue;
         }
         const int64_t s0 = bd.start;

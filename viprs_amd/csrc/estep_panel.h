@@ -1304,7 +1304,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     // chain = SNPs already visited, their q keeps accumulating for the next
                     // sweep); upper-triangular form: right of the chain only (the rest is the
                     // reference's second pass)
+#if defined(PANEL_TIMING_NO_SECOND_PASS) && PANEL_TIMING_NO_SECOND_PASS + 0 >= 2     // (timing experiments only: wrong results)
+                    const bool active = (c < b) && cp > p;
+#else
                     const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
+#endif
                     auto hand_off = [&]() {
                         if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
                             // hand panel p+1 (now carrying a_0 .. a_{p-1}) to the other members
@@ -1346,6 +1350,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                     strip_update<U, CPL, false, kDepth>(base + (int64_t)rr0 * stride + c, stride, last_row, mvec, tgt);
                             }
                         }
+                        if (k == uw) PPROF(6, wave == 1);
                         hand_off();
                     } else {
                         if (any_a && active) {
@@ -1363,7 +1368,11 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     // of the same panel -- by the member that owns the panel's strip, on its last updater wave (the first one
                     // carries the priority strip and the hand-off the rest of the team waits for).  The staging of the next
                     // diagonal tile into the same buffer waits for it (s_ddone; LDS executes a wave's operations in order).
+#ifdef PANEL_TIMING_NO_SECOND_PASS           // (timing experiments only: wrong results)
+                    if (false) {
+#else
                     if (any_ed && own(rr0)) {
+#endif
                         float* __restrict__ sp = ls + loc(rr0 + lane);
                         *sp = diag_lower_update(lT + (pp & 1) * kPanel * kPanel, edvec, *sp, lane);
                     }
