@@ -59,7 +59,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg3max"],
                     help="cfg3max = cfg3 with its largest block replaced by a 6 000-SNP one (BASELINE's clip limit)")
-    ap.add_argument("--low-memory", action="store_true", help="upper-triangular LD (reference default)")
+    ap.add_argument("--symmetric", action="store_true",
+                    help="symmetric LD (low_memory=False) as the primary workload.  Default: the upper-triangular form, what "
+                         "VIPRS() runs by default (low_memory=True, VIPRS.py:75) -- since round 5 its sweep is level with the symmetric one")
+    ap.add_argument("--low-memory", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
     ap.add_argument("--ld-dtype", default="float32", choices=["float32", "int8", "int16"])
     ap.add_argument("--precision", default="float32", choices=["float32", "float64"],
                     help="state type (the reference's float_precision, VIPRS.py:72); float64: spike_slab only, no CPU leg")
@@ -86,7 +89,11 @@ def parse_args():
                     help="untimed sweeps of the primary workload BEFORE the --warmup steps (the first ~25 sweeps of a fresh process "
                          "run 2 %% slower: clocks and TLBs; a fit runs hundreds of iterations); reported as config.prewarm_s")
     ap.add_argument("--seed", type=int, default=7209)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.symmetric and args.low_memory:
+        ap.error("--symmetric and --low-memory exclude each other")
+    args.low_memory = not args.symmetric
+    return args
 
 
 def config_sizes(config, seed):
@@ -469,19 +476,21 @@ def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exa
     device reduction of the partial sums + its read-back, the host's M-step / ELBO / stopping rules."""
     from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
     from viprs_amd.model import VIPRS, VIPRSMix
-    gdl = ArrayDataLoader({1: LDArrays(symmetric=(ld.ld_left_bound, ld.ld_indptr, ld.ld_data), dq_scale=ld.dq_scale)},
+    form = (ld.ld_left_bound, ld.ld_indptr, ld.ld_data)
+    lm = bool(ld.low_memory)
+    gdl = ArrayDataLoader({1: LDArrays(upper=form, dq_scale=ld.dq_scale) if lm else LDArrays(symmetric=form, dq_scale=ld.dq_scale)},
                           {1: SumstatsArrays(ss.std_beta, ss.n_per_snp)}, n=float(ss.n))
     stamps = []
     cb = lambda i: stamps.append(time.perf_counter())
     out = {"name": f"fit_iteration {kind}", "unit": "ms per EM iteration", "iterations": iters, "warmup_iterations": warm,
-           "math_mode": math_mode, "snps": int(ld.m)}
+           "math_mode": math_mode, "snps": int(ld.m), "low_memory": lm}
     if kind.startswith("VIPRSGrid"):
         from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
         from viprs_amd.model.gridsearch.VIPRSGrid import VIPRSGrid
         grid = HyperparameterGrid(n_snps=gdl.m)
         grid.generate_pi_grid(steps=8)
         grid.generate_sigma_epsilon_grid(steps=4)
-        model = VIPRSGrid(gdl, grid, low_memory=False, device=device, math_mode=math_mode)
+        model = VIPRSGrid(gdl, grid, low_memory=lm, device=device, math_mode=math_mode)
         model.fit(max_iter=warm + iters, min_iter=warm + iters + 1, batched=True, on_iteration=cb)
         plan = next(iter(model._plans.values()))
         out["models"] = int(model.n_models)
@@ -489,10 +498,10 @@ def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exa
         # a FIXED start (the reference draws pi and h2 at random when none is given, VIPRS.py:260-292: run-to-run
         # different trajectories): pi = 0.01, sigma_epsilon = 0.8, the start of the sweep benchmark
         if kind.startswith("VIPRSMix"):
-            model = VIPRSMix(gdl, K=4, low_memory=False, device=device, math_mode=math_mode)
+            model = VIPRSMix(gdl, K=4, low_memory=lm, device=device, math_mode=math_mode)
             theta = {"pis": np.full(4, 0.01 / 4), "sigma_epsilon": 0.8}
         else:
-            model = VIPRS(gdl, low_memory=False, device=device, math_mode=math_mode)
+            model = VIPRS(gdl, low_memory=lm, device=device, math_mode=math_mode)
             theta = {"pi": 0.01, "sigma_epsilon": 0.8}
         out["theta_0"] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in theta.items()}
         model.fit(max_iter=warm + iters, min_iter=warm + iters + 1, theta_0=theta, on_iteration=cb)
@@ -749,48 +758,57 @@ def main():
     weak = None
     if not args.no_secondary and args.model == "spike_slab" and args.precision == "float32":
         half = max(5, args.steps // 2)
-        if world == 1 and not args.low_memory and args.ld_dtype == "float32" and args.config != "cfg1":
-            # configs[3] / configs[4] on the LD plan that is already resident (symmetric fp32)
+        if world == 1 and args.low_memory and args.ld_dtype == "float32" and args.config != "cfg1":
+            # `value` is the reference's DEFAULT LD form (low_memory=True, VIPRS.py:75: the upper-triangular store, swept over
+            # its mirror image on the device); the secondaries: the same workload in the symmetric form, configs[3] / configs[4]
+            # in both forms, the published int8 store format, float64 state, math_mode=fast, the EM iteration around the sweep
             cfgk = args.config
-            for model2, w2, nm in (("mixture", 4, "configs[3]: sparse mixture prior K=4, symmetric fp32 LD"),
-                                   ("grid", 32, "configs[4]: grid of 32 (sigma_eps x pi) models batched per SNP, symmetric fp32 LD")):
-                sw2 = Sweep(args, ld, ss, inp, device, model2, w2, False, plan=sw.plan)
-                secondary.append(measure_secondary(nm, sw2, half, barrier, args.math, f"{cfgk}_float32_sym_{model2}{w2}"))
+            UP = "upper-triangular fp32 LD (low_memory=True, the reference's default form)"
+            SY = "symmetric fp32 LD (low_memory=False)"
+            ld_s, ss_s, inp_s, _ = build_workload(args, sizes_all, None, args.seed, False, np.dtype("float32"), data=False)
+            sw_s = Sweep(args, ld_s, ss_s, inp_s, device, "spike_slab", 1, False)
+            secondary.append(measure_secondary(SY + ", spike-and-slab", sw_s, half, barrier, args.math, f"{cfgk}_float32_sym"))
+            for model2, w2, nm in (("mixture", 4, "configs[3]: sparse mixture prior K=4"),
+                                   ("grid", 32, "configs[4]: grid of 32 (sigma_eps x pi) models batched per SNP")):
+                # on the LD plans that are already resident: the primary (upper-triangular) one, then the symmetric one
+                sw2 = Sweep(args, ld, ss, inp, device, model2, w2, True, plan=sw.plan)
+                secondary.append(measure_secondary(f"{nm}, {UP}", sw2, half, barrier, args.math, f"{cfgk}_float32_upper_{model2}{w2}"))
                 sw2.close()
-            # the reference's DEFAULT LD form (low_memory=True, VIPRS.py:75): upper-triangular store + second pass;
-            # fp32, and int8 (dq_scale = 1/127): the format of the reference's published LD stores (docs/download_ld.md:6-10)
-            for dt2, nm in ((np.dtype("float32"), "upper-triangular fp32 LD (low_memory=True, the reference's default form), spike-and-slab"),
-                            (np.dtype("int8"), "upper-triangular int8 LD (low_memory=True + the published store format), spike-and-slab")):
-                ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, dt2, data=False)
-                sw_u = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True)
-                secondary.append(measure_secondary(nm, sw_u, half, barrier, args.math, f"{cfgk}_{dt2.name}_upper"))
-                if dt2.itemsize == 1:
-                    # float_precision='float64' (VIPRS.py:72) on the same plan: the panel-walking kernels of estep_tile.h
-                    sw_d = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan, precision="float64")
-                    secondary.append(measure_secondary("float64 state (float_precision='float64'), upper-triangular int8 LD, spike-and-slab",
-                                                       sw_d, half, barrier, "exact", f"{cfgk}_int8_upper_f64"))
-                    secondary[-1]["dtype"] = "f64"
-                    sw_d.close()
-                if args.math == "exact":
-                    # math_mode = fast (v_exp_f32 / v_rcp_f32 sigmoid; deviations of the size a one-ulp change of the inputs
-                    # causes, tests/test_gpu_fast_math.py) on the same plan and inputs: the chain step is what changes
-                    sw_f = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan)
-                    sw_u.plan.set_math_mode("fast")
-                    secondary.append(measure_secondary("math_mode=fast: " + nm, sw_f, half, barrier, "fast"))
-                    sw_u.plan.set_math_mode("exact")
-                    secondary[-1]["chain_ns_per_snp"] = chain_ns_per_snp(args, device, "fast", True)
-                    sw_f.close()
-                sw_u.close()
-                del ld_u, sw_u
+                sw2 = Sweep(args, ld_s, ss_s, inp_s, device, model2, w2, False, plan=sw_s.plan)
+                secondary.append(measure_secondary(f"{nm}, {SY}", sw2, half, barrier, args.math, f"{cfgk}_float32_sym_{model2}{w2}"))
+                sw2.close()
             if args.math == "exact":
-                sw_f = Sweep(args, ld, ss, inp, device, "spike_slab", 1, False, plan=sw.plan)
-                sw.plan.set_math_mode("fast")
-                secondary.append(measure_secondary("math_mode=fast: symmetric fp32 LD, spike-and-slab (the headline configuration)",
-                                                   sw_f, half, barrier, "fast"))
-                sw.plan.set_math_mode("exact")
-                secondary[-1]["chain_ns_per_snp"] = chain_ns_per_snp(args, device, "fast", False)
+                # math_mode = fast (v_exp_f32 / v_rcp_f32 sigmoid; deviations of the size a one-ulp change of the inputs
+                # causes, tests/test_gpu_fast_math.py) on the same plans and inputs: the chain step is what changes
+                for nm, sw0, ld0, ss0, inp0, lm0 in ((UP, sw, ld, ss, inp, True), (SY, sw_s, ld_s, ss_s, inp_s, False)):
+                    sw_f = Sweep(args, ld0, ss0, inp0, device, "spike_slab", 1, lm0, plan=sw0.plan)
+                    sw0.plan.set_math_mode("fast")
+                    secondary.append(measure_secondary(f"math_mode=fast: {nm}, spike-and-slab", sw_f, half, barrier, "fast"))
+                    sw0.plan.set_math_mode("exact")
+                    secondary[-1]["chain_ns_per_snp"] = chain_ns_per_snp(args, device, "fast", lm0)
+                    sw_f.close()
+            sw_s.close()
+            del ld_s, sw_s
+            # int8 (dq_scale = 1/127): the format of the reference's published LD stores (docs/download_ld.md:6-10)
+            nm8 = "upper-triangular int8 LD (low_memory=True + the published store format), spike-and-slab"
+            ld_u, ss_u, inp_u, _ = build_workload(args, sizes_all, None, args.seed, True, np.dtype("int8"), data=False)
+            sw_u = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True)
+            secondary.append(measure_secondary(nm8, sw_u, half, barrier, args.math, f"{cfgk}_int8_upper"))
+            # float_precision='float64' (VIPRS.py:72) on the same plan: the panel-walking kernels of estep_tile.h
+            sw_d = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan, precision="float64")
+            secondary.append(measure_secondary("float64 state (float_precision='float64'), upper-triangular int8 LD, spike-and-slab",
+                                               sw_d, half, barrier, "exact", f"{cfgk}_int8_upper_f64"))
+            secondary[-1]["dtype"] = "f64"
+            sw_d.close()
+            if args.math == "exact":
+                sw_f = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan)
+                sw_u.plan.set_math_mode("fast")
+                secondary.append(measure_secondary("math_mode=fast: " + nm8, sw_f, half, barrier, "fast"))
+                sw_u.plan.set_math_mode("exact")
                 sw_f.close()
-            # the EM iteration around the sweep (VIPRS.py:979-1019): what a user of fit() pays per iteration
+            sw_u.close()
+            del ld_u, sw_u
+            # the EM iteration around the sweep (VIPRS.py:979-1019): what a user of fit() pays per iteration (default LD form)
             if args.config in ("cfg3", "cfg2"):
                 for kind in ("VIPRS", "VIPRSMix(K=4)", "VIPRSGrid(32 models, batched)"):
                     secondary.append(measure_fit_iteration(kind, ld, ss, device, math_mode=args.math))
@@ -825,8 +843,6 @@ def main():
             weak = other
             sw_w.close()
 
-    # the reference's DEFAULT LD form (low_memory=True) first among the secondaries: `value` is the symmetric form
-    secondary.sort(key=lambda e: 0 if str(e.get("name", "")).startswith("upper-triangular fp32") else 1)
     if rank == 0:
         traffic, traffic_src = None, None
         if world == 1:
@@ -869,8 +885,9 @@ def main():
                 "ld_entries_rank0": int(ld.ld_indptr[-1]), "ld_dtype": args.ld_dtype, "ld_kind": args.ld_kind,
                 "largest_block": int(np.max(sizes_all)),
                 "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
-                "primary": "`value` is the " + ("upper-triangular" if ld.low_memory else "symmetric") + " LD form; the other "
-                           "form (the reference's default is low_memory=True) is the FIRST entry of `secondary`",
+                "primary": "`value` is the " + ("upper-triangular LD form -- what VIPRS() runs by default (low_memory=True, VIPRS.py:75); "
+                                                "the symmetric form is the FIRST entry of `secondary`" if ld.low_memory else
+                                                "symmetric LD form (--symmetric); the reference's default is low_memory=True"),
                 "math_mode": args.math, "math_mode_effective": sw_math_effective, "skipped_snps_last_sweep_rank0": int(skipped),
                 "comm": comm_kind, "rccl_ranks": int(comm_ranks) if comm_kind == "rccl" else None,
                 "ranks": int(comm_ranks),
@@ -885,12 +902,13 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("estep_grid_mfma_kernel (one workgroup per LD block, LD read once for all models)"
-                           + (" + estep_grid_upper_epilogue_kernel" if ld.low_memory else "")) if args.model == "grid" else
+                           + ("; upper-triangular form: the second pass runs inside it, over the mirrored blocks" if ld.low_memory else "")) if args.model == "grid" else
                           ("estep_tile_f64_kernel (float64 state: one workgroup per LD block, two block-size classes on two "
-                           "streams" + (" + tile_f64_second_pass_dense_kernel" if ld.low_memory else "") + ")")
+                           "streams" + (" + tile_f64_second_pass_exact_kernel" if ld.low_memory else "") + ")")
                           if args.precision == "float64" else
                           ("estep_sweep_kernel (ONE launch per sweep: team workgroups for the large LD blocks, small-block workers "
-                           "behind them" + ("; the upper-triangular form's second pass runs inside it" if ld.low_memory else "") + ")"),
+                           "behind them" + ("; upper-triangular form: the dense blocks hold the mirrored upper triangle and the second "
+                                            "pass runs inside the sweep as strip updates into per-row sums" if ld.low_memory else "") + ")"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * n_gpus),
                 "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(bytes_ranks.sum()),
                 "kernel_ms_avg": k_max_ms, "kernel_ms_p10": pct(k_ms, 10), "kernel_ms_p50": pct(k_ms, 50),
@@ -900,14 +918,15 @@ def main():
                         "kernels' own streams); percentiles are rank 0's per-sweep kernel times",
             },
         }
-        if secondary and str(secondary[0].get("name", "")).startswith("upper-triangular fp32"):
-            # the same workload in the LD form VIPRS() runs by default (low_memory=True, VIPRS.py:75), at the top level too
+        # which LD form `value` is, at the top level too (the reference's default is low_memory=True, VIPRS.py:75)
+        out["default_ld_form"] = {"ld_form": "upper-triangular (low_memory=True, the reference's default)",
+                                  "is_value": bool(ld.low_memory),
+                                  "note": "`value` IS this form" if ld.low_memory else "`value` is the symmetric form (--symmetric)"}
+        if ld.low_memory and secondary and str(secondary[0].get("name", "")).startswith("symmetric fp32"):
             d0 = secondary[0]
-            out["default_ld_form"] = {"ld_form": "upper-triangular (low_memory=True, the reference's default)",
-                                      "value": d0["value"], "unit": d0["unit"], "ms_per_step": d0["ms_per_step"],
-                                      "kernel_ms_avg": d0["kernel_ms_avg"], "roofline_frac": d0["roofline_frac"],
-                                      "traffic_over_algorithmic": d0.get("traffic_over_algorithmic"),
-                                      "note": "`value` above is the symmetric form (low_memory=False); details of this entry: config.secondary[0]"}
+            out["symmetric_ld_form"] = {"value": d0["value"], "unit": d0["unit"], "ms_per_step": d0["ms_per_step"],
+                                        "kernel_ms_avg": d0["kernel_ms_avg"], "roofline_frac": d0["roofline_frac"],
+                                        "note": "the same workload with low_memory=False; details: config.secondary[0]"}
         if n_gpus > 1:
             # self-diagnosing multi-GPU line: what every rank held and how long its kernel took, next to the model
             out["per_rank"] = {

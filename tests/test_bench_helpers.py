@@ -191,7 +191,9 @@ def test_bench_main_two_ranks_end_to_end_over_the_file_transport(tmp_path, extra
         assert sum(pr["ld_blocks"]) == len(sizes) and max(pr["largest_block"]) == int(sizes.max())
         parts = bench.shard_blocks_lpt(sizes, 2)
         assert pr["snps"] == [int(sizes[p].sum()) for p in parts]
-        assert pr["algorithmic_bytes"] == [int(4 * (sizes[p] ** 2).sum() + 68 * sizes[p].sum()) for p in parts]
+        # (the default LD form is the reference's: upper-triangular, b (b - 1) / 2 stored entries per block, each used twice)
+        assert pr["algorithmic_bytes"] == [int(4 * ((sizes[p] ** 2).sum() - sizes[p].sum()) + 68 * sizes[p].sum()) for p in parts]
+        assert out["default_ld_form"]["is_value"] is True and "upper-triangular" in out["config"]["ld_form"]
         assert out["metric"] == "SNP-updates/sec/E-step (1M SNPs, ~1700 LD blocks)"          # BASELINE's metric, one workload
         assert out["weak_scaling"]["snps_per_gpu"] == int(sizes.sum()) and "INDEPENDENT" in out["weak_scaling"]["metric"]
         assert len(out["weak_scaling"]["kernel_ms_avg_per_rank"]) == 2

@@ -6,15 +6,16 @@
 #  profiles/pmc_traffic.json keyed by workload and stamped with the hash of the kernel sources it was collected on).
 # Kernel statistics in one pass, FETCH_SIZE / WRITE_SIZE each in its own --pmc pass (tools/profile.sh).
 CONFIGS=(
-  "sym|cfg3_float32_sym|"
-  "upper|cfg3_float32_upper|--low-memory"
-  "int8u|cfg3_int8_upper|--low-memory --ld-dtype int8"
-  "mix|cfg3_float32_sym_mixture4|--model mixture"
-  "grid|cfg3_float32_sym_grid32|--model grid"
-  "grid_upper|cfg3_float32_upper_grid32|--model grid --low-memory"
-  "f64|cfg3_int8_upper_f64|--low-memory --ld-dtype int8 --precision float64"
-  "fast|cfg3_float32_sym_fast|--math fast"
-  "fast_int8u|cfg3_int8_upper_fast|--math fast --low-memory --ld-dtype int8"
+  "upper|cfg3_float32_upper|"
+  "sym|cfg3_float32_sym|--symmetric"
+  "int8u|cfg3_int8_upper|--ld-dtype int8"
+  "mix_upper|cfg3_float32_upper_mixture4|--model mixture"
+  "mix|cfg3_float32_sym_mixture4|--symmetric --model mixture"
+  "grid_upper|cfg3_float32_upper_grid32|--model grid"
+  "grid|cfg3_float32_sym_grid32|--symmetric --model grid"
+  "f64|cfg3_int8_upper_f64|--ld-dtype int8 --precision float64"
+  "fast|cfg3_float32_upper_fast|--math fast"
+  "fast_int8u|cfg3_int8_upper_fast|--math fast --ld-dtype int8"
 )
 HERE="$(cd "$(dirname "$0")/.." && pwd)"
 if [ "$1" = "--summarize" ]; then
