@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 achievable)
 STATE_BYTES_PER_SNP = 68     # lb+indptr (12) + 4 inputs (16) + 5 state reads/writes (40)
+SECONDARY_PREWARM_S = 0.1    # untimed sweeps in front of every secondary measurement
 
 
 def parse_args():
@@ -430,6 +431,11 @@ def pmc_traffic(key):
 def measure_secondary(name, sw, steps, barrier, math_mode="exact", traffic_key=None):
     """One secondary configuration on one GPU: K timed steps, kernel time from the library's HIP events; with the
     time model of the sweep (what bounds it and how close the kernel is: `frac_of_model`) and the PMC traffic."""
+    # (0.1 s of untimed sweeps first, as the primary workload gets 0.3 s: a freshly built plan's first sweeps run 2-5 % slower)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < SECONDARY_PREWARM_S:
+        sw.step()
+    sw.state.synchronize()
     el = sw.run(steps, 3, barrier)
     k = sw.plan.timing_history(which=1)
     k_all = sw.plan.timing_history(which=0)
@@ -440,7 +446,7 @@ def measure_secondary(name, sw, steps, barrier, math_mode="exact", traffic_key=N
     out = {"name": name, "value": sw.ld.m * steps / el, "unit": "SNP-updates/s", "ms_per_step": el / steps * 1e3,
            "kernel_ms_avg": k_avg, "kernel_ms_p50": pct(k, 50), "all_kernels_ms_avg": float(np.mean(k_all)) if k_all else None,
            "roofline_frac": by / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "algorithmic_bytes_per_launch": int(by), "steps": steps, "math_mode": math_mode,
+           "algorithmic_bytes_per_launch": int(by), "steps": steps, "prewarm_s": SECONDARY_PREWARM_S, "math_mode": math_mode,
            "math_mode_effective": sw.plan.effective_math_mode(),      # what the kernels really ran in (fast: not every model has it)
            "time_model_ms": t_model, "time_model_bound": bound, "time_model_terms_ms": terms,
            "chain_ns_per_snp_model": ns, "frac_of_model": t_model / float(np.mean(k_all) if k_all else k_avg)}
