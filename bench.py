@@ -442,9 +442,16 @@ def measure_secondary(name, sw, steps, barrier, math_mode="exact", traffic_key=N
     by = sw.algorithmic_bytes()
     f64 = sw.state_itemsize != 4
     t_model, bound, ns, terms = sweep_time_model(np.diff(sw.ld.block_start), by, sw.model, math_mode, f64)
-    k_avg = float(np.mean(k))
+    # A secondary that re-uses a plan after other work sometimes shows ONE sweep of 2-3 x the kernel time right after the
+    # timing reset (seen with math_mode=fast on the plans of the exact runs; not reproducible outside this sequence,
+    # EXPERIMENTS.md round 5).  Such sweeps (> 1.5 x the median) are counted and left out of `kernel_ms_avg`; the plain mean of
+    # all sweeps stays beside it.
+    k_med = float(np.median(k))
+    k_in = [x for x in k if x <= 1.5 * k_med]
+    k_avg = float(np.mean(k_in))
     out = {"name": name, "value": sw.ld.m * steps / el, "unit": "SNP-updates/s", "ms_per_step": el / steps * 1e3,
-           "kernel_ms_avg": k_avg, "kernel_ms_p50": pct(k, 50), "all_kernels_ms_avg": float(np.mean(k_all)) if k_all else None,
+           "kernel_ms_avg": k_avg, "kernel_ms_avg_all_sweeps": float(np.mean(k)), "outlier_sweeps": len(k) - len(k_in),
+           "kernel_ms_p50": pct(k, 50), "all_kernels_ms_avg": float(np.mean(k_all)) if k_all else None,
            "roofline_frac": by / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": int(by), "steps": steps, "prewarm_s": SECONDARY_PREWARM_S, "math_mode": math_mode,
            "math_mode_effective": sw.plan.effective_math_mode(),      # what the kernels really ran in (fast: not every model has it)
@@ -786,13 +793,13 @@ def main():
             if args.math == "exact":
                 # math_mode = fast (v_exp_f32 / v_rcp_f32 sigmoid; deviations of the size a one-ulp change of the inputs
                 # causes, tests/test_gpu_fast_math.py) on the same plans and inputs: the chain step is what changes
-                for nm, sw0, ld0, ss0, inp0, lm0 in ((UP, sw, ld, ss, inp, True), (SY, sw_s, ld_s, ss_s, inp_s, False)):
-                    sw_f = Sweep(args, ld0, ss0, inp0, device, "spike_slab", 1, lm0, plan=sw0.plan)
+                # (on the plans' own state objects: where the allocator puts a state's arrays moves the sweep by up to 8 % --
+                #  EXPERIMENTS.md round 5 -- and the first state of a plan is what a fit uses)
+                for nm, sw0, lm0 in ((UP, sw, True), (SY, sw_s, False)):
                     sw0.plan.set_math_mode("fast")
-                    secondary.append(measure_secondary(f"math_mode=fast: {nm}, spike-and-slab", sw_f, half, barrier, "fast"))
+                    secondary.append(measure_secondary(f"math_mode=fast: {nm}, spike-and-slab", sw0, half, barrier, "fast"))
                     sw0.plan.set_math_mode("exact")
                     secondary[-1]["chain_ns_per_snp"] = chain_ns_per_snp(args, device, "fast", lm0)
-                    sw_f.close()
             sw_s.close()
             del ld_s, sw_s
             # int8 (dq_scale = 1/127): the format of the reference's published LD stores (docs/download_ld.md:6-10)
@@ -807,11 +814,9 @@ def main():
             secondary[-1]["dtype"] = "f64"
             sw_d.close()
             if args.math == "exact":
-                sw_f = Sweep(args, ld_u, ss_u, inp_u, device, "spike_slab", 1, True, plan=sw_u.plan)
                 sw_u.plan.set_math_mode("fast")
-                secondary.append(measure_secondary("math_mode=fast: " + nm8, sw_f, half, barrier, "fast"))
+                secondary.append(measure_secondary("math_mode=fast: " + nm8, sw_u, half, barrier, "fast"))
                 sw_u.plan.set_math_mode("exact")
-                sw_f.close()
             sw_u.close()
             del ld_u, sw_u
             # the EM iteration around the sweep (VIPRS.py:979-1019): what a user of fit() pays per iteration (default LD form)
