@@ -17,9 +17,14 @@
 //                        they also stage tile R[p, p+1] into LDS for the chain's next phase.
 //
 // Symmetric form: columns LEFT of the current panel (q of SNPs already visited) keep receiving the
-// later rows as well (they are what the next sweep starts from); upper-triangular form: the
-// reference's second pass (update_q_factor, e_step.hpp:331-337) is folded into the sweep -- the
-// updater waves extend per-row running sums by one panel of columns per phase (HalfTileRows below).
+// later rows as well (they are what the next sweep starts from).  Upper-triangular form: the
+// reference's second pass (update_q_factor, e_step.hpp:331-337) is folded into the sweep.  By default
+// (kFormMirror) the dense blocks hold the upper triangle MIRRORED into the lower one and the columns
+// left of the chain take the later rows exactly as in the symmetric form -- into per-row sums s, with
+// eta_diff as the multiplier: R[i, j] read as R[j, i], a row's sum in ascending column order, the
+// reference's dot bit for bit.  The round-4 form of that pass (kFormUpper: packed upper triangle,
+// per-row running sums extended by one panel of columns per phase through an LDS transposition,
+// HalfTileRows below) is kept behind VIPRS_UPPER_MIRROR=0.
 //
 // Large blocks (a single CU pulls only ~50 GB/s from HBM) are shared by a TEAM of TS workgroups on
 // TS CUs: see the comment at `team` in the kernel.
@@ -664,7 +669,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
-    // Upper-triangular form, integer LD: the 16-byte pieces of a DIAGONAL tile that lie on or left of the diagonal hold stored
+    // Packed upper-triangular form (kFormUpper), integer LD: the 16-byte pieces of a DIAGONAL tile that lie on or left of the diagonal hold stored
     // zeros; the lanes that would request them read the plan's 16 zero bytes instead (one hot cache line) -- in the chain's
     // tile staging and in the second pass.  int8 upper, cfg3: 0.517 -> 0.507 ms (builds alternating on one box).  What it
     // saves are REQUESTS through the vector-memory path, not HBM bytes: an int8 tile row is 64 bytes, half a cache line, and
