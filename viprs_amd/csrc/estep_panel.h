@@ -1531,7 +1531,6 @@ struct SweepArgs {
 
 template <typename U, typename MODEL, int FORM, int NW, int CPL>
 __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(SweepArgs S) {
-    constexpr bool SYM = FORM != kFormUpper;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wg = blockIdx.x;
     const int team_cls = wg < S.n_wg[0] ? 0 : (wg < S.n_wg[0] + S.n_wg[1] ? 1 : 2);
