@@ -310,7 +310,8 @@ class Sweep:
             self.plan = LDPlan.synthetic(ld, device=device, math_mode=args.math)
         else:
             self.plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, low_memory, device=device, math_mode=args.math)
-        self.state = DeviceState(self.plan, precision, model, width)
+        # (ranks sharing a device in a dry run: no placement probe -- its sweeps are not under the device lock)
+        self.state = DeviceState(self.plan, precision, model, width, placement="off" if Sweep.device_lock else None)
         self.model, self.width = model, width
         self.state_itemsize = np.dtype(precision).itemsize
         self.active = None
@@ -906,6 +907,8 @@ def main():
                                 if strong else f"one workload per GPU x{n_gpus}") if n_gpus > 1 else "single GPU",
                 "step": "device state re-init + one E-step sweep over all blocks",
                 "prewarm_s": args.prewarm_seconds,        # untimed sweeps before the W warm-up steps (steady-state clocks)
+                # where the state's per-SNP arrays were put: best of n allocations by a probe sweep (viprs_amd/plan.py)
+                "state_placement": getattr(sw.state, "placement", None),
                 "time_model_ms": model_ms,
                 "chain_ns_per_snp": chain_ns if world == 1 else None,
                 "secondary": secondary or None,

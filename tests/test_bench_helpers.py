@@ -132,7 +132,7 @@ class FakePlan:
     def close(self): pass
 
 class FakeState:
-    def __init__(self, plan, dtype, model, width): self.plan = plan
+    def __init__(self, plan, dtype, model, width, placement=None): self.plan = plan
     def upload(self, name, arr): assert arr.shape[0] == self.plan.m, (name, arr.shape, self.plan.m)
     def reset(self, pi): pass
     def e_step(self, dq, active=None, sync=True): self.plan.n += 1; time.sleep(0.001)
@@ -236,7 +236,7 @@ if "RANK" in os.environ:
         def last_skipped(self): return 7
         def close(self): pass
     class FakeState:
-        def __init__(self, plan, dtype, model, width): self.plan = plan
+        def __init__(self, plan, dtype, model, width, placement=None): self.plan = plan
         def upload(self, name, arr): assert arr.shape[0] == self.plan.m
         def reset(self, pi): pass
         def e_step(self, dq, active=None, sync=True): self.plan.n += 1; time.sleep(0.001)

@@ -96,3 +96,36 @@ def test_mirrored_grid_with_a_partial_last_tile_and_few_models(gpu):
     H.assert_state_equal(got, ref)
     cut = _run_grid(O, H.cut_far_field(ld), inp, g, st0, active, sweeps=3)
     assert np.max(np.abs(cut["q"] - ref["q"])) > 1e-4 * np.max(np.abs(ref["q"]))      # (the far field matters on this input)
+
+
+def test_state_placement_probe_hands_out_a_fresh_state(gpu):
+    """`DeviceState` of a large fp32 plan: several allocations are probed with a synthetic sweep and the fastest is kept
+    (viprs_amd/plan.py, EXPERIMENTS.md round 5).  What comes back is a fresh state -- all zeros -- whose sweeps equal those of
+    a state created without the probe, bit for bit."""
+    from viprs_amd.plan import DeviceState, LDPlan
+    sizes = [650] * 330                                            # 214 500 SNPs: above the probe's threshold
+    ld, ss, inp = syn.make_problem(sizes=sizes, low_memory=True, ld_dtype=np.int8, seed=64, kind="longrange")
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)
+    out = {}
+    for mode in ("off", "probe"):
+        ds = DeviceState(plan, "float32", "spike_slab", 1, placement=mode)
+        if mode == "off":
+            assert ds.placement is None
+        else:
+            p = ds.placement
+            assert p["candidates"] == DeviceState.PLACEMENT_CANDIDATES and 0 <= p["chosen"] < p["candidates"]
+            assert len(p["kernel_ms_min"]) == p["candidates"] and min(p["kernel_ms_min"]) > 0
+            for name in ("std_beta", "u_logs", "mu_mult", "var_gamma", "eta", "q", "eta_diff"):
+                assert not ds.download(name).any(), name           # handed out zeroed
+        ds.upload("std_beta", inp.std_beta)
+        for k in ("u_logs", "sqrt_half_var_tau", "mu_mult"):
+            ds.upload(k, getattr(inp, k))
+        ds.reset(inp.pi)
+        for _ in range(2):
+            ds.e_step(ld.dq_scale)
+        out[mode] = {k: ds.download(k) for k in H.STATE}
+        ds.close()
+    H.assert_state_equal(out["probe"], out["off"])
+    st0 = inp.state_copy()
+    H.assert_state_equal(out["probe"], H.run_oracle(ld, inp, st0, sweeps=2))
+    plan.close()

@@ -7,6 +7,7 @@ independent LD blocks, uploaded and re-laid-out for the panel kernels once; ever
 only moves per-SNP vectors.
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -260,18 +261,94 @@ class DeviceState:
         "var_mu": L.FIELD_VAR_MU, "eta": L.FIELD_ETA, "q": L.FIELD_Q, "eta_diff": L.FIELD_ETA_DIFF,
     }
 
-    def __init__(self, plan, float_precision="float32", model="spike_slab", width=1):
+    # Placement probe (see `_probe_placement`): candidates tried / smallest plan it is worth it for
+    PLACEMENT_CANDIDATES = 6
+    PLACEMENT_MIN_SNPS = 200_000
+
+    def __init__(self, plan, float_precision="float32", model="spike_slab", width=1, placement=None):
         self.plan = plan
         self.dtype = np.dtype(float_precision)
         self.model = model
         self.width = int(width)
-        kind = {"spike_slab": L.MODEL_SPIKE_SLAB, "mixture": L.MODEL_MIXTURE, "grid": L.MODEL_GRID}[model]
-        self._h = ctypes.c_void_p()
-        L.check(L.lib.viprs_state_create(ctypes.byref(self._h), plan.handle, _FLOAT_CODE[self.dtype], kind,
-                                         self.width))
+        self._kind = {"spike_slab": L.MODEL_SPIKE_SLAB, "mixture": L.MODEL_MIXTURE, "grid": L.MODEL_GRID}[model]
+        self._h = self._create()
+        self.placement = None
         if not hasattr(plan, "_states"):
             plan._states = weakref.WeakSet()
         plan._states.add(self)
+        mode = placement if placement is not None else os.environ.get("VIPRS_STATE_PLACEMENT", "probe")
+        if (mode == "probe" and self.dtype == np.float32 and model in ("spike_slab", "mixture")
+                and plan.m >= self.PLACEMENT_MIN_SNPS and plan.n_blocks > 0):
+            self._probe_placement()
+
+    def _create(self):
+        h = ctypes.c_void_p()
+        L.check(L.lib.viprs_state_create(ctypes.byref(h), self.plan.handle, _FLOAT_CODE[self.dtype], self._kind, self.width))
+        return h
+
+    def _probe_placement(self):
+        """WHERE the allocator puts a state's per-SNP arrays moves the stream-bound sweeps by up to 8 % (four levels
+        2.6 % apart on cfg3: same plan, same kernels, same memory counters -- EXPERIMENTS.md round 5); the level is fixed
+        for the life of the allocation.  So a large fp32 state is allocated `PLACEMENT_CANDIDATES` times, each candidate
+        sweeps a synthetic input a few times (a sweep from the standard start on typical hyper-parameters: every LD
+        entry is streamed), the fastest one is kept and handed out zeroed, the others are freed.  ~0.1 s once per fit;
+        `VIPRS_STATE_PLACEMENT=off` (or `placement="off"`) skips it.  `self.placement` records what was measured."""
+        from .utils import synthetic as syn
+        m, K, T = self.plan.m, self.width, self.dtype
+        rng = np.random.default_rng(12345)
+
+        class _SS:
+            n_per_snp = np.full(m, 1e5)
+        beta = (0.01 * rng.standard_normal(m)).astype(T)
+        if self.model == "spike_slab":
+            inp = syn.make_inputs(type("S", (), {"std_beta": beta, "n_per_snp": _SS.n_per_snp})())
+            fields = {"std_beta": beta, "u_logs": inp.u_logs, "sqrt_half_var_tau": inp.sqrt_half_var_tau, "mu_mult": inp.mu_mult}
+            pi0 = inp.pi
+        else:
+            mix = syn.make_mixture_inputs(_SS, K, float_precision=T)
+            pi0 = mix.pop("pi")
+            fields = dict(mix, std_beta=beta)
+        itemsize = np.dtype(self.plan.ld_dtype).itemsize
+        dq = 1.0 if np.issubdtype(np.dtype(self.plan.ld_dtype), np.floating) else 1.0 / (2 ** (8 * itemsize - 1) - 1)
+        own, handles, times = self._h, [self._h], []
+        try:
+            for _ in range(self.PLACEMENT_CANDIDATES - 1):
+                handles.append(self._create())
+
+            def sweeps(h, n):
+                self._h = h
+                self.plan.timing_reset()
+                for _ in range(n):
+                    self.reset(pi0)
+                    self.e_step(dq, sync=False)
+                self.synchronize()
+                return self.plan.timing_history(which=1)
+            for h in handles:
+                self._h = h
+                for k, a in fields.items():
+                    self.upload(k, a)
+            sweeps(handles[0], 40)                                   # clocks up before anything is compared
+            times = [[] for _ in handles]
+            for _ in range(2):                                       # two rounds: no candidate is only measured early
+                for i, h in enumerate(handles):
+                    times[i] += list(sweeps(h, 5))
+            best = int(np.argmin([min(t) for t in times]))
+            self._h = handles[best]
+            zero = {k: np.zeros(self._shape(k), dtype=T) for k in
+                    ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult", "var_gamma", "var_mu", "eta", "q", "eta_diff")}
+            if self.model == "mixture":
+                zero["log_null_pi"] = np.zeros(m, dtype=T)
+            for k, a in zero.items():                                # handed out as a fresh state: all zeros
+                self.upload(k, a)
+            self.plan.timing_reset()
+            self.placement = {"candidates": len(handles), "chosen": best,
+                              "kernel_ms_min": [round(float(min(t)), 4) for t in times]}
+        finally:
+            keep = self._h if self._h in handles else own
+            for h in handles:
+                if h is not keep and h:
+                    L.lib.viprs_state_destroy(h)
+            self._h = keep
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
