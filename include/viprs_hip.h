@@ -130,6 +130,13 @@ int viprs_plan_info(const viprs_plan* plan, int key, int64_t* value);
 /* Copies the planner's block boundaries (n_blocks + 1 entries) */
 int viprs_plan_get_blocks(const viprs_plan* plan, int64_t* block_start, int32_t* block_kind);
 int viprs_plan_set_math_mode(viprs_plan* plan, int math_mode);
+/* Which LD blocks the following sweeps visit: one byte per block in SNP order (the order of viprs_plan_get_blocks), non-zero =
+ * swept; NULL = every block again.  The reference fits one model per chromosome by default (bin/viprs_fit:232-238, fan-out
+ * :1079-1086) and each of those fits stops at its own iteration (VIPRS.py:1046-1094); with the chromosomes' blocks in ONE
+ * plan (viprs_state_set_groups below) a converged chromosome's blocks leave the sweep this way -- its state stays as its
+ * last E-step left it.  Host-side list surgery over a few thousand descriptors; LD and per-SNP arrays do not move.
+ * Not supported by the batched grid kernel (VIPRS_EUNSUPPORTED from viprs_state_e_step on a grid state). */
+int viprs_plan_set_active_blocks(viprs_plan* plan, const uint8_t* active, int64_t n_blocks);
 
 /* ---- one-shot calls on host buffers: the drop-ins for the Cython entry points ------------ */
 /* Argument order and meaning follow e_step_cpp.pyx:91-122 after the plan handle (which stands
@@ -246,6 +253,27 @@ int viprs_state_sums_columns_begin(viprs_state* state, int n, const double* cols
 int viprs_state_sums_columns_end(viprs_state* state, double* out);
 /* Per-column re-initialisation of a grid state: var_gamma[:, g] = pi_g, everything else 0.         */
 int viprs_state_reset_column(viprs_state* state, int g, double pi);
+
+/* ---- SNP groups: one spike-and-slab model per chromosome, all chromosomes in ONE plan -----------------------------
+ * The reference's default mode (bin/viprs_fit:232-238: `split_by_chromosome()` unless --genomewide) fits an independent
+ * VIPRS model per chromosome, each with its own (pi, tau_beta, sigma_epsilon), M-step sums, ELBO and stopping iteration.
+ * A chromosome-sized fit cannot fill the device (its sweep is bound by the chain of its largest LD block), 22 of them in
+ * one plan cost one genome-wide sweep.  A GROUP is a contiguous SNP range made of whole LD blocks:
+ *   viprs_state_set_groups        group g = SNPs [group_start[g], group_start[g+1]); n_groups + 1 entries covering 0 .. m;
+ *                                 n_groups = 0 removes the groups.  Spike-and-slab states only.
+ *   viprs_state_prep_groups       viprs_state_prep with per-group scalars: n rows of 6 doubles
+ *                                 (group, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda); only the listed
+ *                                 groups' SNPs are rewritten (a converged group keeps the inputs of its last E-step).
+ *   viprs_state_sums_groups_begin n rows of 2 doubles (group, one_plus_lambda): the VIPRS_N_SUMS sums of viprs_state_sums
+ *                                 per listed group, one launch; [0] is the plain sum of gamma (no per-SNP weights).
+ *   viprs_state_sums_groups_end   n rows of VIPRS_N_SUMS doubles in the order of the rows given to `begin`.
+ * A group's inputs and sums are bit-identical to those of a plan that holds only that group's blocks (the reduction over
+ * a group uses the workgroup count and element order a plan of that size would use).  With viprs_state_set_comm the rows
+ * are all-rank sums (one all-gather for all groups). */
+int viprs_state_set_groups(viprs_state* state, int n_groups, const int64_t* group_start);
+int viprs_state_prep_groups(viprs_state* state, int n, const double* params);
+int viprs_state_sums_groups_begin(viprs_state* state, int n, const double* rows);
+int viprs_state_sums_groups_end(viprs_state* state, double* out);
 
 /* ---- multi-GPU: RCCL over xGMI for the scalar reductions of the EM iteration -------------------------
  * One process per GPU; LD blocks are sharded over the ranks (independent units: within one E-step call

@@ -66,17 +66,18 @@ def install_stubs():
     return GWADataLoader
 
 
-def make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed, ld_kind="ar1"):
+def make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed, ld_kind="ar1", n_of=None, h2_of=None):
     """Array-backed loader with the attributes VIPRS.__init__/BayesPRSModel.__init__ read
     (VIPRS.py:153-191, BayesPRSModel.py:59-142)."""
     lds, sss, inputs = {}, {}, {}
     for ci, (chrom, sizes) in enumerate(chrom_sizes.items()):
         ld_sym = syn.make_ld(sizes, low_memory=False, ld_dtype=ld_dtype, seed=seed + ci, kind=ld_kind)
         ld_up = syn.make_ld(sizes, low_memory=True, ld_dtype=ld_dtype, seed=seed + ci, kind=ld_kind)
-        ss = syn.make_sumstats(ld_sym, seed=seed + ci)
+        ss_kw = dict(n=(n_of or {}).get(chrom, 1e5), h2=(h2_of or {}).get(chrom, 0.2))
+        ss = syn.make_sumstats(ld_sym, seed=seed + ci, **ss_kw)
         # marginal effects of a second cohort on the same LD (same causal effects, independent noise): what
         # BayesPRSModel.pseudo_validate() scores the fit against (BayesPRSModel.py:184-187, 397-410)
-        ss.validation_std_beta = syn.make_sumstats(ld_sym, seed=seed + ci, noise_seed=seed + ci + 5000).std_beta
+        ss.validation_std_beta = syn.make_sumstats(ld_sym, seed=seed + ci, noise_seed=seed + ci + 5000, **ss_kw).std_beta
 
         class LOP:
             def __init__(self, l):
@@ -227,9 +228,69 @@ def grid_cases():
         print(name, "pseudo R2", pseudo_r2, "ELBO", out["elbo"], "nit", out["nit"], out["messages"][:2])
 
 
+def sub_loader(GWADataLoader, gdl, c):
+    """What `gdl.split_by_chromosome()[c]` hands to a per-chromosome fit (bin/viprs_fit:232-238): a loader that holds
+    chromosome c only."""
+    sub = GWADataLoader()
+    sub.ld, sub.sumstats_table, sub.genotype = {c: gdl.ld[c]}, {c: gdl.sumstats_table[c]}, None
+    sub.shapes = {c: gdl.shapes[c]}
+    sub.m = int(gdl.shapes[c])
+    sub.n = float(np.max(gdl.sumstats_table[c].n_per_snp))
+    sub.get_ld_matrices = lambda: sub.ld
+    return sub
+
+
+def per_chromosome_cases():
+    """The reference's DEFAULT mode: one independent VIPRS model per chromosome (bin/viprs_fit:232-238, :1079-1086).  Every
+    chromosome is fitted by the reference ON ITS OWN loader; the fixture carries each fit's trajectory and posterior.
+    Chromosomes of different size, sample size and heritability, so that the fits stop at different iterations."""
+    GWADataLoader = sys.modules["magenpy"].GWADataLoader
+    from viprs.model.VIPRS import VIPRS
+    cases = [
+        ("fitchr_ss_4chr_upper", {19: [260, 140], 20: [330, 200, 90], 21: [180], 22: [150, 300]}, dict(low_memory=True), {},
+         dict(n_of={19: 1e5, 20: 4e4, 21: 2e5, 22: 1e5}, h2_of={19: 0.3, 20: 0.1, 21: 0.05, 22: 0.2})),
+        ("fitchr_ss_3chr_lr_int8_upper", {20: [420, 130], 21: [300, 180], 22: [250]}, dict(low_memory=True, dequantize_on_the_fly=True),
+         dict(ld_kind="longrange", ld_dtype=np.int8), dict(n_of={20: 1e5, 21: 5e4, 22: 1e5}, h2_of={20: 0.2, 21: 0.3, 22: 0.08})),
+        ("fitchr_ss_2chr_sym_fixed_sigma", {21: [260, 200], 22: [310]}, dict(low_memory=False, fix_params={"sigma_epsilon": 0.9}), {},
+         dict(n_of={21: 1e5, 22: 6e4})),
+    ]
+    for name, chrom_sizes, kw, ld_kw, data_kw in cases:
+        if ONLY and name not in ONLY:
+            continue
+        ld_dtype, ld_kind = ld_kw.get("ld_dtype", np.float32), ld_kw.get("ld_kind", "ar1")
+        gdl, inputs = make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed=611, ld_kind=ld_kind, **data_kw)
+        theta_0 = {"pi": 0.01, "sigma_epsilon": 0.8}
+        out = dict(ld_kind=ld_kind, dequantize_on_the_fly=bool(kw.get("dequantize_on_the_fly", False)),
+                   float_precision=str(kw.get("float_precision", "float32")), theta0_pi=0.01, theta0_sigma_epsilon=0.8,
+                   low_memory=kw.get("low_memory", True), K=0,
+                   fix_sigma_epsilon=kw.get("fix_params", {}).get("sigma_epsilon", np.nan), chroms=np.array(sorted(chrom_sizes)))
+        for c in sorted(chrom_sizes):
+            model = VIPRS(sub_loader(GWADataLoader, gdl, c), **{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
+            model.fit(max_iter=100, theta_0=dict(theta_0), disable_pbar=True)
+            model.validation_std_beta = {c: inputs[c][2].validation_std_beta}
+            ld_sym, ld_up, ss = inputs[c]
+            out.update({
+                f"n_{c}": model.n, f"elbo_history_{c}": np.array(model.history["ELBO"], dtype=np.float64),
+                f"nit_{c}": model.optim_result.nit, f"success_{c}": bool(model.optim_result.success),
+                f"message_{c}": str(model.optim_result.message), f"final_pi_{c}": np.float64(model.pi),
+                f"final_tau_beta_{c}": np.float64(model.tau_beta), f"final_sigma_epsilon_{c}": np.float64(model.sigma_epsilon),
+                f"final_sigma_g_{c}": np.float64(model._sigma_g), f"pseudo_r2_{c}": np.float64(model.pseudo_validate()),
+                f"sizes_{c}": np.array(chrom_sizes[c]), f"std_beta_{c}": ss.std_beta, f"n_per_snp_{c}": ss.n_per_snp,
+                f"rho_{c}": ld_sym.rho, f"validation_std_beta_{c}": ss.validation_std_beta, f"pip_{c}": model.pip[c],
+                f"post_mean_beta_{c}": model.post_mean_beta[c], f"post_var_beta_{c}": model.post_var_beta[c], f"q_{c}": model.q[c]})
+            if ld_kind != "ar1":
+                out[f"ld_upper_indptr_{c}"] = ld_up.ld_indptr
+                out[f"ld_upper_data_{c}"] = ld_up.ld_data
+            print(name, "chr", c, "nit", model.optim_result.nit, model.optim_result.message, "ELBO", model.history["ELBO"][-1],
+                  "pi", model.pi, "sig_eps", model.sigma_epsilon)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
 ONLY = sys.argv[1:]          # e.g. `make_fit_golden.py fit_ss_lr_int8_upper`: regenerate the named fixtures only
 
 if __name__ == "__main__":
     main()
     if not ONLY or any(n.startswith("fitgrid") for n in ONLY):
         grid_cases()
+    if not ONLY or any(n.startswith("fitchr") for n in ONLY):
+        per_chromosome_cases()

@@ -159,7 +159,7 @@ dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:{port}", ra
 from oracle import oracle as O
 from tests.test_zarr_ld import _loaders
 from viprs_amd.model import VIPRS
-from viprs_amd.parallel import TorchDistComm
+from tests.comm_torch import TorchDistComm
 import pathlib
 g_store, g_arr = _loaders(pathlib.Path({tmp!r}) / ("r" + sys.argv[1]), {{1: [60, 130, 45], 2: [80, 70]}})
 reads = []

@@ -66,6 +66,7 @@ _PROTOS = {
     "viprs_plan_info": (_i, [_vp, _i, _pi64]),
     "viprs_plan_get_blocks": (_i, [_vp, _vp, _vp]),
     "viprs_plan_set_math_mode": (_i, [_vp, _i]),
+    "viprs_plan_set_active_blocks": (_i, [_vp, _vp, _i64]),
     "viprs_e_step": (_i, [_vp, _i] + [_vp] * 9 + [_d, _i, _i]),
     "viprs_e_step_mixture": (_i, [_vp, _i, _i] + [_vp] * 10 + [_d, _i, _i]),
     "viprs_e_step_grid": (_i, [_vp, _i, _i] + [_vp] * 9 + [_d, _vp, _i, _i, _i]),
@@ -92,6 +93,10 @@ _PROTOS = {
     "viprs_state_sums_columns_begin": (_i, [_vp, _i, _vp]),
     "viprs_state_sums_columns_end": (_i, [_vp, _vp]),
     "viprs_state_reset_column": (_i, [_vp, _i, _d]),
+    "viprs_state_set_groups": (_i, [_vp, _i, _vp]),
+    "viprs_state_prep_groups": (_i, [_vp, _i, _vp]),
+    "viprs_state_sums_groups_begin": (_i, [_vp, _i, _vp]),
+    "viprs_state_sums_groups_end": (_i, [_vp, _vp]),
     "viprs_comm_unique_id": (_i, [_vp]),
     "viprs_comm_create": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
     "viprs_comm_destroy": (_i, [_vp]),

@@ -426,6 +426,17 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         // raw copy no longer needed: every block was repacked
         HIP_TRY(P->d_ld_raw.alloc(0));
     }
+    // the full lists, kept beside the ones a sweep visits (viprs_plan_set_active_blocks)
+    P->dense_all_h = P->dense_h;
+    P->ragged_all_h = P->ragged_h;
+    std::copy(P->class_begin, P->class_begin + 4, P->class_begin_all);
+    P->max_dense_all = P->max_dense;
+    P->max_ragged_all = P->max_ragged;
+    P->m_active = m;
+    if (!P->dense_h.empty()) {
+        HIP_TRY(P->d_dense_all.alloc(P->dense_h.size()));
+        HIP_TRY(hipMemcpy(P->d_dense_all.p, P->dense_h.data(), sizeof(BlockDesc) * P->dense_h.size(), hipMemcpyHostToDevice));
+    }
     // every copy / memset above went through the null stream; the plan's own streams are non-blocking
     // (not ordered with it), so nothing may still be in flight when the first sweep is launched
     HIP_TRY(hipDeviceSynchronize());
@@ -437,14 +448,15 @@ namespace viprs {
 // The dense blocks of an upper-triangular plan in the form the coming launch sweeps (see mirror_lower_kernel); the
 // conversion runs on the plan's stream, once per change of kernel family (a fit keeps to one).
 int ensure_upper_storage(viprs_plan* P, bool mirrored) {
-    if (!P->low_memory || P->dense_h.empty() || (P->mirror != 0) == mirrored) return VIPRS_OK;
+    // (every dense block of the plan, whatever subset the sweeps currently visit: the flag is per plan)
+    if (!P->low_memory || P->dense_all_h.empty() || (P->mirror != 0) == mirrored) return VIPRS_OK;
     int max_np = 0;
-    for (const BlockDesc& d : P->dense_h) max_np = std::max(max_np, (d.size + kPanel - 1) / kPanel);
-    const dim3 grid((unsigned)std::min(max_np * (max_np + 1) / 2, 512), (unsigned)P->dense_h.size());
+    for (const BlockDesc& d : P->dense_all_h) max_np = std::max(max_np, (d.size + kPanel - 1) / kPanel);
+    const dim3 grid((unsigned)std::min(max_np * (max_np + 1) / 2, 512), (unsigned)P->dense_all_h.size());
     switch (P->ld_dtype) {
-        case VIPRS_LD_F32: mirror_lower_kernel<float><<<grid, 256, 0, P->stream>>>((float*)P->d_ld_dense.p, P->d_dense.p, mirrored ? 1 : 0); break;
-        case VIPRS_LD_I8: mirror_lower_kernel<int8_t><<<grid, 256, 0, P->stream>>>((int8_t*)P->d_ld_dense.p, P->d_dense.p, mirrored ? 1 : 0); break;
-        case VIPRS_LD_I16: mirror_lower_kernel<int16_t><<<grid, 256, 0, P->stream>>>((int16_t*)P->d_ld_dense.p, P->d_dense.p, mirrored ? 1 : 0); break;
+        case VIPRS_LD_F32: mirror_lower_kernel<float><<<grid, 256, 0, P->stream>>>((float*)P->d_ld_dense.p, P->d_dense_all.p, mirrored ? 1 : 0); break;
+        case VIPRS_LD_I8: mirror_lower_kernel<int8_t><<<grid, 256, 0, P->stream>>>((int8_t*)P->d_ld_dense.p, P->d_dense_all.p, mirrored ? 1 : 0); break;
+        case VIPRS_LD_I16: mirror_lower_kernel<int16_t><<<grid, 256, 0, P->stream>>>((int16_t*)P->d_ld_dense.p, P->d_dense_all.p, mirrored ? 1 : 0); break;
         default: return fail(VIPRS_EINVAL, "dense blocks with unsupported LD dtype");
     }
     HIP_TRY(hipGetLastError());
@@ -653,6 +665,57 @@ int viprs_plan_get_blocks(const viprs_plan* P, int64_t* block_start, int32_t* bl
         if (block_kind) block_kind[i] = P->blocks[i].kind;
     }
     block_start[P->blocks.size()] = P->m;
+    return VIPRS_OK;
+}
+
+// Which LD blocks the following sweeps visit: `active` = one byte per block in SNP order (viprs_plan_get_blocks), NULL =
+// every block again.  The size-sorted block lists the kernels work through are rebuilt from the full ones (a few thousand
+// descriptors: microseconds) and every schedule derived from them is forgotten; LD and per-SNP arrays do not move.
+int viprs_plan_set_active_blocks(viprs_plan* P, const uint8_t* active, int64_t n_blocks) {
+    if (!P) return fail(VIPRS_EINVAL, "null plan");
+    if (active && n_blocks != (int64_t)P->blocks.size()) return fail(VIPRS_EINVAL, "one flag per LD block of the plan is needed");
+    if (!active && !P->filtered) return VIPRS_OK;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipStreamSynchronize(P->stream));            // sweeps in flight read the lists
+    if (P->side_stream) HIP_TRY(hipStreamSynchronize(P->side_stream));
+    auto is_active = [&](const BlockDesc& d) {
+        if (!active) return true;
+        // P->blocks is in SNP order: the block that starts at d.start
+        auto it = std::lower_bound(P->blocks.begin(), P->blocks.end(), (int64_t)d.start,
+                                   [](const Block& b, int64_t s) { return b.start < s; });
+        return active[(size_t)(it - P->blocks.begin())] != 0;
+    };
+    P->dense_h.clear();
+    P->ragged_h.clear();
+    P->max_dense = P->max_ragged = 0;
+    P->m_active = 0;
+    int cb[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < P->dense_all_h.size(); ++i) {
+        const BlockDesc& d = P->dense_all_h[i];
+        if (!is_active(d)) continue;
+        const int cls = (int)i < P->class_begin_all[1] ? 0 : ((int)i < P->class_begin_all[2] ? 1 : 2);
+        for (int c = cls + 1; c < 4; ++c) ++cb[c];
+        P->dense_h.push_back(d);                          // (the full list is in descending order of size: so is this one)
+        P->max_dense = std::max(P->max_dense, d.size);
+        P->m_active += d.size;
+    }
+    std::copy(cb, cb + 4, P->class_begin);
+    for (const BlockDesc& d : P->ragged_all_h) {
+        if (!is_active(d)) continue;
+        P->ragged_h.push_back(d);
+        P->max_ragged = std::max(P->max_ragged, d.size);
+        P->m_active += d.size;
+    }
+    if (!P->dense_h.empty())
+        HIP_TRY(hipMemcpy(P->d_dense.p, P->dense_h.data(), sizeof(BlockDesc) * P->dense_h.size(), hipMemcpyHostToDevice));
+    if (!P->ragged_h.empty())
+        HIP_TRY(hipMemcpy(P->d_ragged.p, P->ragged_h.data(), sizeof(BlockDesc) * P->ragged_h.size(), hipMemcpyHostToDevice));
+    P->filtered = active != nullptr && (P->dense_h.size() != P->dense_all_h.size() || P->ragged_h.size() != P->ragged_all_h.size());
+    // schedules derived from the lists: rebuilt on the next launch that needs them
+    P->team_split = viprs_plan::TeamSplit();
+    P->grid_teams_built = false;
+    HIP_TRY(P->d_rowlist_dense.alloc(0));
+    HIP_TRY(P->d_rowlist_ragged.alloc(0));
     return VIPRS_OK;
 }
 

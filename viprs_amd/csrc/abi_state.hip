@@ -49,31 +49,49 @@ __global__ void prep_columns_kernel(const double* __restrict__ n, int64_t m, con
     shvt[off + i] = (T)(0.5 * vt);                                    // e_step_grid takes var_tau / 2 (e_step.hpp:616)
 }
 
+// the same for SNP GROUPS of a spike-and-slab state (one model per chromosome in one plan): blockIdx.y picks a row of
+// `params` (group, logit_pi, log_tau_beta, sigma_eps, tau_beta, one_plus_lambda); only the group's SNPs are written
+template <typename T>
+__global__ void prep_groups_kernel(const double* __restrict__ n, const int64_t* __restrict__ gstart,
+                                   const double* __restrict__ params, T* __restrict__ mu_mult, T* __restrict__ u_logs,
+                                   T* __restrict__ shvt, double* __restrict__ var_tau_out) {
+    const double* __restrict__ p = params + 6 * (int64_t)blockIdx.y;
+    const int g = (int)p[0];
+    const double logit_pi = p[1], log_tau_beta = p[2], sigma_eps = p[3], tau_beta = p[4], one_plus_lambda = p[5];
+    const int64_t end = gstart[g + 1];
+    for (int64_t i = gstart[g] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (int64_t)gridDim.x * blockDim.x) {
+        const double vt = n[i] * one_plus_lambda / sigma_eps + tau_beta;
+        var_tau_out[i] = vt;
+        mu_mult[i] = (T)(n[i] / (vt * sigma_eps));
+        u_logs[i] = (T)(logit_pi + 0.5 * (log_tau_beta - log(vt)));
+        shvt[i] = (T)sqrt(0.5 * vt);
+    }
+}
+
 constexpr int kSumsBlock = 256;
 constexpr int kNSums = VIPRS_N_SUMS;
+constexpr int kSumsMaxBlocks = 1024;
+// workgroups of the reduction over `count` SNPs (the same for a whole plan and for one group of it: a group's sums are
+// bit-identical to those of a plan that holds only that group)
+__host__ __device__ inline int sums_blocks(int64_t count) {
+    const int64_t nb = (count + kSumsBlock - 1) / kSumsBlock;
+    return (int)(nb < kSumsMaxBlocks ? nb : kSumsMaxBlocks);
+}
 
 // stage 1: per-workgroup partial sums (fixed assignment of elements to threads, tree reduction in
-// LDS: deterministic); stage 2 adds the partials in index order
+// LDS: deterministic); stage 2 adds the partials in index order.  `sums_body`: workgroup `bx` of `nb` over SNPs [i0, i1).
 template <typename T>
-__global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __restrict__ gam, const T* __restrict__ mu,
-                                                          const T* __restrict__ eta, const T* __restrict__ q,
-                                                          const T* __restrict__ ed, const T* __restrict__ beta,
-                                                          const double* __restrict__ var_tau, double one_plus_lambda,
-                                                          const double* __restrict__ weight, double* __restrict__ partials,
-                                                          const double* __restrict__ cols = nullptr) {
-    if (cols) {
-        // several columns of a grid state in one launch: blockIdx.y picks (column, one_plus_lambda)
-        const int64_t off = (int64_t)cols[2 * blockIdx.y] * m;
-        one_plus_lambda = cols[2 * blockIdx.y + 1];
-        gam += off; mu += off; eta += off; q += off; ed += off; var_tau += off;
-        partials += (int64_t)blockIdx.y * gridDim.x * kNSums;
-    }
+__device__ __forceinline__ void sums_body(int64_t i0, int64_t i1, int nb, int bx, const T* __restrict__ gam,
+                                          const T* __restrict__ mu, const T* __restrict__ eta, const T* __restrict__ q,
+                                          const T* __restrict__ ed, const T* __restrict__ beta,
+                                          const double* __restrict__ var_tau, double one_plus_lambda,
+                                          const double* __restrict__ weight, double* __restrict__ out) {
     __shared__ double red[kNSums][kSumsBlock];
     double acc[kNSums];
 #pragma unroll
     for (int k = 0; k < kNSums; ++k) acc[k] = 0.0;
     const double lo = 1e-15, hi = 1.0 - 1e-15;       // np.finfo(float64).resolution (VIPRS.py:509)
-    for (int64_t i = (int64_t)blockIdx.x * kSumsBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kSumsBlock) {
+    for (int64_t i = i0 + (int64_t)bx * kSumsBlock + threadIdx.x; i < i1; i += (int64_t)nb * kSumsBlock) {
         const double g = (double)gam[i], mud = (double)mu[i], vt = var_tau[i];
         const double zeta = g * (mud * mud + 1.0 / vt);                       // VIPRS.py:896
         acc[0] += weight ? g * weight[i] : g;                                  // sum_c mean(gamma_c) over merged chromosomes
@@ -100,13 +118,69 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
         }
         __syncthreads();
     }
-    if (threadIdx.x < kNSums) partials[(int64_t)blockIdx.x * kNSums + threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x < kNSums) out[threadIdx.x] = red[threadIdx.x][0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __restrict__ gam, const T* __restrict__ mu,
+                                                          const T* __restrict__ eta, const T* __restrict__ q,
+                                                          const T* __restrict__ ed, const T* __restrict__ beta,
+                                                          const double* __restrict__ var_tau, double one_plus_lambda,
+                                                          const double* __restrict__ weight, double* __restrict__ partials,
+                                                          const double* __restrict__ cols = nullptr) {
+    if (cols) {
+        // several columns of a grid state in one launch: blockIdx.y picks (column, one_plus_lambda)
+        const int64_t off = (int64_t)cols[2 * blockIdx.y] * m;
+        one_plus_lambda = cols[2 * blockIdx.y + 1];
+        gam += off; mu += off; eta += off; q += off; ed += off; var_tau += off;
+        partials += (int64_t)blockIdx.y * gridDim.x * kNSums;
+    }
+    sums_body<T>(0, m, (int)gridDim.x, (int)blockIdx.x, gam, mu, eta, q, ed, beta, var_tau, one_plus_lambda, weight,
+                 partials + (int64_t)blockIdx.x * kNSums);
+}
+
+// the sums of SNP groups of a spike-and-slab state: blockIdx.y picks a row (group, one_plus_lambda) of `rows`; group g is
+// reduced by sums_blocks(its SNPs) workgroups exactly as a plan of its own would be (the rest of the row's grid leaves)
+template <typename T>
+__global__ __launch_bounds__(kSumsBlock) void sums_groups_kernel(const int64_t* __restrict__ gstart, const double* __restrict__ rows,
+                                                                 const T* __restrict__ gam, const T* __restrict__ mu,
+                                                                 const T* __restrict__ eta, const T* __restrict__ q,
+                                                                 const T* __restrict__ ed, const T* __restrict__ beta,
+                                                                 const double* __restrict__ var_tau, double* __restrict__ partials) {
+    const int g = (int)rows[2 * blockIdx.y];
+    const int64_t i0 = gstart[g], i1 = gstart[g + 1];
+    const int nb = sums_blocks(i1 - i0);
+    if ((int)blockIdx.x >= nb) return;
+    sums_body<T>(i0, i1, nb, (int)blockIdx.x, gam, mu, eta, q, ed, beta, var_tau, rows[2 * blockIdx.y + 1], nullptr,
+                 partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kNSums);
 }
 
 // one wave per sum: lane l adds the partials of blocks l, l + 64, ... in order, then a fixed xor-shuffle
 // tree combines the 64 lanes -- a deterministic order whatever the timing
 __global__ void sums_final_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
     partials += (int64_t)blockIdx.x * n_blocks * kNSums;            // one workgroup per column (grid states)
+    out += (int64_t)blockIdx.x * kNSums;
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (k >= kNSums) return;
+    const bool is_max = (k == kNSums - 1);
+    double a = 0.0;
+    for (int b = lane; b < n_blocks; b += 64) {
+        const double v = partials[(int64_t)b * kNSums + k];
+        a = is_max ? fmax(a, v) : a + v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(a, off, 64);
+        a = is_max ? fmax(a, o) : a + o;
+    }
+    if (lane == 0) out[k] = a;
+}
+
+// the same per group: workgroup y adds the sums_blocks(group's SNPs) partials of row y (`stride` slots per row)
+__global__ void sums_final_groups_kernel(const double* __restrict__ partials, int stride, const int64_t* __restrict__ gstart,
+                                         const double* __restrict__ rows, double* __restrict__ out) {
+    const int g = (int)rows[2 * blockIdx.x];
+    const int n_blocks = sums_blocks(gstart[g + 1] - gstart[g]);
+    partials += (int64_t)blockIdx.x * stride * kNSums;
     out += (int64_t)blockIdx.x * kNSums;
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (k >= kNSums) return;
@@ -356,7 +430,7 @@ static int sums_enqueue_empty(viprs_state* S, int n, int group) {
 template <typename T>
 static int sums_enqueue(viprs_state* S, int64_t off, int64_t vt_off, double one_plus_lambda) {
     viprs_plan* P = S->plan;
-    const int nb = (int)std::min<int64_t>((P->m + kSumsBlock - 1) / kSumsBlock, 1024);
+    const int nb = sums_blocks(P->m);
     if (S->d_partials.n < (size_t)nb * kNSums) HIP_TRY(S->d_partials.alloc((size_t)nb * kNSums));
     if (!S->d_sums.p) HIP_TRY(S->d_sums.alloc(kNSums));
     // pinned landing buffer: kNSums doubles + the plan's device error word (no second synchronisation)
@@ -791,6 +865,141 @@ int viprs_state_reset_column(viprs_state* S, int g, double pi) {
             (double*)S->f[VIPRS_FIELD_ETA_DIFF].p + off, n, pi);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
+}
+
+
+// ---- SNP groups: one spike-and-slab model per chromosome, all of them in ONE plan / state (bin/viprs_fit:232-238 fits one
+// model per chromosome unless --genomewide; the chromosomes' LD blocks are independent, so their E-steps share one sweep)
+int viprs_state_set_groups(viprs_state* S, int n_groups, const int64_t* group_start) {
+    if (!S) return fail(VIPRS_EINVAL, "null state");
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EUNSUPPORTED, "SNP groups: spike-and-slab states only");
+    viprs_plan* P = S->plan;
+    if (n_groups == 0) {                         // back to one set of hyper-parameters
+        S->n_groups = 0;
+        S->group_start.clear();
+        return VIPRS_OK;
+    }
+    if (n_groups < 0 || !group_start) return fail(VIPRS_EINVAL, "bad group list");
+    if (group_start[0] != 0 || group_start[n_groups] != P->m) return fail(VIPRS_EINVAL, "the groups must cover SNPs 0 .. m");
+    for (int g = 0; g < n_groups; ++g)
+        if (group_start[g + 1] < group_start[g]) return fail(VIPRS_EINVAL, "group_start must not decrease");
+    // a group is a set of whole LD blocks (its hyper-parameters are fixed within a block's sweep)
+    for (const Block& b : P->blocks) {
+        const int64_t* it = std::upper_bound(group_start, group_start + n_groups + 1, b.start);      // first boundary > b.start
+        if (it != group_start + n_groups + 1 && *it < b.end) return fail(VIPRS_EINVAL, "a group boundary cuts through an LD block");
+    }
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    S->n_groups = n_groups;
+    S->group_start.assign(group_start, group_start + n_groups + 1);
+    S->group_max_nb = 1;
+    for (int g = 0; g < n_groups; ++g) S->group_max_nb = std::max(S->group_max_nb, sums_blocks(group_start[g + 1] - group_start[g]));
+    HIP_TRY(S->d_group_start.alloc((size_t)n_groups + 1));
+    HIP_TRY(hipMemcpy(S->d_group_start.p, group_start, sizeof(int64_t) * ((size_t)n_groups + 1), hipMemcpyHostToDevice));
+    HIP_TRY(S->d_group_prep.alloc((size_t)6 * n_groups));
+    HIP_TRY(S->d_group_sumrows.alloc((size_t)2 * n_groups));
+    if (S->h_gparams) { HIP_TRY(hipHostFree(S->h_gparams)); S->h_gparams = nullptr; }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_gparams), (size_t)8 * n_groups * sizeof(double), hipHostMallocDefault));
+    return VIPRS_OK;
+}
+
+static int group_rows_check(const viprs_state* S, int n, const double* rows, int width) {
+    if (!S || !rows) return fail(VIPRS_EINVAL, "null argument");
+    if (S->n_groups == 0) return fail(VIPRS_EINVAL, "viprs_state_set_groups has not been called");
+    if (n < 0 || n > S->n_groups) return fail(VIPRS_EINVAL, "bad group count");
+    for (int i = 0; i < n; ++i) {
+        const double g = rows[(size_t)width * i];
+        if (g < 0 || g >= S->n_groups || g != floor(g)) return fail(VIPRS_EINVAL, "group index out of range");
+    }
+    return VIPRS_OK;
+}
+
+int viprs_state_prep_groups(viprs_state* S, int n, const double* params) {
+    int rc = group_rows_check(S, n, params, 6);
+    if (rc != VIPRS_OK) return rc;
+    viprs_plan* P = S->plan;
+    if (P->m == 0 || n == 0) return VIPRS_OK;
+    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    if (!S->ev_prep) HIP_TRY(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(S->ev_prep));            // the previous launch has read its parameters
+    memcpy(S->h_gparams, params, (size_t)6 * n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(S->d_group_prep.p, S->h_gparams, (size_t)6 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    int64_t longest = 0;
+    for (int i = 0; i < n; ++i) {
+        const int g = (int)params[6 * i];
+        longest = std::max(longest, S->group_start[(size_t)g + 1] - S->group_start[(size_t)g]);
+    }
+    const dim3 grid((unsigned)std::max<int64_t>(1, (longest + 255) / 256), (unsigned)n);
+    if (S->float_dtype == VIPRS_F32)
+        prep_groups_kernel<float><<<grid, 256, 0, P->stream>>>(S->d_n.p, S->d_group_start.p, S->d_group_prep.p,
+                                                               (float*)S->f[VIPRS_FIELD_MU_MULT].p, (float*)S->f[VIPRS_FIELD_U_LOGS].p,
+                                                               (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+    else
+        prep_groups_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, S->d_group_start.p, S->d_group_prep.p,
+                                                                (double*)S->f[VIPRS_FIELD_MU_MULT].p, (double*)S->f[VIPRS_FIELD_U_LOGS].p,
+                                                                (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(S->ev_prep, P->stream));
+    return VIPRS_OK;
+}
+
+}  // extern "C"
+
+template <typename T>
+static int sums_groups_enqueue(viprs_state* S, int n) {
+    viprs_plan* P = S->plan;
+    const int nb = S->group_max_nb;
+    const size_t need = (size_t)nb * kNSums * n;
+    if (S->d_partials.n < need) HIP_TRY(S->d_partials.alloc(need));
+    if (S->d_sums.n < (size_t)kNSums * S->n_groups) HIP_TRY(S->d_sums.alloc((size_t)kNSums * S->n_groups));
+    const size_t hcap = (size_t)kNSums * S->n_groups + 1;
+    if (S->h_sums_cap < hcap) {
+        if (S->h_sums) HIP_TRY(hipHostFree(S->h_sums));
+        S->h_sums = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), hcap * sizeof(double), hipHostMallocDefault));
+        S->h_sums_cap = hcap;
+    }
+    sums_groups_kernel<T><<<dim3(nb, n), kSumsBlock, 0, P->stream>>>(
+        S->d_group_start.p, S->d_group_sumrows.p, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const T*)S->f[VIPRS_FIELD_VAR_MU].p,
+        (const T*)S->f[VIPRS_FIELD_ETA].p, (const T*)S->f[VIPRS_FIELD_Q].p, (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p,
+        (const T*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p, S->d_partials.p);
+    HIP_TRY(hipGetLastError());
+    sums_final_groups_kernel<<<n, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_group_start.p, S->d_group_sumrows.p, S->d_sums.p);
+    HIP_TRY(hipGetLastError());
+    if (S->comm) {
+        const int rc = comm_reduce_on_stream(S->comm, S->d_sums.p, kNSums * n, kNSums, P->stream);
+        if (rc != VIPRS_OK) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(S->h_sums, S->d_sums.p, (size_t)kNSums * n * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(S->h_sums + (size_t)kNSums * n, P->d_error.p, sizeof(int32_t), hipMemcpyDeviceToHost, P->stream));
+    S->sums_cols = n;
+    S->sums_pending = true;
+    return VIPRS_OK;
+}
+
+extern "C" {
+
+int viprs_state_sums_groups_begin(viprs_state* S, int n, const double* rows) {
+    int rc = group_rows_check(S, n, rows, 2);
+    if (rc != VIPRS_OK) return rc;
+    viprs_plan* P = S->plan;
+    S->sums_cols = n;
+    if (P->m == 0 && n > 0 && S->comm) return sums_enqueue_empty(S, kNSums * n, kNSums);
+    if (P->m == 0 || n == 0) { S->sums_pending = false; S->sums_empty = true; return VIPRS_OK; }
+    S->sums_empty = false;
+    if (!S->d_var_tau.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp / viprs_state_prep_groups have not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    // (own half of the pinned staging: the previous reduction that read it has been collected)
+    double* h = S->h_gparams + (size_t)6 * S->n_groups;
+    memcpy(h, rows, (size_t)2 * n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(S->d_group_sumrows.p, h, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    return S->float_dtype == VIPRS_F32 ? sums_groups_enqueue<float>(S, n) : sums_groups_enqueue<double>(S, n);
+}
+
+int viprs_state_sums_groups_end(viprs_state* S, double* out) {
+    if (S && S->n_groups == 0) return fail(VIPRS_EINVAL, "viprs_state_set_groups has not been called");
+    return viprs_state_sums_columns_end(S, out);          // same landing buffer and bookkeeping: sums_cols rows of VIPRS_N_SUMS
 }
 
 }  // extern "C"

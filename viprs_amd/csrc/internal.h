@@ -99,6 +99,14 @@ struct viprs_plan {
     int class_begin[4] = {0, 0, 0, 0};
     int team0 = 0;                          // team size of the largest class for this plan's largest block (0: the configured one)
     viprs::DevBuf<viprs::BlockDesc> d_dense, d_ragged;
+    // viprs_plan_set_active_blocks: the lists above are what a sweep visits -- all blocks, or the active subset (the
+    // lock-step fit of one model per chromosome drops the blocks of the chromosomes that have converged); the full lists:
+    std::vector<viprs::BlockDesc> dense_all_h, ragged_all_h;
+    int class_begin_all[4] = {0, 0, 0, 0};
+    int max_dense_all = 0, max_ragged_all = 0;
+    viprs::DevBuf<viprs::BlockDesc> d_dense_all;   // what ensure_upper_storage converts (every block, active or not)
+    bool filtered = false;
+    int64_t m_active = 0;                          // SNPs of the blocks a sweep visits
     viprs::DevBuf<unsigned long long> d_granules;  // team hand-off granules (one row of 64 per panel of a team block)
     int64_t n_granule_rows = 0;
     viprs::DevBuf<int32_t> d_error;
@@ -160,7 +168,13 @@ struct viprs_state {
     viprs::DevBuf<double> d_weight;                // optional per-SNP weight of sum [0] (several chromosomes in one plan)
     viprs::DevBuf<double> d_log_var_tau0;          // mixture: the log var_tau of the initial state (the reference's ELBO never refreshes it)
     viprs::DevBuf<double> d_colparams, d_sumcols;  // grid: per-column parameters of the batched prep / of the batched sums
-    int sums_cols = 0;                      // columns of the reduction in flight (grid: sums_columns_begin)
+    int sums_cols = 0;                      // columns of the reduction in flight (grid: sums_columns_begin; groups: sums_groups_begin)
+    // viprs_state_set_groups: contiguous SNP ranges with their own hyper-parameters and their own sums (one model per chromosome)
+    int n_groups = 0, group_max_nb = 0;
+    std::vector<int64_t> group_start;              // n_groups + 1 entries
+    viprs::DevBuf<int64_t> d_group_start;
+    viprs::DevBuf<double> d_group_prep, d_group_sumrows;   // per-launch parameter rows (6 / 2 doubles per listed group)
+    double* h_gparams = nullptr;                   // pinned staging of both (8 x n_groups)
     size_t h_sums_cap = 0;
     double* h_sums = nullptr;               // pinned landing buffer of the device sums
     bool sums_pending = false, sums_empty = false;
@@ -170,6 +184,7 @@ struct viprs_state {
     ~viprs_state() {
         if (h_sums) (void)hipHostFree(h_sums);
         if (h_params) (void)hipHostFree(h_params);
+        if (h_gparams) (void)hipHostFree(h_gparams);
         if (ev_prep) (void)hipEventDestroy(ev_prep);
     }
     size_t field_elems(int field) const {

@@ -72,6 +72,11 @@ class ArrayDataLoader:
     def get_ld_matrices(self):
         return self.ld
 
+    def split_by_chromosome(self):
+        """One loader per chromosome, as magenpy's ``GWADataLoader.split_by_chromosome()`` hands to the reference's
+        per-chromosome fits (bin/viprs_fit:232-238)."""
+        return {c: ArrayDataLoader({c: self.ld[c]}, {c: self.sumstats_table[c]}) for c in self.chromosomes}
+
     @classmethod
     def synthetic(cls, chrom_sizes, ld_dtype=np.float32, seed=7209, n=1e5, forms=("symmetric", "upper"), h2=0.2,
                   kind="ar1"):

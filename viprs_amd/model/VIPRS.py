@@ -34,6 +34,8 @@ def _is_numeric(x):
 
 class VIPRS:
 
+    _always_merge = False        # subclasses that need the one-plan layout even for a single local chromosome
+
     def __init__(self, gdl, fix_params=None, tracked_params=None, lambda_min=None, float_precision="float32",
                  order="F", low_memory=True, dequantize_on_the_fly=False, threads=1,
                  device=None, comm=None, math_mode="exact", e_step_fn=None, device_resident=True,
@@ -185,7 +187,7 @@ class VIPRS:
             # several ranks: ONE plan per rank whatever the number of local chromosomes (one collective per EM
             # iteration, per-SNP weights 1 / m_c of the FULL chromosome for the update_pi mean)
             self._merged = (self._resident and bool(merge_chromosomes) and self._supports_merged()
-                            and (len(self.chromosomes) > 1 or world > 1))
+                            and (len(self.chromosomes) > 1 or world > 1 or self._always_merge))
             if self._merged:
                 # one plan over the concatenated chromosomes: windows and row offsets shifted into place
                 from ..data import merge_ld_arrays
@@ -313,23 +315,28 @@ class VIPRS:
         self.sigma_epsilon, self.pi, self.lambda_min = t(self.sigma_epsilon), t(self.pi), t(self.lambda_min)
         self._sigma_g = t(0.0)
 
-    def initialize_theta(self, theta_0=None):
-        th = self._merge_theta(theta_0)
+    @staticmethod
+    def _theta_values(th, n_snps):
+        """(pi, sigma_epsilon, tau_beta) of VIPRS.py:260-310 for a model over `n_snps` variants, before the casts."""
         if "pi" in th:
-            self.pi = th["pi"]
+            pi = th["pi"]
         else:                                                      # VIPRS.py:260-265
-            self.pi = np.random.uniform(low=max(10.0 / self.n_snps, 1e-5), high=min(0.2, 1e4 / self.n_snps))
+            pi = np.random.uniform(low=max(10.0 / n_snps, 1e-5), high=min(0.2, 1e4 / n_snps))
         if "sigma_epsilon" in th:                                  # :301-310
-            self.sigma_epsilon = th["sigma_epsilon"]
-            self.tau_beta = th["tau_beta"] if "tau_beta" in th else \
-                (self.pi * self.n_snps) / np.maximum(0.01, 1.0 - self.sigma_epsilon)
+            sigma_epsilon = th["sigma_epsilon"]
+            tau_beta = th["tau_beta"] if "tau_beta" in th else (pi * n_snps) / np.maximum(0.01, 1.0 - sigma_epsilon)
         elif "tau_beta" in th:                                     # :295-300
-            self.tau_beta = th["tau_beta"]
-            self.sigma_epsilon = np.clip(1.0 - self.pi * self.n_snps / self.tau_beta, 1e-4, 1.0 - 1e-4)
+            tau_beta = th["tau_beta"]
+            sigma_epsilon = np.clip(1.0 - pi * n_snps / tau_beta, 1e-4, 1.0 - 1e-4)
         else:                                                      # :279-292 (no simple_ldsc without magenpy)
             h2 = np.random.uniform(low=0.01, high=0.1)
-            self.sigma_epsilon = 1.0 - h2
-            self.tau_beta = self.pi * self.n_snps / max(h2, 0.01)
+            sigma_epsilon = 1.0 - h2
+            tau_beta = pi * n_snps / max(h2, 0.01)
+        return pi, sigma_epsilon, tau_beta
+
+    def initialize_theta(self, theta_0=None):
+        th = self._merge_theta(theta_0)
+        self.pi, self.sigma_epsilon, self.tau_beta = self._theta_values(th, self.n_snps)
         self._cast_theta()
 
     def get_pi(self, chrom=None):
@@ -581,8 +588,13 @@ class VIPRS:
                 s[9] += v[9]
                 self._dev_max_eta_diff = max(self._dev_max_eta_diff, float(v[10]))
             return s
+        return self._host_partial_sums(self.chromosomes)
+
+    def _host_partial_sums(self, chroms):
+        """The sums over the NumPy state of the given local chromosomes (layout above, 10 entries)."""
+        lam = self.lambda_min
         s = np.zeros(9, dtype=np.float64)
-        for c in self.chromosomes:
+        for c in chroms:
             g, z = self.var_gamma[c], self.zeta[c]
             s[0] += np.sum(g, axis=0) / self._all_shapes[c]              # update_pi: mean of per-chromosome means (:446-453)
             s[1] += z.sum()
@@ -596,7 +608,7 @@ class VIPRS:
             s[7] += gc.sum()
             s[8] += ng.sum()
         extra = np.zeros(1)
-        for c in self.chromosomes:
+        for c in chroms:
             extra[0] += (np.clip(self.var_gamma[c].astype(np.float64), _DOUBLE_RES, 1 - _DOUBLE_RES)
                          * self._log_var_tau[c]).sum()
         return np.concatenate([s, extra])

@@ -21,7 +21,7 @@ import numpy as np
 import pandas as pd
 
 from ..VIPRS import VIPRS
-from ...utils.optim import ConditionStreak, OptimizeResult
+from .._lockstep import LockstepEM
 
 
 class VIPRSGrid(VIPRS):
@@ -237,37 +237,11 @@ class VIPRSGrid(VIPRS):
                 st.reset_column(g, float(th[g]["pi"]))
             states[key] = st
 
-        # ---- per-model hyper-parameters as ARRAYS: the host side of an iteration is a handful of NumPy calls over the active
-        # models instead of ~40 Python statements (several np.log / np.isclose on scalars) per model -- for 32 models that
-        # loop cost as much as a third of the batched sweep itself.  The arithmetic follows the serial fit's DTYPES, which
-        # decide roundings: a hyper-parameter that is fixed stays a scalar of the state precision (VIPRS.set_fixed_params /
-        # _cast_theta), one that the M-step updates becomes a float64 (VIPRS.m_step) -- `*_is32` track which is which,
-        # and `in_dtype` evaluates an expression in float32 for the former.  (Array ufuncs give the same bits as the
-        # scalar calls they replace.)
-        f32, f64 = np.float32, np.float64
-        is32 = lambda v: isinstance(v, np.floating) and v.dtype == np.float32
-        pi_v = np.array([p["pi"] for p in th], dtype=T)                       # always of the state precision (m_step casts)
-        sig_v = np.array([p["sigma_epsilon"] for p in th], dtype=f64)
-        tau_v = np.array([p["tau_beta"] for p in th], dtype=f64)
-        sig_is32 = np.array([is32(p["sigma_epsilon"]) for p in th])
-        tau_is32 = np.array([is32(p["tau_beta"]) for p in th])
-        fx_pi = np.array(["pi" in p["fixed"] for p in th])
-        fx_tau = np.array(["tau_beta" in p["fixed"] for p in th])
-        fx_sig = np.array(["sigma_epsilon" in p["fixed"] for p in th])
-        lam1_v = np.array([float(1.0 + p["lam"]) for p in th], dtype=f64)
-        sig_e, tau_e = sig_v.copy(), tau_v.copy()                             # what var_tau of the last E-step was built from
-
-        def in_dtype(v, m32, fn):
-            """fn evaluated in float32 where the serial fit holds a float32 scalar (mask m32), in float64 elsewhere."""
-            out = fn(v)
-            if m32.any():
-                out = np.where(m32, fn(v.astype(f32)).astype(f64), out)
-            return out
-
-        def prep_rows(a):
-            pa = pi_v[a]
-            logit = (np.log(pa) - np.log(1.0 - pa)).astype(f64)
-            return np.column_stack([a.astype(f64), logit, in_dtype(tau_v[a], tau_is32[a], np.log), sig_v[a], tau_v[a], lam1_v[a]])
+        # ---- per-model hyper-parameters as ARRAYS (`LockstepEM`: M-step, ELBO and stopping rules of all active models in
+        # a handful of NumPy calls, in the serial fit's dtypes)
+        em = LockstepEM(T, th, self.n_snps, self.n, n_chroms_total=self._n_chroms_total, min_iter=min_iter,
+                        f_abs_tol=f_abs_tol, x_abs_tol=x_abs_tol, patience=patience)
+        lam1_v = em.lam1
 
         def all_sums(models):
             """(len(models), 11) sums: one batched reduction per chromosome, all in flight at once"""
@@ -281,85 +255,30 @@ class VIPRSGrid(VIPRS):
                 tot[:, 10] = np.maximum(tot[:, 10], v[:, 10])
             return tot
 
-        results = [OptimizeResult() for _ in range(G)]
-        sigma_g = np.zeros(G)
-        prev_elbo = np.full(G, -np.inf)
-        prev_sigma_g = np.zeros(G)
-        plateau_n, dropping_n = np.zeros(G, dtype=np.int64), np.zeros(G, dtype=np.int64)     # ConditionStreak counters
-        elbos = np.zeros(G)
         active = np.arange(G, dtype=np.int32)
         for st in states.values():               # initial ELBO needs var_tau of the initial hyper-parameters
-            st.prep_columns(prep_rows(active))
-        MESSAGES = (None, "The MSE is negative ({:.6f}).", "Objective (ELBO) is undefined.", "Residual variance estimate is negative.",
-                    "Estimated heritability is out of bounds.", "Objective (ELBO) converged successfully.",
-                    "Variational parameters converged successfully.", "LD-weighted variational parameters converged successfully.",
-                    "The objective (ELBO) is decreasing.")
-        SUCCESS = (False, False, False, False, False, True, True, True, False)
+            st.prep_columns(em.prep_rows(active))
 
         for i in range(1, max_iter + 1):
             if active.size == 0:
                 break
             a = active
-            sig_e[a], tau_e[a] = sig_v[a], tau_v[a]                             # what var_tau is built from
-            rows = prep_rows(a)
+            em.mark_e_step(a)                                                   # what var_tau is built from
+            rows = em.prep_rows(a)
             for st in states.values():               # one prep launch, one sweep and one reduction per plan
                 st.prep_columns(rows)
                 st.e_step(self.dequantize_scale, active_model_idx=a, sync=False)
-            s = all_sums(a)
-            # ---- VIPRS.m_step, per model (VIPRS.py:426-484) ----
-            pi_v[a] = np.where(fx_pi[a], pi_v[a], (s[:, 0] / self._n_chroms_total).astype(T))
-            upd = ~fx_tau[a]
-            tau_v[a] = np.where(upd, pi_v[a] * self.n_snps / s[:, 1], tau_v[a])
-            tau_is32[a] &= ~upd
-            sigma_g[a] = s[:, 2]
-            upd = ~fx_sig[a]
-            sig_v[a] = np.where(upd, (1.0 + (-2.0 * s[:, 3]).astype(T)) + sigma_g[a], sig_v[a])
-            sig_is32[a] &= ~upd
-            # ---- ELBO (VIPRS.py:497-581) in the serial fit's dtypes ----
-            sg, sa, ta, pa = sigma_g[a], sig_v[a], tau_v[a], pi_v[a]
-            e = in_dtype(sa, sig_is32[a], lambda v: -np.log(2.0 * np.pi * v))
-            e = np.where(fx_sig[a], e - in_dtype(sa, sig_is32[a], lambda v: 1.0 / v) * (1.0 - 2.0 * s[:, 3] + sg), e - 1.0)
-            e = e * (0.5 * self.n)
-            e = e - (s[:, 5] - np.log(pa) * s[:, 7])
-            e = e - (s[:, 6] - np.log(1.0 - pa) * s[:, 8])
-            e = e + 0.5 * (in_dtype(ta, tau_is32[a], lambda v: 1.0 + np.log(v)) * s[:, 7] - s[:, 9])
-            e = e - 0.5 * ta * s[:, 1]
-            elbos[a] = e
-            mse = 1.0 - 2.0 * s[:, 3] + (sg - s[:, 1] + s[:, 4])
-            h2 = sg / (sg + sa)
-            # ---- VIPRS.fit stopping rules (VIPRS.py:1003-1080), first match wins ----
-            pl = (i > min_iter) & np.isclose(sg, prev_sigma_g[a], atol=x_abs_tol, rtol=0.0) & (s[:, 10] < x_abs_tol * 10)
-            dr = (e < prev_elbo[a]) & ~np.isclose(e, prev_elbo[a], atol=1e3 * f_abs_tol, rtol=1e-4)
-            plateau_n[a] = np.where(pl, plateau_n[a] + 1, 0)
-            dropping_n[a] = np.where(dr, dropping_n[a] + 1, 0)
-            code = np.select(
-                [mse < 0.0, ~np.isfinite(e), sa < 0.0, (h2 > 1.0) | (h2 < 0.0),
-                 (i > min_iter) & np.isclose(prev_elbo[a], e, atol=f_abs_tol, rtol=0.0),
-                 (i > min_iter) & (s[:, 10] < x_abs_tol), plateau_n[a] > patience, dropping_n[a] > patience],
-                [1, 2, 3, 4, 5, 6, 7, 8], default=0)
-            for k, g in enumerate(a):
-                c = int(code[k])
-                if c == 0:
-                    results[g].update(float(e[k]))
-                else:
-                    msg = MESSAGES[c].format(float(mse[k])) if c == 1 else MESSAGES[c]
-                    results[g].update(float(e[k]), stop_iteration=True, success=SUCCESS[c], message=msg)
-            prev_elbo[a], prev_sigma_g[a] = e, sg
+            code = em.update(a, all_sums(a), i)
             active = a[code == 0]
             if on_iteration is not None:
                 on_iteration(i)
+        em.finish()
+        results, sigma_g, elbos = em.results, em.sigma_g, em.elbos
         # back into the per-model records the publishing code reads (in the serial fit's dtypes)
         for g in range(G):
             p = th[g]
-            p["pi"] = pi_v[g]
-            p["sigma_epsilon"] = f32(sig_v[g]) if sig_is32[g] else sig_v[g]
-            p["tau_beta"] = f32(tau_v[g]) if tau_is32[g] else tau_v[g]
-            p["sigma_epsilon_e"], p["tau_beta_e"] = sig_e[g], tau_e[g]
-        for g in range(G):
-            if not results[g].stop_iteration:
-                results[g].update(elbos[g], stop_iteration=True, success=False, increment=False,
-                                  message="Maximum iterations reached without convergence.\\n"
-                                          "You may need to run the model for more iterations.")
+            p["pi"], p["sigma_epsilon"], p["tau_beta"] = em.theta(g)
+            p["sigma_epsilon_e"], p["tau_beta_e"] = em.sig_e[g], em.tau_e[g]
 
         # ---- read the (m, G) state back in the reference's layout ---------------------------------------
         store = self._new_store()

@@ -9,8 +9,7 @@ LD blocks share no ``q`` entries, so blocks are independent units and the data p
 * ``RcclComm``         -- the communicator of the GPU path: RCCL over xGMI through the C ABI
                           (``viprs_comm_*``, no PyTorch); attached to a ``DeviceState`` the device-resident
                           partial sums are all-gathered and reduced in rank order on the plan's stream;
-* ``TorchDistComm``    -- ``torch.distributed`` process group; only the CPU test-suite uses it (``gloo``),
-                          as the transport under the oracle-driven host logic;
+* ``FileComm``         -- host-vector collectives through files: dry runs of the multi-rank path on one device;
 * ``LocalComm``        -- single process.
 """
 import ctypes
@@ -378,44 +377,6 @@ class RcclComm:
             self.close()
         except Exception:
             pass
-
-
-class TorchDistComm:
-    """``torch.distributed`` process group (already initialised by the launcher).  CPU-test transport
-    (``gloo``) of the oracle-driven host logic; the GPU path uses ``RcclComm``."""
-    device_side = False
-
-    def __init__(self, device=None):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self._torch, self._dist = torch, dist
-        self.rank = dist.get_rank()
-        self.world_size = dist.get_world_size()
-        if device is None:
-            device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        self.device = device
-
-    def _reduce(self, vec, op):
-        t = self._torch.as_tensor(np.array(vec, dtype=np.float64)).to(self.device)
-        self._dist.all_reduce(t, op=op)
-        return t.cpu().numpy()
-
-    def allreduce_sum(self, vec):
-        return self._reduce(vec, self._dist.ReduceOp.SUM)
-
-    def allreduce_max(self, vec):
-        return self._reduce(vec, self._dist.ReduceOp.MAX)
-
-    def allgather(self, vec):
-        t = self._torch.as_tensor(np.array(vec, dtype=np.float64)).to(self.device)
-        parts = [self._torch.empty_like(t) for _ in range(self.world_size)]
-        self._dist.all_gather(parts, t)
-        return np.stack([p.cpu().numpy() for p in parts])
-
-    def barrier(self):
-        self._dist.barrier()
 
 
 class FileComm:

@@ -186,6 +186,15 @@ class LDPlan:
         L.check(L.lib.viprs_plan_get_blocks(self.handle, _ptr(starts), _ptr(kinds)))
         return starts, kinds[:n]
 
+    def set_active_blocks(self, active):
+        """Which LD blocks the following sweeps visit: a boolean per block in SNP order (`blocks()`), None = all of them
+        (`viprs_plan_set_active_blocks`).  Spike-and-slab / mixture states; the batched grid kernel refuses a filtered plan."""
+        if active is None:
+            L.check(L.lib.viprs_plan_set_active_blocks(self.handle, None, 0))
+            return
+        a = np.ascontiguousarray(active, dtype=np.uint8)
+        L.check(L.lib.viprs_plan_set_active_blocks(self.handle, _ptr(a), int(a.shape[0])))
+
     def set_math_mode(self, mode):
         code = {"exact": L.MATH_EXACT, "fast": L.MATH_FAST}.get(mode, mode)
         L.check(L.lib.viprs_plan_set_math_mode(self.handle, int(code)))
@@ -449,6 +458,35 @@ class DeviceState:
         out = (ctypes.c_double * L.N_SUMS)()
         L.check(L.lib.viprs_state_sums_end(self._h, out))
         return np.array(out[:], dtype=np.float64)
+
+    # -- SNP groups: one model per chromosome in one state ---------------------------------------
+    def set_groups(self, group_start):
+        """Contiguous SNP ranges (whole LD blocks) with their own hyper-parameters and sums: `group_start` has
+        n_groups + 1 entries from 0 to m; None removes the groups."""
+        if group_start is None:
+            L.check(L.lib.viprs_state_set_groups(self._h, 0, None))
+            self.n_groups = 0
+            return
+        gs = np.ascontiguousarray(group_start, dtype=np.int64)
+        L.check(L.lib.viprs_state_set_groups(self._h, int(gs.shape[0]) - 1, _ptr(gs)))
+        self.n_groups = int(gs.shape[0]) - 1
+
+    def prep_groups(self, params):
+        """`prep` with per-group scalars: rows (group, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda)."""
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 6)
+        L.check(L.lib.viprs_state_prep_groups(self._h, int(p.shape[0]), _ptr(p)))
+
+    def sums_groups_begin(self, groups, one_plus_lambda):
+        r = np.ascontiguousarray(np.column_stack([np.asarray(groups, dtype=np.float64),
+                                                  np.broadcast_to(np.asarray(one_plus_lambda, dtype=np.float64),
+                                                                  (len(groups),))]))
+        self._n_sum_cols = int(r.shape[0])
+        L.check(L.lib.viprs_state_sums_groups_begin(self._h, self._n_sum_cols, _ptr(r)))
+
+    def sums_groups_end(self):
+        out = np.zeros((self._n_sum_cols, L.N_SUMS), dtype=np.float64)
+        L.check(L.lib.viprs_state_sums_groups_end(self._h, _ptr(out)))
+        return out
 
     # -- one model (column) of a grid state -----------------------------------------------------
     def prep_column(self, g, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda):
