@@ -22,9 +22,13 @@ HBM before the timed region starts.  Before the W warm-up steps the primary work
 
 Workload: BASELINE.json configs[2] -- ~1.1 M SNPs in ~1 700 LD blocks (lognormal block sizes, SURVEY.md 8d;
 long-range non-Toeplitz block LD by default, `--ld-kind ar1` for the analytic AR(1) blocks of rounds 1-2),
-spike-and-slab prior, fp32 state, fp32 LD, symmetric form.  N = 1 also times, as `config.secondary`,
-configs[3] (mixture K = 4) and configs[4] (grid of 32 models) on the same resident LD, and the reference's
-default LD form (upper-triangular) with fp32 and int8 LD.
+spike-and-slab prior, fp32 state, fp32 LD in the reference's DEFAULT form (upper-triangular, `low_memory=True`; `--symmetric`
+selects the other, which is also the first secondary and is repeated at the top level as `symmetric_ld_form`).  N = 1 also
+times, as `config.secondary`, configs[3] (mixture K = 4) and configs[4] (grid of 32 models) on the same resident LD in both
+forms, the int8 store format, a float64 state, math_mode=fast, the EM iteration of the three models, the reference's
+default OPERATING mode (22 per-chromosome models: one lock-step batch against 22 fits one after the other) and
+BASELINE configs[0] / configs[1] with the CPU baseline of their own workloads.  `metric_definition` stamps what `value`
+is (LD form, scaling mode, state placement) so that lines of different rounds are compared like for like.
 N > 1 (default, "strong" = BASELINE.json configs[2], "block-sharded 1/2/4/8 GPUs"): the blocks of ONE 1.1 M-SNP /
 1 700-block workload are dealt to the ranks (chain-aware LPT, viprs_amd.parallel.shard_blocks; no data-path
 collective) and `value` = that workload's SNPs per max-over-ranks sweep time -- the same quantity as the N = 1 line.
@@ -570,6 +574,121 @@ def _lib_sync(device):
     _lib.check(_lib.lib.viprs_device_synchronize(device))
 
 
+# ---- the reference's DEFAULT mode: one model per chromosome (bin/viprs_fit:232-238, :1079-1086) ---------------------
+CHROM_MB = (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103, 90, 81, 78, 59, 63, 48, 51)   # GRCh37 autosomes
+
+
+def split_into_chromosomes(ld, ss):
+    """The workload's LD blocks as 22 'chromosomes': contiguous runs of blocks whose SNP counts follow the autosomes'
+    lengths (chr1 8.6 % ... chr21 1.7 %).  Returns an ArrayDataLoader over views of the workload's host arrays."""
+    from viprs_amd.data import ArrayDataLoader, LDArrays, SumstatsArrays
+    starts = np.asarray(ld.block_start, dtype=np.int64)
+    cum = np.cumsum(CHROM_MB) / float(np.sum(CHROM_MB)) * ld.m
+    cut = [0] + [int(np.argmin(np.abs(starts - c))) for c in cum[:-1]] + [len(starts) - 1]
+    for i in range(1, len(cut)):                              # every chromosome at least one block
+        cut[i] = max(cut[i], cut[i - 1] + 1)
+    cut[-1] = len(starts) - 1
+    lds, sss, sizes = {}, {}, {}
+    for c in range(22):
+        a, b = int(starts[cut[c]]), int(starts[cut[c + 1]])
+        o = int(ld.ld_indptr[a])
+        form = (np.ascontiguousarray(ld.ld_left_bound[a:b] - a).astype(np.int32), np.ascontiguousarray(ld.ld_indptr[a:b + 1] - o),
+                ld.ld_data[o:int(ld.ld_indptr[b])])
+        lds[c + 1] = LDArrays(upper=form, dq_scale=ld.dq_scale) if ld.low_memory else LDArrays(symmetric=form, dq_scale=ld.dq_scale)
+        sss[c + 1] = SumstatsArrays(ss.std_beta[a:b], ss.n_per_snp[a:b])
+        sizes[c + 1] = np.diff(starts[cut[c]:cut[c + 1] + 1])
+    return ArrayDataLoader(lds, sss), sizes
+
+
+def measure_per_chromosome(ld, ss, device, iters=12, warm=3, math_mode="exact"):
+    """22 independent per-chromosome models (what `viprs_fit` runs unless --genomewide): ONE lock-step batch on one plan
+    (`VIPRSPerChromosome`: per-group hyper-parameters and sums, one sweep per EM round) against the same 22 models fitted
+    one after the other by `VIPRS` (one plan, one sweep, one reduction per chromosome per iteration).  ms per EM ROUND =
+    one iteration of every chromosome's model; a fixed start (pi = 0.01, sigma_epsilon = 0.8), stopping rules held off
+    (`min_iter`) so that every round updates all 22 models."""
+    from viprs_amd.model import VIPRS, VIPRSPerChromosome
+    gdl, sizes = split_into_chromosomes(ld, ss)
+    lm = bool(ld.low_memory)
+    theta = {"pi": 0.01, "sigma_epsilon": 0.8}
+    n_it = warm + iters
+    out = {"name": "22 per-chromosome models (the reference's default mode, bin/viprs_fit:232-238): lock-step batch vs one fit after the other",
+           "unit": "ms per EM round (one iteration of all 22 models)", "iterations": iters, "warmup_iterations": warm,
+           "math_mode": math_mode, "snps": int(ld.m), "low_memory": lm, "chromosomes": 22,
+           "snps_per_chromosome": [int(np.sum(sizes[c])) for c in sorted(sizes)],
+           "largest_block_per_chromosome": [int(np.max(sizes[c])) for c in sorted(sizes)]}
+    stamps = []
+    model = VIPRSPerChromosome(gdl, low_memory=lm, device=device, math_mode=math_mode)
+    model.fit(max_iter=n_it, min_iter=n_it + 1, theta_0=dict(theta), on_iteration=lambda i: stamps.append(time.perf_counter()))
+    d = np.diff(np.array(stamps))[warm - 1:]
+    plan = model._plans["*"]
+    k = plan.timing_history(which=0)
+    out["batched"] = {"ms_per_round": float(np.median(d)) * 1e3 if len(d) else None, "ms_per_round_mean": float(np.mean(d)) * 1e3 if len(d) else None,
+                      "ms_per_round_all": [round(float(x) * 1e3, 4) for x in d], "rounds_run": len(stamps),
+                      "sweep_kernels_ms_avg": float(np.mean(k[-iters:])) if k else None,
+                      "models_still_iterating_at_the_end": int(sum(not r.success and "Maximum" in str(r.message) for r in model.optim_results.values()))}
+    elbo_b = {c: list(model.history[c]["ELBO"]) for c in model.groups}
+    del model
+    # the same 22 fits, one after the other (each on its own plan and state: what 22 VIPRS objects cost)
+    per_chrom, sweep_k, same = [], [], True
+    for c, sub in gdl.split_by_chromosome().items():
+        st = []
+        one = VIPRS(sub, low_memory=lm, device=device, math_mode=math_mode)
+        one.fit(max_iter=n_it, min_iter=n_it + 1, theta_0=dict(theta), on_iteration=lambda i: st.append(time.perf_counter()))
+        dd = np.diff(np.array(st))[warm - 1:]
+        per_chrom.append(float(np.median(dd)) * 1e3 if len(dd) else float("nan"))
+        kk = next(iter(one._plans.values())).timing_history(which=0)
+        sweep_k.append(float(np.mean(kk[-iters:])) if kk else float("nan"))
+        same = same and (one.history["ELBO"] == elbo_b[c])
+        del one
+    out["sequential"] = {"ms_per_round": float(np.sum(per_chrom)), "ms_per_iteration_per_chromosome": [round(x, 4) for x in per_chrom],
+                         "sweep_kernel_ms_per_chromosome": [round(x, 4) for x in sweep_k], "sweep_kernels_ms_sum": float(np.sum(sweep_k))}
+    out["elbo_trajectories_identical"] = bool(same)          # the batch computes, bit for bit, what the 22 separate fits compute
+    if out["batched"]["ms_per_round"]:
+        out["speedup_batched_over_sequential"] = out["sequential"]["ms_per_round"] / out["batched"]["ms_per_round"]
+    return out
+
+
+def measure_small_config(args, cfg, device, barrier, steps, cpu_seconds):
+    """BASELINE configs[0] / configs[1] (cfg1: one 500-SNP block, "reference Cython CPU e_step (1 thread)"; cfg2: chr22-like,
+    19k SNPs / 40 blocks, "1 x MI355X vs OpenMP CPU") on the device -- resident sweep, time model (both are bound by the
+    serial chain of their largest block, not by HBM) -- with the CPU baseline of the SAME workload beside it, and the
+    PCIe-inclusive one-shot host-buffer call (`cpp_e_step`, never `value`)."""
+    sizes = config_sizes(cfg, args.seed)
+    ld, ss, inp, _ = build_workload(args, sizes, None, args.seed, True, np.dtype("float32"), data=True)
+    sw = Sweep(args, ld, ss, inp, device, "spike_slab", 1, True)
+    what = {"cfg1": "configs[0]: single LD block, 500 SNPs", "cfg2": "configs[1]: chr22-like, ~19k SNPs / 40 LD blocks"}[cfg]
+    out = measure_secondary(f"{what}, spike-and-slab, upper-triangular fp32 LD (low_memory=True)", sw, steps, barrier, args.math)
+    out["config"] = cfg
+    out["largest_block"] = int(np.max(sizes))
+    sw.close()
+    from viprs_amd.vi import e_step_hip as H
+    st = inp.state_copy()
+    call = lambda: H.cpp_e_step(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, inp.std_beta, st["var_gamma"], st["var_mu"], st["eta"], st["q"],
+                                st["eta_diff"], inp.u_logs, inp.sqrt_half_var_tau, inp.mu_mult, ld.dq_scale, 1, True)
+    for _ in range(3):
+        call()
+    ts = []
+    for _ in range(20):
+        for k, v in inp.state_copy().items():
+            st[k][...] = v
+        t0 = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - t0)
+    out["one_shot_host_call"] = {"ms_per_call": float(np.median(ts)) * 1e3, "value": ld.m / float(np.median(ts)), "unit": "SNP-updates/s",
+                                 "note": "cpp_e_step drop-in on HOST buffers: 9 vectors up, sweep, 5 vectors down per call (LD resident "
+                                         "after the first call): the PCIe-inclusive rate, never `value`"}
+    if cpu_seconds > 0:
+        cb = cpu_baseline(ld, inp, cpu_seconds, "spike_slab", 1, None, None, args.cpu_threads)
+        # configs[0] is worded for ONE thread, configs[1] for the OpenMP path
+        cb["headline"] = ({"value": cb["single_thread_value"], "cores": 1, "variant": "1_single_thread"} if cfg == "cfg1" else
+                          {"value": cb["value"], "cores": cb["cores"], "variant": "2_openmp_all_threads_racy"})
+        out["cpu_baseline"] = cb
+        out["gpu_over_cpu"] = {"resident_sweep_over_headline": out["value"] / cb["headline"]["value"],
+                               "resident_sweep_over_best_exact": out["value"] / cb["best_exact"]["value"],
+                               "one_shot_call_over_headline": out["one_shot_host_call"]["value"] / cb["headline"]["value"]}
+    return out
+
+
 def per_rank(comm, rank, world, x):
     """One scalar per rank -> the vector of all ranks' values, on every rank."""
     v = np.zeros(world)
@@ -824,6 +943,13 @@ def main():
             if args.config in ("cfg3", "cfg2"):
                 for kind in ("VIPRS", "VIPRSMix(K=4)", "VIPRSGrid(32 models, batched)"):
                     secondary.append(measure_fit_iteration(kind, ld, ss, device, math_mode=args.math))
+            if args.config == "cfg3":
+                # the reference's default operating mode: one model per chromosome -- 22 of them in one lock-step batch
+                secondary.append(measure_per_chromosome(ld, ss, device, math_mode=args.math))
+                # BASELINE configs[0] and configs[1], each with the CPU baseline of its own workload
+                for cfg_small, cpu_s in (("cfg1", 2.0), ("cfg2", 6.0)):
+                    secondary.append(measure_small_config(args, cfg_small, device, barrier, max(10, args.steps),
+                                                          cpu_s if args.cpu_seconds > 0 else 0.0))
         if world > 1:
             # the other scaling figure beside `value`, same run, same ranks
             sw.close()
@@ -932,6 +1058,12 @@ def main():
                         "kernels' own streams); percentiles are rank 0's per-sweep kernel times",
             },
         }
+        # what `value` is, versioned: rounds 1-4 quoted the symmetric form and weak scaling; since round 5 the reference's default
+        # LD form, strong scaling and the best-of-n state placement (`symmetric_ld_form` / `weak_scaling` keep the old figures)
+        out["metric_definition"] = {"version": 2, "since": "round 5",
+                                    "ld_form": "upper-triangular (low_memory=True)" if ld.low_memory else "symmetric (low_memory=False)",
+                                    "scaling": args.scaling, "state_placement": "probe (best of n allocations)" if getattr(sw.state, "placement", None) else "first allocation",
+                                    "version_1": "rounds 1-4: symmetric LD form, weak scaling for N > 1, first allocation"}
         # which LD form `value` is, at the top level too (the reference's default is low_memory=True, VIPRS.py:75)
         out["default_ld_form"] = {"ld_form": "upper-triangular (low_memory=True, the reference's default)",
                                   "is_value": bool(ld.low_memory),

@@ -489,7 +489,8 @@ def _assert_equal_with_nonfinite(got, ref):
 
 @pytest.mark.parametrize("precision", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("low_memory", [False, True], ids=["sym", "upper"])
-def test_nonfinite_inputs_propagate_as_in_the_reference(gpu, low_memory, precision):
+@pytest.mark.parametrize("sweeps", [1, 2])
+def test_nonfinite_inputs_propagate_as_in_the_reference(gpu, low_memory, precision, sweeps):
     """The reference has no input checks (`noexcept nogil`): a NaN in the summary statistics poisons its LD block (q of the
     whole window becomes NaN: fma(R, NaN, q)), u_logs = -inf (pi = 0) gives gamma = exp(-inf) / (1 + exp(-inf)) = 0, an
     overflowing effect runs through inf.  The device follows it entry for entry -- team blocks, single workgroups, both LD
@@ -501,12 +502,22 @@ def test_nonfinite_inputs_propagate_as_in_the_reference(gpu, low_memory, precisi
     inp.u_logs[s[1] + 5: s[1] + 9] = -np.inf                # pi = 0 for four SNPs of block 1
     inp.std_beta[s[3] + 10] = 1e30 if precision == np.float32 else 1e300      # overflow in block 3
     inp.mu_mult[s[4] + 3] = np.inf                          # inf times a finite residual in block 4
+    if sweeps == 1:
+        # the LAST SNP of block 2: its eta_diff is NaN, but in the upper-triangular form no row's second-pass dot covers a
+        # column <= the row itself (e_step.hpp:331-337 starts at j + 1), so q of that SNP stays finite after one sweep -- a
+        # device pass that multiplies the stored zeros on / left of the diagonal by eta_diff would make it NaN
+        inp.std_beta[s[3] - 1] = np.nan
     st0 = inp.state_copy()
     with np.errstate(all="ignore"):
-        ref = H.run_oracle(ld, inp, st0, sweeps=2)
-    got = H.run_hip(ld, inp, st0, sweeps=2)
+        ref = H.run_oracle(ld, inp, st0, sweeps=sweeps)
+    got = H.run_hip(ld, inp, st0, sweeps=sweeps)
     _assert_equal_with_nonfinite(got, ref)
-    assert np.isnan(ref["q"][s[0]:s[1]]).all() and np.isfinite(ref["q"][s[2]:s[3]]).all()     # poisoned block / untouched block
+    assert np.isnan(ref["q"][s[0]:s[1]]).all()                 # the poisoned block
+    if sweeps == 1:
+        assert np.isnan(ref["eta_diff"][s[3] - 1]) and np.isnan(ref["q"][s[2]:s[3] - 1]).all()
+        assert np.isfinite(ref["q"][s[3] - 1]) == bool(low_memory)
+    else:
+        assert np.isfinite(ref["q"][s[2]:s[3]]).all()          # an untouched block
     # (gamma = 0 there: d = -eta_old = 0 takes the skip branch, e_step.hpp:410-413 -- eta_diff 0, var_gamma keeps its start)
     assert (ref["eta_diff"][s[1] + 5: s[1] + 9] == 0).all() and (ref["var_gamma"][s[1] + 5: s[1] + 9] == precision(inp.pi)).all()
 

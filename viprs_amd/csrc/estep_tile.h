@@ -517,128 +517,18 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
     if (tid == 0 && my_skipped) atomicAdd(A0.skipped, my_skipped);
 }
 
-// Second pass of the upper-triangular form, update_q_factor (e_step.hpp:331-337): q[j] += dq * dot(eta_diff[win(j)],
-// row(j)).  One wave per group of kTileGroupRows consecutive rows of a block, the lanes across the columns (coalesced):
-// a lane loads eta_diff of its columns ONCE for the rows of the group (int8 LD: the float64 eta_diff is 8 x the bytes
-// of the LD elements it multiplies -- per row it, not the LD, would be the traffic).  The groups of ALL blocks of the
-// list are dealt round-robin to the waves of the launch (`groups`: (index of the block in the list) << 32 | first row).
-// The dot is summed per lane and then across the lanes -- not in the reference's index order (see the header).
-constexpr int kTileGroupRows = 8;
-
-template <typename U, bool DENSE>
-__global__ __launch_bounds__(kTileThreads, 3) void tile_f64_second_pass_kernel(EStepArgs<double> A0, const int64_t* __restrict__ groups,
-                                                                               int64_t n_groups) {
-    using T = double;
-    constexpr int CPT = DENSE ? tile_cpt<U>() : 4;
-    constexpr int R = kTileGroupRows;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * kTileThreads + threadIdx.x) >> 6;
-    const int64_t n_waves = (int64_t)gridDim.x * kTileThreads / 64;
-    const int n_models = max(1, A0.n_active);
-    const int64_t n_items = n_groups * n_models;
-    const U* __restrict__ ld = static_cast<const U*>(DENSE ? A0.ld_dense : A0.ld_rows);
-    // a group costs one round trip to memory and about as much arithmetic: the group record two items ahead and the
-    // block descriptor one item ahead are already on their way
-    auto group_of = [&](int64_t item) { return item < n_items ? groups[item % n_groups] : (int64_t)0; };
-    int64_t g = group_of(wave), g_n = group_of(wave + n_waves);
-    BlockDesc bd = A0.blocks[(int)(g >> 32)];
-    for (int64_t item = wave; item < n_items; item += n_waves) {
-        const int64_t g_nn = group_of(item + 2 * n_waves);
-        const BlockDesc bd_n = A0.blocks[(int)(g_n >> 32)];
-        const EStepArgs<T> A = select_model(A0, (int)(item / n_groups));
-        const int row0 = (int)(uint32_t)g;
-        const int nr = min(R, bd.size - row0);
-        const int64_t s0 = bd.start;
-        int ws[R], we[R];
-        int64_t base[R];
-        int cmin = bd.size, cmax = 0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int jj = row0 + min(k, nr - 1);
-            const int64_t j = s0 + jj;
-            // dense blocks of the upper form: row jj holds columns jj + 1 .. size - 1 (no index loads)
-            ws[k] = DENSE ? jj + 1 : A.lb[j] - (int)s0;
-            we[k] = k < nr ? (DENSE ? bd.size : ws[k] + A.rowlen[j]) : ws[k];       // (rows beyond the group: empty window)
-            base[k] = DENSE ? bd.ld_off + (int64_t)jj * bd.stride : A.rowstart[j] - ws[k];
-            if (we[k] > ws[k]) { cmin = min(cmin, ws[k]); cmax = max(cmax, we[k]); }
-        }
-        const T* __restrict__ ed = A.eta_diff + s0;
-        T s[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) s[k] = 0;
-        for (int cb = (cmin & ~(CPT - 1)) + CPT * lane; cb < cmax; cb += CPT * 64) {
-            T e[CPT];
-#pragma unroll
-            for (int x = 0; x < CPT; ++x) e[x] = cb + x < cmax ? ed[cb + x] : (T)0;
-            UVec<U, CPT> r[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                if (DENSE) {
-                    r[k] = *reinterpret_cast<const UVec<U, CPT>*>(ld + base[k] + cb);    // (rows are padded to 64)
-                } else {
-#pragma unroll
-                    for (int x = 0; x < CPT; ++x) {
-                        const int c = cb + x;
-                        r[k].v[x] = (c >= ws[k] && c < we[k]) ? ld[base[k] + c] : (U)0;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-#pragma unroll
-                for (int x = 0; x < CPT; ++x) {
-                    if (DENSE) {
-                        // no window test: the repacked block holds exact zeros on and left of the diagonal and in the
-                        // padding (abi_plan.hip: repack_dense_kernel on a zeroed buffer), e is 0 beyond the block, and
-                        // the rows of the group beyond the block are never stored
-                        s[k] = __builtin_fma(static_cast<T>(r[k].v[x]), e[x], s[k]);
-                    } else {
-                        const int c = cb + x;
-                        const T w = __builtin_fma(static_cast<T>(r[k].v[x]), e[x], s[k]);
-                        s[k] = (c >= ws[k] && c < we[k]) ? w : s[k];
-                    }
-                }
-            }
-        }
-        // The 8 row sums across the 64 lanes, all at once: three exchange steps in which a lane gives away the half of its
-        // values it does not keep (after them lane l holds the 8-lane partial of row l & 7), then three steps across the
-        // 8-lane groups -- 10 double exchanges instead of 48 (each one is two ds_bpermute; with ~1 000 columns per item the
-        // reduction was as long as the fma loop).
-        static_assert(R == 8, "the butterfly below reduces 8 rows");
-        {
-            T t4[4], t2[2], t1;
-            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const T give = b0 ? s[2 * j] : s[2 * j + 1], keep = b0 ? s[2 * j + 1] : s[2 * j];
-                t4[j] = keep + __shfl_xor(give, 1);                  // rows 2 j + (lane & 1)
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const T give = b1 ? t4[2 * j] : t4[2 * j + 1], keep = b1 ? t4[2 * j + 1] : t4[2 * j];
-                t2[j] = keep + __shfl_xor(give, 2);                  // rows 4 j + (lane & 3)
-            }
-            {
-                const T give = b2 ? t2[0] : t2[1], keep = b2 ? t2[1] : t2[0];
-                t1 = keep + __shfl_xor(give, 4);                     // row lane & 7
-            }
-            t1 += __shfl_xor(t1, 8);
-            t1 += __shfl_xor(t1, 16);
-            t1 += __shfl_xor(t1, 32);
-            if (lane < R && lane < nr) A.q[s0 + row0 + lane] += A.dq * t1;
-        }
-        g = g_n;
-        g_n = g_nn;
-        bd = bd_n;
-    }
-}
+constexpr int kTileGroupRows = 8;       // second pass: rows per record of the plan's row lists (a 64-row group starts at every 8th)
 
 // ---------------------------------------------------------------------------------------------------------------
-// The second pass in the REFERENCE'S ORDER (round 5; math_mode = exact): dot() of e_step.hpp:82-104 is a serial fma chain
-// over a row's columns in index order, so here a LANE owns a ROW and walks its columns in ascending order -- q of the
-// upper-triangular form then equals the reference's bit for bit (the kernels above and below sum per lane and across
-// lanes: 1e-10, kept for math_mode = fast).  One wave per group of 64 consecutive rows (the records of `groups` whose
-// first row is a multiple of 64).
+// Second pass of the upper-triangular form, update_q_factor (e_step.hpp:331-337): q[j] += dq * dot(eta_diff[win(j)],
+// row(j)), in the REFERENCE'S ORDER: dot() of e_step.hpp:82-104 is a serial fma chain over a row's columns in index order,
+// so a LANE owns a ROW and walks its columns in ascending order -- q of the upper-triangular form equals the reference's
+// bit for bit.  (Rounds 3-5 also carried two shorter passes that summed per lane and across lanes, 1e-10 from the reference,
+// for math_mode = fast; a float64 state now always takes this one: every float64 result is `==`.)  One wave per group of 64
+// consecutive rows (the records of `groups` whose first row is a multiple of 64).
+//   The terms on and left of the diagonal do not exist in the reference's dot (its row starts at column j + 1): the stored
+//   zeros there are SKIPPED, not multiplied -- fma(0, eta_diff, s) would turn a non-finite eta_diff[c], c <= j, into a NaN in
+//   q[j] that the reference does not produce.
 //   dense blocks, LD elements of 1 / 2 / 4 bytes: a tile of 64 rows x 32 columns is loaded coalesced and handed to the
 //     rows through the wave's LDS buffer (HalfTileRows, as the fp32 panel kernel's second pass does), eta_diff of the
 //     tile's 64 columns sits in LDS as doubles (broadcast reads); the next half tile's loads are in flight while the
@@ -697,6 +587,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_exact_ke
                 const U* __restrict__ col0 = base + ct * kPanel;
                 h0.load_co(col0, bd.stride, r0, b, lane);
                 h1.load_co(col0 + kPanel / 2, bd.stride, r0, b, lane);
+                const bool diag = ct == r0 / kPanel;              // the tile that holds the rows' own diagonal (wave-uniform)
                 auto accumulate = [&](const H& h, int c0) {
 #pragma unroll
                     for (int i = 0; i < H::N; ++i) {
@@ -704,8 +595,11 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_exact_ke
 #pragma unroll
                         for (int x = 0; x < H::C; x += 2) {
                             const double2 ee = ep[x >> 1];
-                            s = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x), ee.x, s);
-                            s = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x + 1), ee.y, s);
+                            const int cc = c0 + H::C * i + x;     // column inside the tile; this lane's row sits at `lane`
+                            const T t0 = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x), ee.x, s);
+                            s = (diag && cc <= lane) ? s : t0;
+                            const T t1 = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x + 1), ee.y, s);
+                            s = (diag && cc + 1 <= lane) ? s : t1;
                         }
                     }
                 };
@@ -737,157 +631,6 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_exact_ke
             }
         }
         if (live) A.q[s0 + r0 + lane] += A.dq * s;                 // e_step.hpp:335
-    }
-}
-
-// The same pass over the repacked dense blocks, software-pipelined.  The kernel above spends one round trip to memory
-// per 64 * CPT columns of a group and as long again on the arithmetic, two waves per SIMD (the row registers): it ran at
-// ~1.5 TB/s.  Here a wave walks its work as a sequence of UNITS -- (group, batch of 64 * CPT columns) -- and the loads of
-// unit i + 1 (8 row vectors + the eta_diff values under them) are issued before the arithmetic of unit i; group records
-// and block descriptors are fetched three / two items ahead.  The sums are formed in the same order as above (bitwise
-// the same q).
-template <typename U>
-__global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_dense_kernel(EStepArgs<double> A0,
-                                                                                    const int64_t* __restrict__ groups,
-                                                                                    int64_t n_groups) {
-    using T = double;
-    // (at most 8 columns per lane and unit: two units of rows + eta_diff are in registers at a time)
-    constexpr int CPT = tile_cpt<U>() < 8 ? tile_cpt<U>() : 8;
-    constexpr int R = kTileGroupRows;
-    constexpr int kSpan = CPT * 64;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * kTileThreads + threadIdx.x) >> 6));
-    const int64_t n_waves = (int64_t)gridDim.x * (kTileThreads / 64);
-    const int n_models = max(1, A0.n_active);
-    const U* __restrict__ ld = static_cast<const U*>(A0.ld_dense);
-
-    struct Unit {                 // wave-uniform
-        int64_t voff;             // model offset + first SNP of the block: index into eta_diff / q
-        int64_t row_off;          // element offset of row `row0` of the block in the dense LD buffer
-        int size, stride, row0, nr, cb0;
-        bool valid, first, last;
-    };
-    struct Batch {
-        UVec<U, CPT> r[R];
-        T e[CPT];
-    };
-
-    // The fetch cursor: the current item = (group record g, model slot m) with descriptor bd, batch starting at column
-    // cb0; one and two items ahead: (g1, m1, bd1) and (g2, m2).  A wave takes the items wave, wave + n_waves, ...;
-    // (l_idx, l_model) = the item two ahead in (group, model) coordinates, advanced without a 64-bit division.
-    // (A queue of chunks of items instead -- the pass of one block class runs next to the sweep of the other, waves on
-    //  the busy CUs fall behind -- was measured: thousands of waves on one counter cost more than the imbalance,
-    //  EXPERIMENTS.md 4.4.)
-    const int ng = (int)n_groups;
-    const int step_idx = (int)(n_waves % n_groups), step_model = (int)(n_waves / n_groups);
-    auto record = [&](int idx, int model) { return model < n_models ? groups[idx] : (int64_t)0; };   // (beyond the end: a valid dummy)
-    auto desc_of = [&](int64_t gg) { return A0.blocks[(int)(gg >> 32)]; };
-    auto first_cb = [&](int64_t gg) { return ((int)(uint32_t)gg + 1) & ~(CPT - 1); };
-    int m = (int)(wave / n_groups), m1 = (int)((wave + n_waves) / n_groups), l_model = (int)((wave + 2 * n_waves) / n_groups);
-    int l_idx = (int)((wave + 2 * n_waves) % n_groups);
-    int64_t g = record((int)(wave % n_groups), m), g1 = record((int)((wave + n_waves) % n_groups), m1), g2 = record(l_idx, l_model);
-    int m2 = l_model;
-    BlockDesc bd = desc_of(g), bd1 = desc_of(g1);
-    int cb0 = first_cb(g);
-    auto unit = [&]() {
-        Unit u;
-        u.valid = m < n_models;
-        u.row0 = (int)(uint32_t)g;
-        u.size = bd.size;
-        u.stride = bd.stride;
-        u.nr = min(R, bd.size - u.row0);
-        u.cb0 = cb0;
-        u.first = cb0 == first_cb(g);
-        u.last = cb0 + kSpan >= bd.size;
-        const int64_t moff = A0.n_active > 0 && u.valid ? (int64_t)A0.active[m] * A0.m : 0;
-        u.voff = moff + bd.start;
-        u.row_off = bd.ld_off + (int64_t)u.row0 * bd.stride;
-        return u;
-    };
-    auto advance = [&]() {
-        if (cb0 + kSpan < bd.size) { cb0 += kSpan; return; }
-        g = g1; g1 = g2;
-        m = m1; m1 = m2;
-        l_idx += step_idx;
-        l_model += step_model;
-        if (l_idx >= ng) { l_idx -= ng; ++l_model; }
-        m2 = l_model;
-        g2 = record(l_idx, l_model);
-        bd = bd1;
-        bd1 = desc_of(g1);
-        cb0 = first_cb(g);
-    };
-    // The loads of a unit, no branches and no values to merge afterwards (they must stay in flight behind the arithmetic
-    // of the unit before): a lane beyond the end of the block loads the block's last vector / last eta_diff once more
-    // and has its eta_diff values replaced by 0 when they are used (LD elements are finite: they add 0); a unit beyond
-    // the end of the wave's work loads from block 0 and is never used.
-    auto fetch = [&](Batch& b, const Unit& u) {
-        const int cb = u.cb0 + CPT * lane;
-        const T* __restrict__ ed = A0.eta_diff + u.voff;
-#pragma unroll
-        for (int x = 0; x < CPT; ++x) b.e[x] = ed[min(cb + x, u.size - 1)];
-        const int cbr = min(cb, (u.size - 1) & ~(CPT - 1));        // (rows are padded to 64)
-#pragma unroll
-        for (int k = 0; k < R; ++k)      // (the rows of the group beyond the block repeat its last row and are not stored)
-            b.r[k] = *reinterpret_cast<const UVec<U, CPT>*>(ld + u.row_off + (int64_t)min(k, u.nr - 1) * u.stride + cbr);
-    };
-
-    T s[R];
-    // the arithmetic of unit uc (its loads are in c) behind the loads of the unit after it
-    auto step = [&](Batch& c, const Unit& uc, Batch& n, Unit& un) {
-        advance();
-        un = unit();
-        fetch(n, un);
-        if (uc.first) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) s[k] = 0;
-        }
-        // (no window test: exact zeros on and left of the diagonal and in the padding, e is 0 beyond the block; a group
-        //  whose rows all have empty windows -- the last row of a block alone -- adds nothing, as above)
-        if (uc.row0 + 1 < uc.size) {
-            const int cb = uc.cb0 + CPT * lane;
-            T e[CPT];
-#pragma unroll
-            for (int x = 0; x < CPT; ++x) e[x] = cb + x < uc.size ? c.e[x] : (T)0;
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-#pragma unroll
-                for (int x = 0; x < CPT; ++x) s[k] = __builtin_fma(static_cast<T>(c.r[k].v[x]), e[x], s[k]);
-        }
-        if (uc.last) {
-            // the 8 row sums across the 64 lanes at once (see the kernel above)
-            T t4[4], t2[2], t1;
-            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const T give = b0 ? s[2 * j] : s[2 * j + 1], keep = b0 ? s[2 * j + 1] : s[2 * j];
-                t4[j] = keep + __shfl_xor(give, 1);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const T give = b1 ? t4[2 * j] : t4[2 * j + 1], keep = b1 ? t4[2 * j + 1] : t4[2 * j];
-                t2[j] = keep + __shfl_xor(give, 2);
-            }
-            {
-                const T give = b2 ? t2[0] : t2[1], keep = b2 ? t2[1] : t2[0];
-                t1 = keep + __shfl_xor(give, 4);
-            }
-            t1 += __shfl_xor(t1, 8);
-            t1 += __shfl_xor(t1, 16);
-            t1 += __shfl_xor(t1, 32);
-            if (lane < R && lane < uc.nr) A0.q[uc.voff + uc.row0 + lane] += A0.dq * t1;
-        }
-    };
-    static_assert(R == 8, "the butterfly above reduces 8 rows");
-    Batch ba, bb;
-    Unit ua = unit(), ub;
-    if (!ua.valid) return;
-    fetch(ba, ua);
-    for (;;) {
-        step(ba, ua, bb, ub);
-        if (!ub.valid) break;
-        step(bb, ub, ba, ua);
-        if (!ua.valid) break;
     }
 }
 

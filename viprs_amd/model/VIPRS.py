@@ -130,7 +130,11 @@ class VIPRS:
             elif _is_numeric(lambda_min):
                 self.lambda_min = lambda_min
             else:                                # 'infer': the reference keeps the LAST chromosome's value (:186-191)
-                self.lambda_min = ld_mat.get_lambda_min(min_max_ratio=1e-3)
+                try:
+                    self.lambda_min = ld_mat.get_lambda_min(min_max_ratio=1e-3)
+                except NotImplementedError as e:     # (a store whose ridge formula this build cannot verify: say where, and the remedy)
+                    raise type(e)(f"lambda_min='infer', chromosome {c}: {e}  Remedy: VIPRS(..., lambda_min=<number>), or "
+                                  "set `lambda_min_formula` on the LD matrix object.") from e
 
         self._shard = {}
         self._block_owner = {}                   # chromosome -> (block starts, owning rank of every block)

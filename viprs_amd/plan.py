@@ -286,9 +286,27 @@ class DeviceState:
             plan._states = weakref.WeakSet()
         plan._states.add(self)
         mode = placement if placement is not None else os.environ.get("VIPRS_STATE_PLACEMENT", "probe")
-        if (mode == "probe" and self.dtype == np.float32 and model in ("spike_slab", "mixture")
-                and plan.m >= self.PLACEMENT_MIN_SNPS and plan.n_blocks > 0):
-            self._probe_placement()
+        # (stream-bound sweeps only: fp32 state on the panel kernels -- dense blocks, mixtures of up to 8 components; a plan of
+        #  windowed components or a wide mixture is chain-bound and has no panel-kernel bracket to rank candidates by)
+        if (mode == "probe" and self.dtype == np.float32 and model in ("spike_slab", "mixture") and self.width <= 8
+                and plan.m >= self.PLACEMENT_MIN_SNPS and plan.info(L.INFO_N_DENSE) > 0):
+            own = self._h
+            try:
+                self._probe_placement()
+            except Exception as e:              # noqa: BLE001 -- a usable state exists: the probe must never fail the constructor
+                # (out of memory on the extra candidates, a team hand-off time-out when another process shares the GPU ...)
+                if self._h is not own and self._h:
+                    try:
+                        L.lib.viprs_state_destroy(self._h)
+                    except Exception:           # noqa: BLE001
+                        pass
+                self._h = own
+                self.placement = {"error": f"{type(e).__name__}: {e}"[:200], "chosen": 0}
+                try:                            # hand out what the caller was promised: a zeroed state
+                    self._zero_fields()
+                    self.plan.timing_reset()
+                except Exception:               # noqa: BLE001
+                    pass
 
     def _create(self):
         h = ctypes.c_void_p()
@@ -341,23 +359,30 @@ class DeviceState:
             for _ in range(2):                                       # two rounds: no candidate is only measured early
                 for i, h in enumerate(handles):
                     times[i] += list(sweeps(h, 5))
-            best = int(np.argmin([min(t) for t in times]))
+            mins = [min(t) if t else 0.0 for t in times]
+            # no decision when the timings say nothing: no panel-kernel bracket (zeros) or all candidates level (< 0.2 %)
+            decided = min(mins) > 0.0 and (max(mins) - min(mins)) > 2e-3 * min(mins)
+            best = int(np.argmin(mins)) if decided else 0
             self._h = handles[best]
-            zero = {k: np.zeros(self._shape(k), dtype=T) for k in
-                    ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult", "var_gamma", "var_mu", "eta", "q", "eta_diff")}
-            if self.model == "mixture":
-                zero["log_null_pi"] = np.zeros(m, dtype=T)
-            for k, a in zero.items():                                # handed out as a fresh state: all zeros
-                self.upload(k, a)
+            self._zero_fields()                                      # handed out as a fresh state: all zeros
             self.plan.timing_reset()
-            self.placement = {"candidates": len(handles), "chosen": best,
-                              "kernel_ms_min": [round(float(min(t)), 4) for t in times]}
+            self.placement = {"candidates": len(handles), "chosen": best, "decided": bool(decided),
+                              "kernel_ms_min": [round(float(x), 4) for x in mins]}
         finally:
             keep = self._h if self._h in handles else own
             for h in handles:
                 if h is not keep and h:
                     L.lib.viprs_state_destroy(h)
             self._h = keep
+
+    def _zero_fields(self):
+        T, m = self.dtype, self.plan.m
+        zero = {k: np.zeros(self._shape(k), dtype=T) for k in
+                ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult", "var_gamma", "var_mu", "eta", "q", "eta_diff")}
+        if self.model == "mixture":
+            zero["log_null_pi"] = np.zeros(m, dtype=T)
+        for k, a in zero.items():
+            self.upload(k, a)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
