@@ -386,13 +386,22 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                 T ql = qv[p0 + min(lane, np - 1)];
                 // the rows of the panel before onto these 64 columns first (e_step.hpp:421 for j in that panel; a skipped
                 // row carries a = 0: fma(r, 0, q) == q); 8 rows' LDS reads in flight at a time
+                // (Entries outside a row's window are staged as 0, and fma(0, a, q) == q only for a FINITE a: the reference does
+                //  not touch q outside the window whatever a is, so a column outside the window keeps its q by a select --
+                //  dense blocks: every column of this panel is inside the windows of the panel before, no test.)
                 if (p0 > 0) {
+                    const int* const ows = s_ws + (par ^ 1) * kPanel;
+                    const int* const owe = s_we + (par ^ 1) * kPanel;
                     for (int j0 = 0; j0 < kPanel; j0 += 8) {
                         T rr[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) rr[k] = static_cast<T>(tile_o[(j0 + k) * kPanel + lane]);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) ql = __builtin_fma(rr[k], readlane_f64(prev_a, j0 + k), ql);
+                        for (int k = 0; k < 8; ++k) {
+                            const T v = __builtin_fma(rr[k], readlane_f64(prev_a, j0 + k), ql);
+                            if constexpr (DENSE) ql = v;
+                            else ql = (p0 + lane >= ows[j0 + k] && p0 + lane < owe[j0 + k]) ? v : ql;
+                        }
                     }
                 }
                 TPROF(4);
@@ -404,9 +413,19 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                 // read from LDS while step jj computes, the skip branch (e_step.hpp:410-413) is a select -- a skipped SNP
                 // applies a = 0 (fma(r, 0, q) == q) and keeps its outputs.
                 T r_nxt = static_cast<T>(tile_d[lane]);
+                // is this lane's column inside the window of row jj?  (dense: right of the diagonal in the upper form, any
+                // column in the symmetric one; windowed rows: the row's own bounds, read one step ahead like the tile row)
+                const int* const dws = s_ws + par * kPanel;
+                const int* const dwe = s_we + par * kPanel;
+                bool in_nxt = DENSE ? (!A.low_memory || lane > 0) : (p0 + lane >= dws[0] && p0 + lane < dwe[0]);
                 for (int jj = 0; jj < np; ++jj) {
                     const T r = r_nxt;
+                    const bool in_win = in_nxt;
                     r_nxt = static_cast<T>(tile_d[min(jj + 1, kPanel - 1) * kPanel + lane]);
+                    {
+                        const int jn = min(jj + 1, kPanel - 1);
+                        in_nxt = DENSE ? (!A.low_memory || lane > jn) : (p0 + lane >= dws[jn] && p0 + lane < dwe[jn]);
+                    }
                     const T qj = readlane_f64(ql, jj);
                     const T eta_old = readlane_f64(c_eta, jj);
                     T mu[KM], gam[KM], d;
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                     const bool skip = MODEL::kSkip && fabs(d) < eps;                          // e_step.hpp:410
                     const T de = skip ? (T)0 : d;                                             // :412
                     const T a = A.dq * de;
-                    const T v = __builtin_fma(r, a, ql);                                      // :421, in-panel columns
+                    const T v = in_win ? __builtin_fma(r, a, ql) : ql;                        // :421, in-panel columns of the row's window
                     const bool own = lane == jj;
                     ql = (own && !A.low_memory) ? v - de : v;                                 // :427
                     const bool take = own && !skip;                                           // :416-418, :431
