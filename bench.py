@@ -500,15 +500,18 @@ def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exa
                           {1: SumstatsArrays(ss.std_beta, ss.n_per_snp)}, n=float(ss.n))
     stamps = []
     cb = lambda i: stamps.append(time.perf_counter())
-    out = {"name": f"fit_iteration {kind}", "unit": "ms per EM iteration", "iterations": iters, "warmup_iterations": warm,
-           "math_mode": math_mode, "snps": int(ld.m), "low_memory": lm}
+    # integer LD stays integer on the device (dequantize_on_the_fly, VIPRS.py:156-165: the published stores are int8)
+    dq_fly = bool(np.issubdtype(ld.ld_data.dtype, np.integer))
+    out = {"name": f"fit_iteration {kind}" + (f", {ld.ld_data.dtype.name} LD" if dq_fly else "") + (", math_mode=fast" if math_mode == "fast" else ""),
+           "unit": "ms per EM iteration", "iterations": iters, "warmup_iterations": warm,
+           "math_mode": math_mode, "snps": int(ld.m), "low_memory": lm, "ld_dtype": ld.ld_data.dtype.name}
     if kind.startswith("VIPRSGrid"):
         from viprs_amd.model.gridsearch.HyperparameterGrid import HyperparameterGrid
         from viprs_amd.model.gridsearch.VIPRSGrid import VIPRSGrid
         grid = HyperparameterGrid(n_snps=gdl.m)
         grid.generate_pi_grid(steps=8)
         grid.generate_sigma_epsilon_grid(steps=4)
-        model = VIPRSGrid(gdl, grid, low_memory=lm, device=device, math_mode=math_mode)
+        model = VIPRSGrid(gdl, grid, low_memory=lm, device=device, math_mode=math_mode, dequantize_on_the_fly=dq_fly)
         model.fit(max_iter=warm + iters, min_iter=warm + iters + 1, batched=True, on_iteration=cb)
         plan = next(iter(model._plans.values()))
         out["models"] = int(model.n_models)
@@ -516,14 +519,15 @@ def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exa
         # a FIXED start (the reference draws pi and h2 at random when none is given, VIPRS.py:260-292: run-to-run
         # different trajectories): pi = 0.01, sigma_epsilon = 0.8, the start of the sweep benchmark
         if kind.startswith("VIPRSMix"):
-            model = VIPRSMix(gdl, K=4, low_memory=lm, device=device, math_mode=math_mode)
+            model = VIPRSMix(gdl, K=4, low_memory=lm, device=device, math_mode=math_mode, dequantize_on_the_fly=dq_fly)
             theta = {"pis": np.full(4, 0.01 / 4), "sigma_epsilon": 0.8}
         else:
-            model = VIPRS(gdl, low_memory=lm, device=device, math_mode=math_mode)
+            model = VIPRS(gdl, low_memory=lm, device=device, math_mode=math_mode, dequantize_on_the_fly=dq_fly)
             theta = {"pi": 0.01, "sigma_epsilon": 0.8}
         out["theta_0"] = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in theta.items()}
         model.fit(max_iter=warm + iters, min_iter=warm + iters + 1, theta_0=theta, on_iteration=cb)
         plan = next(iter(model._plans.values()))
+    out["math_mode_effective"] = plan.effective_math_mode()
     out["iterations_run"] = len(stamps)
     out["message"] = str(getattr(getattr(model, "optim_result", None), "message", ""))[:80]
     if len(stamps) < warm + 3:
@@ -562,6 +566,39 @@ def measure_fit_iteration(kind, ld, ss, device, iters=12, warm=3, math_mode="exa
         ph = ph / n2 * 1e3
         out["split_ms"] = {"prep_launch_sync": max(0.0, ph[0] - sweep), "sweep_kernels": sweep, "sums_reduce_readback": ph[2],
                            "host_mstep_elbo_rules": ph[3], "sum_with_syncs": float(ph[0] + ph[2] + ph[3])}
+    else:
+        # the batched grid iteration, phase by phase (all models active; the hyper-parameters keep moving as in the fit)
+        import copy
+        em, states, all_sums = model._lockstep
+        em = copy.deepcopy(em)
+        sync = lambda: _lib_sync(device)
+        a = np.arange(model.n_models, dtype=np.int32)
+        ph = np.zeros(5)
+        n2 = max(5, iters // 2)
+        plan.timing_reset()
+        for it in range(n2):
+            t0 = time.perf_counter()
+            rows = em.prep_rows(a)
+            for st in states.values():
+                st.prep_columns(rows)
+            sync()
+            t1 = time.perf_counter()
+            for st in states.values():
+                st.e_step(model.dequantize_scale, active_model_idx=a, sync=False)
+            sync()
+            t2 = time.perf_counter()
+            s_ = all_sums(a)
+            t3 = time.perf_counter()
+            em.update(a, s_, 10_000 + it)
+            t4 = time.perf_counter()
+            ph += (t1 - t0, t2 - t1, 0.0, t3 - t2, t4 - t3)
+        kk = plan.timing_history(which=0)
+        sweep = float(np.mean(kk)) if kk else 0.0
+        ph = ph / n2 * 1e3
+        out["split_ms"] = {"prep_columns_launch_sync": ph[0], "sweep_launch_sync": ph[1], "sweep_kernels": sweep,
+                           "sums_columns_reduce_readback": ph[3], "host_mstep_elbo_rules": ph[4],
+                           "sum_with_syncs": float(ph[0] + ph[1] + ph[3] + ph[4])}
+        out["ms_per_iteration_max_over_median"] = float(np.max(d) / np.median(d)) if len(d) else None
     try:
         model.close()
     except Exception:
@@ -943,6 +980,18 @@ def main():
             if args.config in ("cfg3", "cfg2"):
                 for kind in ("VIPRS", "VIPRSMix(K=4)", "VIPRSGrid(32 models, batched)"):
                     secondary.append(measure_fit_iteration(kind, ld, ss, device, math_mode=args.math))
+            if args.config == "cfg3" and args.math == "exact":
+                # the published store format (int8, upper-triangular) end to end, exact and math_mode="fast" (inside north_star's
+                # 1e-5 where the problem is well conditioned; tests/test_gpu_fast_math.py): fast shortens the chain step, the
+                # floor of this format's sweep
+                import copy
+                ld8 = copy.copy(ld)
+                ld8.ld_data = np.rint(ld.ld_data * np.float32(127.0)).astype(np.int8)      # = make_ld(..., ld_dtype=int8), tests/test_synth_device.py
+                ld8.dq_scale = 1.0 / 127.0
+                for mm in ("exact", "fast"):
+                    for kind in ("VIPRS", "VIPRSMix(K=4)", "VIPRSGrid(32 models, batched)"):
+                        secondary.append(measure_fit_iteration(kind, ld8, ss, device, math_mode=mm))
+                del ld8
             if args.config == "cfg3":
                 # the reference's default operating mode: one model per chromosome -- 22 of them in one lock-step batch
                 secondary.append(measure_per_chromosome(ld, ss, device, math_mode=args.math))

@@ -159,6 +159,39 @@ def test_fit_fixtures_in_fast_mode(gpu):
     assert n >= 7
 
 
+def test_grid_and_per_chromosome_fits_in_fast_mode(gpu):
+    """math_mode="fast" as a fit option for the other two drivers (round 6): the serial and the batched grid fit against
+    the `fitgrid_*` fixtures and the lock-step per-chromosome fit against the `fitchr_*` fixtures, at the SAME tolerances as
+    exact mode -- `nit`, stopping messages, ELBO, hyper-parameters, posterior."""
+    import os
+    from tests import test_grid as TG
+    from tests import test_per_chromosome as TP
+    from tests.test_fit import loader_from_fixture
+    from viprs_amd.model import VIPRSGrid
+    for name in ("fitgrid_pathwise", "fitgrid_independent"):
+        fx = np.load(os.path.join(TG.HERE, "golden", name + ".npz"))
+        gdl = loader_from_fixture(fx)
+        model = VIPRSGrid(gdl, TG._grid(fx, gdl.m), low_memory=True, math_mode="fast")
+        model.fit(pathwise=bool(fx["pathwise"]), max_iter=80)
+        assert all(p.effective_math_mode() == "fast" for p in model._plans.values())
+        TG._check(model, fx)
+    fx = np.load(os.path.join(TG.HERE, "golden", "fitgrid_independent.npz"))
+    gdl = loader_from_fixture(fx)
+    exact = VIPRSGrid(gdl, TG._grid(fx, gdl.m), low_memory=True).fit(batched=True, max_iter=80)
+    fast = VIPRSGrid(gdl, TG._grid(fx, gdl.m), low_memory=True, math_mode="fast").fit(batched=True, max_iter=80)
+    assert all(p.effective_math_mode() == "fast" for p in fast._plans.values())
+    assert [r.nit for r in fast.optim_results] == [r.nit for r in exact.optim_results]
+    assert [r.message for r in fast.optim_results] == [r.message for r in exact.optim_results]
+    np.testing.assert_allclose(fast.model_elbos, exact.model_elbos, rtol=2e-7)
+    np.testing.assert_allclose(fast.post_mean_beta[22], exact.post_mean_beta[22], rtol=2e-3, atol=2e-7)
+    np.testing.assert_allclose(fast.pip[22], exact.pip[22], rtol=2e-3, atol=2e-6)
+    for path in TP.FITCHR:
+        fx = np.load(path)
+        model = TP.build(fx, e_step="hip", math_mode="fast").fit(max_iter=100, theta_0=TP.theta_of(fx))
+        assert model._plans["*"].effective_math_mode() == "fast"
+        TP.check_against_fixture(model, fx, device_sums=True)
+
+
 @pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])
 @pytest.mark.parametrize("model", ["spike_slab", "mixture", "grid"])
 def test_fast_math_windowed_components(gpu, fast_mode, model, low_memory):

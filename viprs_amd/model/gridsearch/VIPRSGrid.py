@@ -273,6 +273,7 @@ class VIPRSGrid(VIPRS):
             if on_iteration is not None:
                 on_iteration(i)
         em.finish()
+        self._lockstep = (em, states, all_sums)        # (measurement hook: bench.py takes an iteration apart phase by phase)
         results, sigma_g, elbos = em.results, em.sigma_g, em.elbos
         # back into the per-model records the publishing code reads (in the serial fit's dtypes)
         for g in range(G):
