@@ -161,8 +161,8 @@ def test_fit_fixtures_in_fast_mode(gpu):
 
 def test_grid_and_per_chromosome_fits_in_fast_mode(gpu):
     """math_mode="fast" as a fit option for the other two drivers (round 6): the serial and the batched grid fit against
-    the `fitgrid_*` fixtures and the lock-step per-chromosome fit against the `fitchr_*` fixtures, at the SAME tolerances as
-    exact mode -- `nit`, stopping messages, ELBO, hyper-parameters, posterior."""
+    the `fitgrid_*` fixtures and the lock-step per-chromosome fit against the `fitchr_*` fixtures: `nit`, stopping messages,
+    ELBO and hyper-parameters at the exact mode's tolerances, the posterior at them but for isolated skip-branch flips."""
     import os
     from tests import test_grid as TG
     from tests import test_per_chromosome as TP
@@ -174,14 +174,25 @@ def test_grid_and_per_chromosome_fits_in_fast_mode(gpu):
         model = VIPRSGrid(gdl, TG._grid(fx, gdl.m), low_memory=True, math_mode="fast")
         model.fit(pathwise=bool(fx["pathwise"]), max_iter=80)
         assert all(p.effective_math_mode() == "fast" for p in model._plans.values())
-        TG._check(model, fx)
+        # Iteration counts, messages, ELBO and hyper-parameters at the exact mode's tolerances.  The posterior: e_step's skip
+        # branch (e_step.hpp:410-413) freezes a SNP whose update falls below float epsilon, and a sigmoid that differs in
+        # the last place can take the other branch for a single SNP on a single sweep -- one of 5 400 PIPs of
+        # `fitgrid_independent` ends 1.2 % off (3e-5 absolute).  So: at most 0.1 % of the entries beyond the exact mode's
+        # 5e-3, none beyond 2e-2.
+        TG._check(model, fx, rtol_post=2e-2)
+        for name_, atol in (("pip", 5e-6), ("post_mean_beta", 5e-7)):
+            got, ref = getattr(model, name_)[22], fx[f"{name_}_22"]
+            bad = np.abs(got - ref) > atol + 5e-3 * np.abs(ref)
+            assert bad.mean() <= 1e-3, f"{name}: {int(bad.sum())} of {bad.size} entries of {name_} beyond the exact mode's tolerance"
     fx = np.load(os.path.join(TG.HERE, "golden", "fitgrid_independent.npz"))
     gdl = loader_from_fixture(fx)
     exact = VIPRSGrid(gdl, TG._grid(fx, gdl.m), low_memory=True).fit(batched=True, max_iter=80)
     fast = VIPRSGrid(gdl, TG._grid(fx, gdl.m), low_memory=True, math_mode="fast").fit(batched=True, max_iter=80)
     assert all(p.effective_math_mode() == "fast" for p in fast._plans.values())
     assert [r.nit for r in fast.optim_results] == [r.nit for r in exact.optim_results]
-    assert [r.message for r in fast.optim_results] == [r.message for r in exact.optim_results]
+    # (which of two success rules fires first on the stopping iteration -- ELBO within 1e-6 or max |eta_diff| < 1e-6 -- can
+    #  differ: the ELBOs agree to ~5e-9 relative, i.e. ~6e-4 absolute)
+    assert [r.success for r in fast.optim_results] == [r.success for r in exact.optim_results]
     np.testing.assert_allclose(fast.model_elbos, exact.model_elbos, rtol=2e-7)
     np.testing.assert_allclose(fast.post_mean_beta[22], exact.post_mean_beta[22], rtol=2e-3, atol=2e-7)
     np.testing.assert_allclose(fast.pip[22], exact.pip[22], rtol=2e-3, atol=2e-6)
@@ -189,7 +200,7 @@ def test_grid_and_per_chromosome_fits_in_fast_mode(gpu):
         fx = np.load(path)
         model = TP.build(fx, e_step="hip", math_mode="fast").fit(max_iter=100, theta_0=TP.theta_of(fx))
         assert model._plans["*"].effective_math_mode() == "fast"
-        TP.check_against_fixture(model, fx, device_sums=True)
+        TP.check_against_fixture(model, fx, device_sums=True, fast=True)
 
 
 @pytest.mark.parametrize("low_memory", [False, True], ids=["symmetric", "upper"])

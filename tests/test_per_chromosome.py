@@ -41,11 +41,13 @@ def build(fx, e_step="oracle", **extra):
     return VIPRSPerChromosome(loader_from_fixture(fx), **model_kwargs(fx, e_step, **extra))
 
 
-def check_against_fixture(model, fx, device_sums=False):
+def check_against_fixture(model, fx, device_sums=False, fast=False):
     # Long-range LD is ill-conditioned: the reference's own posterior moves by up to 7e-4 per entry when ITS std_beta changes
     # by one ulp.  The device-resident iteration forms the M-step sums in float64 in a fixed order where the
     # reference calls np.sum, so after ~40 iterations single entries of pip sit ~1e-5 from the fixture (1 of 550 here).
     pip_atol = 2e-5 if (device_sums and str(fx["ld_kind"]) != "ar1") else 2e-6
+    if fast and str(fx["ld_kind"]) != "ar1":
+        pip_atol = 1e-4          # math_mode="fast" on that LD: still well inside the 7e-4 the reference itself moves by (one ulp)
     q = model.q_full if model.comm.world_size > 1 else model.q
     assert sorted(model.pip) == sorted(int(c) for c in fx["chroms"])
     for c in (int(c) for c in fx["chroms"]):
@@ -53,7 +55,10 @@ def check_against_fixture(model, fx, device_sums=False):
         assert len(h) == len(ref), f"chromosome {c}: {len(h)} ELBO entries, the reference's own fit has {len(ref)}"
         np.testing.assert_allclose(h, ref, rtol=2e-7, atol=0.05)
         r = model.optim_results[c]
-        assert (r.nit, r.success, r.message) == (int(fx[f"nit_{c}"]), bool(fx[f"success_{c}"]), str(fx[f"message_{c}"]))
+        # (math_mode="fast": the ELBO moves by ~5e-9 relative, and WHICH success rule fires first on the stopping iteration --
+        #  ELBO within 1e-6 or max |eta_diff| < 1e-6 -- may differ; the iteration itself does not)
+        assert (r.nit, r.success) == (int(fx[f"nit_{c}"]), bool(fx[f"success_{c}"]))
+        assert fast or r.message == str(fx[f"message_{c}"])
         np.testing.assert_allclose(np.float64(model.pi[c]), fx[f"final_pi_{c}"], rtol=2e-4)
         np.testing.assert_allclose(np.float64(model.tau_beta[c]), fx[f"final_tau_beta_{c}"], rtol=2e-4)
         np.testing.assert_allclose(float(model.sigma_epsilon[c]), float(fx[f"final_sigma_epsilon_{c}"]), rtol=1e-5)
