@@ -60,29 +60,6 @@ def test_one_plan_alternating_kernel_families(gpu, ld_dtype):
         S.clear_plan_cache()
 
 
-@pytest.mark.parametrize("model", ["spike_slab", "mixture", "grid"])
-def test_packed_form_behind_the_switch(gpu, model, monkeypatch):
-    """VIPRS_UPPER_MIRROR=0: the panel and grid kernels keep the packed upper-triangular form (the round-4 kernels: per-row
-    running sums through an LDS transposition; the grid's epilogue kernel) -- same bits."""
-    from viprs_amd.vi import e_step_hip as S
-    monkeypatch.setenv("VIPRS_UPPER_MIRROR", "0")
-    ld, ss, inp = syn.make_problem(sizes=[130, 1700, 64, 700], low_memory=True, seed=62, kind="longrange")
-    S.clear_plan_cache()
-    try:
-        if model == "spike_slab":
-            st0 = inp.state_copy()
-            H.assert_state_equal(H.run_hip(ld, inp, st0, sweeps=2), H.run_oracle(ld, inp, st0, sweeps=2))
-        elif model == "mixture":
-            mix, st0 = _mixture_inputs(ld, ss, 4)
-            H.assert_state_equal(_run_mix(S, ld, inp, mix, st0, 2), _run_mix(O, ld, inp, mix, st0, 2))
-        else:
-            g, st0 = _grid_inputs(ld, ss, 32)
-            active = np.arange(32, dtype=np.int32)
-            H.assert_state_equal(_run_grid(S, ld, inp, g, st0, active), _run_grid(O, ld, inp, g, st0, active))
-    finally:
-        S.clear_plan_cache()
-
-
 def test_mirrored_grid_with_a_partial_last_tile_and_few_models(gpu):
     """Batched grid kernel over mirrored blocks: block sizes around the 128-column tile / 64-row panel edges (the triangular
     half of a diagonal tile, the read-modify-write of q at the end of a block), a team block, 5 active models out of 7."""

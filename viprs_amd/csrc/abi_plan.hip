@@ -179,11 +179,6 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         sched_config() = c;
     }
     P->low_memory = low_memory != 0;
-    {
-        // (VIPRS_UPPER_MIRROR=0: the panel kernels keep the packed upper form -- kFormUpper, estep_panel.h)
-        const char* e = getenv("VIPRS_UPPER_MIRROR");
-        P->use_mirror = (e && *e) ? (atoi(e) != 0) : true;
-    }
     P->ld_dtype = ld_dtype;
     P->device = device;
     std::string err;
@@ -214,11 +209,12 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         d.ld_off = 0;
         d.gr_off = 0;
         d.band_left = d.band_right = 0;
-        // the panel kernels keep q of a whole block in LDS: a dense block beyond that (~13 000 SNPs) is
-        // scheduled like a windowed component (band kernel if its ring fits, generic kernel otherwise).  The binding
-        // case is the upper-triangular form (q and the second-pass sums s, no off-diagonal tile in LDS)
-        constexpr int kMaxDenseBlock = (160 * 1024 / 4 - panel_lds_floats(kStrip) - panel_upper_lds_floats(kStrip) - kMixLdsFloats) / 2 / kPanel * kPanel;
-        static_assert(kMaxDenseBlock + kStrip + panel_lds_floats(kStrip, true) + kMixLdsFloats <= 160 * 1024 / 4, "symmetric form fits too");
+        // the panel kernels keep q of a block (teams: of a member's strips) in LDS: a dense block beyond ~13 000 SNPs is
+        // scheduled like a windowed component (band kernel if its ring fits, generic kernel otherwise).  (The limit as
+        // rounds 3-5 derived it from the packed upper form's LDS carve; a team of up to 16 members fits any block below it.)
+        constexpr int kMaxDenseBlock = 13184;
+        static_assert(kMaxDenseBlock % kPanel == 0, "whole panels");
+        static_assert(kMaxDenseBlock + kStrip + panel_lds_floats(kStrip, true) + kMixLdsFloats <= 160 * 1024 / 4, "the symmetric form fits one workgroup");
         const bool dense = panel_ld && (b.kind == VIPRS_BLOCK_DENSE_SYM || b.kind == VIPRS_BLOCK_DENSE_UPPER) &&
                            d.size <= kMaxDenseBlock;
         if (dense) {
@@ -371,53 +367,6 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
-        if (!P->low_memory) {
-            // batched grid E-step, symmetric form: the columns left of the chain are finished by
-            // estep_grid_lower_pass_kernel, one item per 128-column tile that has rows below it, longest first
-            std::vector<EpiItem> low;
-            for (size_t i = 0; i < P->dense_h.size(); ++i) {
-                const int np = (P->dense_h[i].size + kPanel - 1) / kPanel;
-                for (int T = 0; 2 * T + 1 < np; ++T) low.push_back({(int32_t)i, T});
-            }
-            // items of the blocks beyond the batched kernel's resident form first (the only ones it leaves to the lower
-            // pass by default), each group longest first
-            constexpr int kResMax = kGridResMaxCols;                // (kernels_common.h)
-            std::stable_sort(low.begin(), low.end(), [&](const EpiItem& x, const EpiItem& y) {
-                const int bx = P->dense_h[(size_t)x.blk].size, by = P->dense_h[(size_t)y.blk].size;
-                const bool gx = bx > kResMax, gy = by > kResMax;
-                if (gx != gy) return gx;
-                const int npx = (bx + kPanel - 1) / kPanel, npy = (by + kPanel - 1) / kPanel;
-                return npx - 2 * x.row0 > npy - 2 * y.row0;
-            });
-            P->n_low_items = (int64_t)low.size();
-            P->n_low_items_big = 0;
-            for (const EpiItem& it : low) P->n_low_items_big += P->dense_h[(size_t)it.blk].size > kResMax ? 1 : 0;
-            std::vector<EpiItem> split;
-            for (int64_t i = 0; i < P->n_low_items_big; ++i)
-                for (int jh = 0; jh < 2; ++jh) split.push_back({low[(size_t)i].blk, 2 * low[(size_t)i].row0 + jh});
-            P->n_low_split = (int64_t)split.size();
-            if (!split.empty()) {
-                HIP_TRY(P->d_low_split.alloc(split.size()));
-                HIP_TRY(hipMemcpy(P->d_low_split.p, split.data(), sizeof(EpiItem) * split.size(), hipMemcpyHostToDevice));
-            }
-            if (!low.empty()) {
-                HIP_TRY(P->d_low_items.alloc(low.size()));
-                HIP_TRY(hipMemcpy(P->d_low_items.p, low.data(), sizeof(EpiItem) * low.size(), hipMemcpyHostToDevice));
-            }
-        }
-        if (P->low_memory) {
-            // (block, 64-row group) items of the batched grid second pass, plan-wide block indices, longest rows
-            // first (the item cost is the number of columns right of its rows)
-            std::vector<EpiItem> all;
-            for (int i = 0; i < (int)P->dense_h.size(); ++i)
-                for (int r0 = 0; r0 < P->dense_h[(size_t)i].size; r0 += kPanel) all.push_back({(int32_t)i, r0});
-            std::stable_sort(all.begin(), all.end(), [&](const EpiItem& x, const EpiItem& y) {
-                return P->dense_h[(size_t)x.blk].size - x.row0 > P->dense_h[(size_t)y.blk].size - y.row0;
-            });
-            P->n_epi = (int64_t)all.size();
-            HIP_TRY(P->d_epi_all.alloc(all.size()));
-            HIP_TRY(hipMemcpy(P->d_epi_all.p, all.data(), sizeof(EpiItem) * all.size(), hipMemcpyHostToDevice));
-        }
     }
     if (!P->ragged_h.empty()) {
         HIP_TRY(P->d_ragged.alloc(P->ragged_h.size()));

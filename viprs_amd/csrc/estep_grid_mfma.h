@@ -23,11 +23,12 @@
 //                      the 64-column tile the chain needs next across the barrier (tile_*).  They also
 //                      stage the next panel's inputs / diagonal tile and flush the previous panel's outputs.
 //
-// q of the block stays in global memory (the (m, G) state itself): per phase the tiles right of the chain
-// are read and written once.  The columns LEFT of the chain (symmetric form) are finished after the sweep by
-// estep_grid_lower_pass_kernel with the accumulators resident in registers; the upper-triangular form's
-// second pass is estep_grid_upper_epilogue_kernel.  One workgroup per LD block, blocks pulled from a queue
-// in descending size.
+// q of a block lives in the accumulator registers of the updater waves for as long as the block is swept (resident form,
+// grid_block_resident below): one workgroup per block of up to kGridResMaxCols SNPs (blocks pulled from a queue in
+// descending size), a TEAM of workgroups with a migrating chain for larger blocks.  The columns LEFT of the chain keep
+// receiving the later rows from the same accumulators -- the symmetric form's updates, and, over the MIRRORED storage of the
+// upper-triangular form, the second-pass sums of update_q_factor_matrix (e_step.hpp:266-303).  (Rounds 2-5 also carried a
+// streaming form with a lower-pass kernel and an epilogue kernel over the packed upper triangle; removed in round 6.)
 #pragma once
 #include "device_math.h"
 #include "estep_panel.h"
@@ -72,44 +73,6 @@ __device__ __forceinline__ void tile_load_rows(float (&R)[kPanel], const U* __re
     asm volatile("" ::: "memory");      // all 64 loads go out here (hipcc would sink each one to its MFMA)
 }
 
-// accumulators: C[model][col], col = lane & 31 (+32 for acc1), model = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-__device__ __forceinline__ void tile_load_acc(f32x16& acc0, f32x16& acc1, const EStepArgs<float>& A, const int* act, int64_t s0, int b,
-                                              int ct, int n_models, int lane) {
-    const int half = lane >> 5, c = ct * kPanel + (lane & 31);
-    const bool ok0 = c < b, ok1 = c + 32 < b;
-    float v0[16], v1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const unsigned col_off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0;      // m * G < 2^31 (host-checked)
-        v0[r] = A.q[col_off + (ok0 ? c : 0)];
-        v1[r] = A.q[col_off + (ok1 ? c + 32 : 0)];
-    }
-    asm volatile("" ::: "memory");      // issue all 32 loads before the first use
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool okg = g < n_models;
-        acc0[r] = (okg && ok0) ? v0[r] : 0.0f;
-        acc1[r] = (okg && ok1) ? v1[r] : 0.0f;
-    }
-}
-
-__device__ __forceinline__ void tile_store_acc(const f32x16& acc0, const f32x16& acc1, const EStepArgs<float>& A,
-                                               const int* act, int64_t s0, int b, int ct, int n_models, int lane) {
-    const int half = lane >> 5, c = ct * kPanel + (lane & 31);
-    const bool ok0 = c < b, ok1 = c + 32 < b;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (g < n_models) {
-            const unsigned col_off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0;
-            if (ok0) A.q[col_off + c] = acc0[r];
-            if (ok1) A.q[col_off + c + 32] = acc1[r];
-        }
-    }
-}
-
 // 64 MFMAs: rows (kr, kr + 1) of the panel per pair, k ascending
 // (SCALED: the LDS array holds eta_diff, the A operand is scale * eta_diff -- the mirrored upper form, grid_block_resident)
 template <bool SCALED = false>
@@ -135,26 +98,6 @@ __device__ __forceinline__ void tile_compute(f32x16& acc0, f32x16& acc1, const f
 // (the memory pipeline takes at most 63 per wave, which throttles the 64-column version).
 template <typename U> struct Vec4 { typedef U type __attribute__((ext_vector_type(4))); };
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // q columns start at arbitrary offsets
-
-template <typename U>
-__device__ __forceinline__ void wtile_load_rows(f32x4 (&R)[kPanel / 2], const U* __restrict__ base, int stride, int rp,
-                                                int c0, int lane) {
-    using V = typename Vec4<U>::type;
-    // uniform base + one 32-bit lane offset: the row step is scalar arithmetic (no per-row VGPR address).
-    // Rows past the end of the block (last, partial panel) are read as they lie in memory -- the next
-    // block's rows or the zeroed slack behind the last block -- and meet a = 0 (the plan allocates the slack).
-    int col = c0 + 4 * (lane & 31);
-    if (col >= stride) col = c0;                      // right half of the last (odd) tile: masked by the caller
-    const unsigned voff = (unsigned)(((lane >> 5) * stride + (col - c0)) * (int)sizeof(U));
-    const char* __restrict__ sb = reinterpret_cast<const char*>(base + (int64_t)rp * kPanel * stride + c0);
-    const size_t step = (size_t)2 * stride * sizeof(U);
-#pragma unroll
-    for (int i = 0; i < kPanel / 2; ++i) {
-        const V v = *reinterpret_cast<const V*>(sb + i * step + voff);
-        R[i] = f32x4{static_cast<float>(v[0]), static_cast<float>(v[1]), static_cast<float>(v[2]), static_cast<float>(v[3])};
-    }
-    asm volatile("" ::: "memory");
-}
 
 // accumulators acc[j][r]: model (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c0 + 4 (lane & 31) + j.
 // FULL: the tile lies inside the block (vector access); otherwise element-wise with column masks.
@@ -238,18 +181,6 @@ __device__ __forceinline__ void wtile_add_to_q(const f32x16 (&acc)[4], const ESt
                     if (c + j < b) A.q[off + j] = A.q[off + j] + dq * acc[j][r];
             }
         }
-    }
-}
-
-// 128 MFMAs: rows (2i, 2i + 1) per step, k ascending
-__device__ __forceinline__ void wtile_compute(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
-                                              const float* __restrict__ a_lds, int lane, int a_pitch = kGridModels) {
-    const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < kPanel / 2; ++i) {
-        const float aop = a_lds[(2 * i + half) * a_pitch + l31];      // A[model = lane & 31][k = lane >> 5]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][j], acc[j], 0, 0, 0);
     }
 }
 
@@ -479,131 +410,18 @@ __device__ __forceinline__ void grid_chain_panel_mfma(const EStepArgs<float>& A,
     }
 }
 
-// the same for two of the four column groups of a 128-column tile (columns c0 + 4n + J0, + J0 + 1): 64 MFMAs
-template <int J0>
-__device__ __forceinline__ void wtile_compute_half(f32x16 (&acc)[4], const f32x4 (&R)[kPanel / 2],
-                                                   const float* __restrict__ a_lds, int lane, int a_pitch) {
-    const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int i = 0; i < kPanel / 2; ++i) {
-        const float aop = a_lds[(2 * i + half) * a_pitch + l31];
-        acc[J0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][J0], acc[J0], 0, 0, 0);
-        acc[J0 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, R[i][J0 + 1], acc[J0 + 1], 0, 0, 0);
-    }
-}
-template <int J0>
-__device__ __forceinline__ void wtile_store_acc_half(const f32x16 (&acc)[4], const EStepArgs<float>& A, const int* act,
-                                                     int64_t s0, int b, int c0, bool lane_ok, int n_models, int lane) {
-    const int half = lane >> 5, c = c0 + 4 * (lane & 31) + J0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (lane_ok && g < n_models) {
-            const unsigned off = (unsigned)act[g] * (unsigned)A.m + (unsigned)s0 + c;
-            if (c < b) A.q[off] = acc[J0][r];
-            if (c + 1 < b) A.q[off + 1] = acc[J0 + 1][r];
-        }
-    }
-}
-
 constexpr int kGridWaves = 8;                      // 1 chain wave + 7 updater waves
 constexpr int kGridNU = kGridWaves - 1;
 constexpr int kGridPerWave = (kGridModels + kGridNU - 1) / kGridNU;     // model rows a wave stages / flushes
 constexpr int kGridDiagPerWave = (kPanel + kGridNU - 1) / kGridNU;      // diagonal-tile rows a wave stages
 
 
-// ---- symmetric form, columns left of the chain: one 128-column tile (estep_grid_lower_pass_kernel, see there) ----
-constexpr int kGridLowWaves = 4;
-constexpr int kGridLowEPitch = kGridModels + 1;
-constexpr int kGridLowWaveFloats = 2 * kPanel * kGridLowEPitch;
-
-// one 128-column tile `T` of block `bd`: every row below the tile's own panels, in row order, accumulators in registers
-// (el: this wave's [2][64][33] staging of dq * eta_diff)
-// JH >= 0: only the column groups 2 JH, 2 JH + 1 of the tile (64 of its 128 columns, interleaved in pairs): half the
-// MFMAs per row panel.  The lower pass is bound by its longest items (a tile at the left edge of the largest block has
-// every other panel of the block below it), and only the few blocks beyond the resident form are left to it: twice as
-// many items of half the length (0.32 -> 0.2 ms on cfg3).
-template <typename U, int JH>
-__device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const int* s_act, const BlockDesc& bd, int T, float* el,
-                                                int lane, int n_models, float dq) {
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
-    const int n = lane & 31;
-    const int b = bd.size, stride = bd.stride;
-    const int64_t s0 = bd.start;
-    const U* __restrict__ base = ldd + bd.ld_off;
-    const int np = (b + kPanel - 1) / kPanel;
-    const int c0 = T * 2 * kPanel;
-    const int p_first = 2 * T + 1;                              // first panel below the tile's left half
-    if (p_first >= np) return;
-    const bool right = 2 * T + 1 < np;                          // the right 64 columns exist
-    const bool lane_ok = (n < 16) || right;
-    const bool full = c0 + 2 * kPanel <= b;
-
-    f32x16 acc[4];
-    if (full) wtile_load_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-    else wtile_load_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-
-    // dq * eta_diff of panel pq (rows pq*64 .. +63 x models): loaded into registers (`issue`) a whole panel ahead of
-    // its use, written to el[buf] (`commit`) once the MFMAs that read the other buffer are out -- the 32 loads per lane
-    // used to sit, exposed, between two panels of every item
-    float av[kGridModels];
-    bool av_ok = false;
-    auto stage_issue = [&](int pq) {
-        const int row = pq * kPanel + lane;
-        av_ok = row < b;
-        const unsigned off = (unsigned)s0 + (unsigned)min(row, b - 1);
-#pragma unroll
-        for (int g = 0; g < kGridModels; ++g) av[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
-        asm volatile("" ::: "memory");
-    };
-    auto stage_commit = [&](int buf) {
-        float* e = el + buf * kPanel * kGridLowEPitch;
-#pragma unroll
-        for (int g = 0; g < kGridModels; ++g) e[lane * kGridLowEPitch + g] = (av_ok && g < n_models) ? dq * av[g] : 0.0f;
-    };
-    auto compute = [&](const f32x4 (&R)[kPanel / 2], int buf) {
-        if (JH < 0) wtile_compute(acc, R, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
-        else wtile_compute_half<JH < 0 ? 0 : 2 * JH>(acc, R, el + buf * kPanel * kGridLowEPitch, lane, kGridLowEPitch);
-    };
-    f32x4 R0[kPanel / 2], R1[kPanel / 2];
-    wtile_load_rows<U>(R0, base, stride, p_first, c0, lane);
-    stage_issue(p_first);
-    stage_commit(0);
-    int buf = 0;
-    for (int pq = p_first; pq < np; pq += 2) {
-        // -- panel pq from R0 / el[buf]; panel pq + 1 (rows and eta_diff) in flight
-        const int p1 = min(pq + 1, np - 1);
-        wtile_load_rows<U>(R1, base, stride, p1, c0, lane);
-        stage_issue(p1);
-        if (pq == p_first && n >= 16) {
-#pragma unroll
-            for (int i = 0; i < kPanel / 2; ++i) R0[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // right half: its own panel, no update
-        }
-        __builtin_amdgcn_wave_barrier();
-        compute(R0, buf);
-        if (pq + 1 >= np) break;
-        stage_commit(buf ^ 1);
-        // -- panel pq + 1 from R1 / el[buf ^ 1]; panel pq + 2 in flight
-        const int p2 = min(pq + 2, np - 1);
-        wtile_load_rows<U>(R0, base, stride, p2, c0, lane);
-        stage_issue(p2);
-        __builtin_amdgcn_wave_barrier();
-        compute(R1, buf ^ 1);
-        if (pq + 2 < np) stage_commit(buf);
-    }
-    if (JH >= 0) wtile_store_acc_half<JH < 0 ? 0 : 2 * JH>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-    else if (full) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-    else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, lane_ok, n_models, lane);
-}
-
-
 // =====================================================================================================================
 // Resident form (blocks of up to kGridResMaxCols SNPs): q of the WHOLE block lives in the accumulator registers of the
 // updater waves for as long as the block is swept -- read from the state once, written once -- and every LD row of the
-// block is read exactly once: the tiles LEFT of the chain (symmetric form) receive the later rows from the same waves,
-// in the same row order, so estep_grid_lower_pass_kernel has nothing left to do for these blocks.
+// block is read exactly once: the tiles LEFT of the chain receive the later rows from the same waves, in the same row order.
 //
-//   wave 0      chain, as in the streaming form (grid_chain_panel).
+//   wave 0      chain (grid_chain_panel).
 //   wave 4      carry: takes the 64 columns of panel p+1 out of their owner's registers one phase ahead (through LDS,
 //               `cq`), applies a_{p-1} during phase p and a_p between the chain's two panels, hands them to the chain
 //               (qx) -- the accumulators stay in ITS registers across the barriers (own loop over the phases).
@@ -613,7 +431,7 @@ __device__ __forceinline__ void grid_lower_tile(const EStepArgs<float>& A, const
 //               are "away": p-1 (its own rows are the chain's diagonal tile), p and p+1 (with the carry).  The B operand
 //               of a masked half is 0: fma(a, 0, acc) == acc (q is never -0: it starts at +0 and a sum is -0 only if
 //               both addends are).  A panel comes back from the chain one phase after it was swept (qx).
-// Same arithmetic per (model, column) as the streaming form and as e_step_grid: the rows arrive in ascending order.
+// Same arithmetic per (model, column) as e_step_grid: the rows arrive in ascending order.
 // =====================================================================================================================
 // The carry is wave 4: the hardware puts waves w and w + 4 of a workgroup on the same SIMD, i.e. wave 4 shares the chain
 // wave's matrix pipe -- and the chain now issues two MFMAs per SNP.  An owner wave there (128 back-to-back MFMAs per tile)
@@ -623,13 +441,10 @@ constexpr int kGridCarryWave = 4;
 // (kGridResOwners = 6, kGridResSlots = 2, kGridResMaxCols = 1 536: kernels_common.h -- the plan sorts by the same limit)
 
 // rows of panel `pp` x the 128 columns from c0 applied to a tile whose accumulators are in registers; `on_l` / `on_r`: the
-// left / right 64 columns take the update (a masked half gets B = 0).  LD rows in 4 chunks of 8 row pairs (one 16-byte load
-// per lane = rows 2i, 2i+1 x 128 columns = the B operands of four MFMAs) through a register ring of DEPTH chunks:
-//   DEPTH 1 (resident form, 32 VGPRs): a chunk's loads are not overlapped with this wave's own MFMAs -- the other owner
-//           waves of the SIMD fill the matrix pipe meanwhile (a deeper ring next to 128 accumulator registers pushes
-//           loop-invariant addresses into scratch);
-//   DEPTH 2 (streaming form, 64 VGPRs): the next chunk is in flight while the current one is multiplied.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// left / right 64 columns take the update (a masked half gets B = 0).  LD rows in chunks of 32 VGPRs (fp32: 8 row pairs, one
+// 16-byte load per lane = rows 2i, 2i+1 x 128 columns = the B operands of four MFMAs): a chunk's loads are not overlapped
+// with this wave's own MFMAs -- the other owner waves of the SIMD fill the matrix pipe meanwhile (a deeper ring next to 128
+// accumulator registers pushes loop-invariant addresses into scratch).
 
 // Four consecutive columns of one LD row as loaded (one dword for int8, two for int16, four for fp32), converted with
 // static_cast<float> (e_step.hpp:173) when consumed.  A masked half of a tile is masked on the raw dwords -- once per load
@@ -686,15 +501,13 @@ template <> __device__ __forceinline__ RawCols4<int16_t> load_cols4<int16_t>(con
     const uint2 t = *reinterpret_cast<const uint2*>(p);
     return RawCols4<int16_t>{{t.x, t.y}};
 }
-// (`after_first_issue` runs once the first chunk's loads are out and before the first MFMA: the streaming form finishes
-// the tile's accumulator loads there, so that they and the first rows share one memory round trip)
 // MIRV (mirrored upper form): the LDS array holds eta_diff and the A operand is scale * eta_diff (scale = dq: a trailing
 // update; 1: a second-pass sum); `tri` = 0 / 1: the left / right 64 columns are the panel's OWN diagonal tile and take only
 // its part below the diagonal (row > column: R[j, i] = R[i, j] for the SNPs i < j of the panel), -1: neither.
-template <typename U, int DEPTH, typename HOOK = NoHook, bool MIRV = false>
+template <typename U, bool MIRV = false>
 __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __restrict__ base, int stride, int pp, int c0,
                                                int lane, bool on_l, bool on_r, const float* __restrict__ a_lds,
-                                               HOOK after_first_issue = HOOK(), float scale = 1.0f, int tri = -1) {
+                                               float scale = 1.0f, int tri = -1) {
     const int half = lane >> 5, l31 = lane & 31;
     const bool lane_on = (lane & 16) ? on_r : on_l;
     const bool lane_tri = MIRV && tri >= 0 && ((lane & 16) != 0) == (tri == 1);
@@ -710,36 +523,15 @@ __device__ __forceinline__ void res_tile_apply(f32x16 (&acc)[4], const U* __rest
     // a chunk = 32 VGPRs of raw rows whatever the LD type: 8 row pairs of fp32, 16 of int16, all 32 of int8 -- integer LD
     // takes fewer memory round trips per tile, not fp32's four with a quarter of the bytes each
     constexpr int CH = 8 * 4 / RawCols4<U>::kDwords, NCH = kPanel / 2 / CH;
-    constexpr int RING = NCH == 1 ? 1 : DEPTH;
-    RawCols4<U> ring[RING][CH];
-    if (RING == 2) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) ring[0][i] = load_cols4<U>(sb + i * step + voff);
-        asm volatile("" ::: "memory");
-    }
-    if (DEPTH == 2 && RING == 1) {
-        // (one chunk is the whole tile: issue it, then let the caller issue what shares its round trip)
-#pragma unroll
-        for (int i = 0; i < CH; ++i) ring[0][i] = load_cols4<U>(sb + i * step + voff);
-        asm volatile("" ::: "memory");
-    }
-    if (DEPTH == 2) after_first_issue();
+    RawCols4<U> ring[CH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        if (RING == 1) {
-            if (!(DEPTH == 2 && c == 0)) {
 #pragma unroll
-                for (int i = 0; i < CH; ++i) ring[0][i] = load_cols4<U>(sb + (c * CH + i) * step + voff);
-                asm volatile("" ::: "memory");
-            }
-        } else if (c + 1 < NCH) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) ring[(c + 1) & 1][i] = load_cols4<U>(sb + ((c + 1) * CH + i) * step + voff);
-            asm volatile("" ::: "memory");
-        }
+        for (int i = 0; i < CH; ++i) ring[i] = load_cols4<U>(sb + (c * CH + i) * step + voff);
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            RawCols4<U> v = ring[RING == 2 ? (c & 1) : 0][i];
+            RawCols4<U> v = ring[i];
             v.mask(lane_on);
             if (MIRV && tri >= 0) { if (lane_tri) v.mask_below(2 * (c * CH + i) + half, tri_col0); }
             const float a_raw = a_lds[(2 * (c * CH + i) + half) * kGridModels + l31];    // A[model = lane & 31][k = lane >> 5]
@@ -777,12 +569,11 @@ constexpr int kGridTeamPanels = 2 * kGridResOwners * kGridResSlots;       // 24 
 // columns through the part of the diagonal tile below the diagonal (res_tile_apply `tri`).  At the end of the block
 // q = q_chain + dq * sum (q_chain: what the chain's flush left in the state).  No epilogue kernel, every LD entry of the
 // mirrored block read once.
-template <typename U, bool SYM, bool EXACT, bool MIR = false>
+template <typename U, bool SYM, bool EXACT>
 __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, float* io, float* la, float* dg, f32x4* cy,
                                                     float* qx, const int* s_act, const BlockDesc& bd, int wave, int lane,
                                                     int n_models, float dq, const ExpTab& tab, const GridTeam tm = GridTeam()) {
-    static_assert(!(SYM && MIR), "the mirrored form is the upper-triangular arithmetic");
-    constexpr bool LEFT = SYM || MIR;          // the tiles left of the chain keep receiving the later rows
+    constexpr bool MIR = !SYM;                 // the upper-triangular arithmetic, over mirrored storage
     constexpr int NU = kGridNU;
     const int64_t s0 = bd.start;
     const int b = bd.size, stride = bd.stride;
@@ -795,8 +586,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
     const int p_lo = tm.member * kGridTeamPanels, p_hi = min(np, p_lo + kGridTeamPanels);
     const int T_lo = tm.member * kGridResOwners * kGridResSlots;
     auto mine = [&](int p) { return !team || (p >= p_lo && p < p_hi); };
-    // upper-triangular form: a member whose panels the chain has passed has nothing left to receive
-    const int p_end = (team && !LEFT) ? min(np, p_hi) : np;
+    const int p_end = np;
     // the a-vector of panel p: published by the holder's carry wave, received by the other members' chain wave
     auto publish_a = [&](int p) {
         const float* src = la + (p & 1) * kGridAFloats;
@@ -835,7 +625,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
         }
     };
 
-    // the per-panel input / output staging of the streaming form (waves 1..7; sym: q of a panel is NOT written here)
+    // the per-panel input / output staging (waves 1..7; sym: q of a panel is NOT written here)
     auto stage_inputs = [&](int pp, bool with_q) {
         float* dst = io + (pp & 1) * kGridIoFloats;
         const int r0 = pp * kPanel;
@@ -888,8 +678,8 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                     A.var_gamma[off] = src[1 * kGridIoArr + g * kGridIoPitch + lane];
                     A.eta_diff[off] = src[2 * kGridIoArr + g * kGridIoPitch + lane];
                     A.eta[off] = src[3 * kGridIoArr + g * kGridIoPitch + lane];
-                    // upper-triangular form: q of the panel is final (its second pass is the epilogue kernel's); symmetric
-                    // form: the panel goes back to its owner and is stored with the block
+                    // upper-triangular form: q as the chain left it (the owners add dq * the second-pass sums when the block is
+                    // done); symmetric form: the panel goes back to its owner and is stored with the block
                     if (!SYM) A.q[off] = qs[g * kGridQxPitch + lane];
                 }
             }
@@ -911,7 +701,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
 #endif
                                       );
 #endif
-            } else if (p < np && (LEFT || p < p_hi)) {
+            } else if (p < np) {
                 receive_a(p);                                       // another member holds the chain: its a-vector -> la
             }
             __syncthreads();                                        // end
@@ -1054,7 +844,7 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                 auto panel_on = [&](int c) {
                     if (c >= np) return false;
                     // (mirrored form: the panel's own columns too -- below the diagonal of its tile)
-                    return LEFT ? (c < p - 1 || c > p + 1 || (MIR && c == p - 1)) : (c > p + 1);
+                    return c < p - 1 || c > p + 1 || (MIR && c == p - 1);
                 };
                 auto apply = [&](f32x16 (&acc)[4], int T, int c0) {
                     const bool l = panel_on(2 * T), r = panel_on(2 * T + 1);
@@ -1063,10 +853,9 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
                         // a tile is never on both sides of the chain at once: left of it (or on it) -- sums, eta_diff as it is;
                         // right of it -- trailing updates, dq * eta_diff
                         const int tri = 2 * T == pp ? 0 : (2 * T + 1 == pp ? 1 : -1);
-                        res_tile_apply<U, 1, NoHook, true>(acc, base, stride, pp, c0, lane, l, r, a_lds, NoHook(),
-                                                           2 * T <= pp ? 1.0f : dq, tri);
+                        res_tile_apply<U, true>(acc, base, stride, pp, c0, lane, l, r, a_lds, 2 * T <= pp ? 1.0f : dq, tri);
                     } else {
-                        res_tile_apply<U, 1>(acc, base, stride, pp, c0, lane, l, r, a_lds);
+                        res_tile_apply<U>(acc, base, stride, pp, c0, lane, l, r, a_lds);
                     }
                 };
                 if (hasA) apply(accA, TA, cA);
@@ -1103,10 +892,11 @@ __device__ __forceinline__ void grid_block_resident(const EStepArgs<float>& A, f
 }
 
 // Team blocks of a launch (host: launch_grid.inc): the first `n_wgs` workgroups are team members -- workgroup w is member
-// `member[w]` of the team of block `block[w]` (the `n_blocks` largest blocks of the size-sorted list, all of them beyond the
-// resident form) -- and join the queue of the remaining blocks when their team block is done.
+// `member[w]` of the team of block `block[w]` (`n_blocks` of the largest blocks of the size-sorted list, all of them beyond
+// the resident form) -- and join the queue of the remaining blocks (from `queue_start`) when their team block is done.
 struct GridTeams {
     int32_t n_wgs = 0, n_blocks = 0;
+    int32_t queue_start = 0;                  // first block of the size-sorted list the queue hands out (= all team blocks of the plan)
     const int32_t* block = nullptr;           // [n_wgs]
     const int32_t* member = nullptr;          // [n_wgs]
     const int32_t* size = nullptr;            // [n_wgs] team size
@@ -1115,23 +905,22 @@ struct GridTeams {
     uint32_t tag_base = 0;
 };
 
-// (MIR: every block of the launch takes the resident form or a team -- the host checks; the streaming form below, with its
-//  epilogue kernel, reads the packed upper-triangular storage)
-template <typename U, bool SYM, bool EXACT, bool MIR = false>
-__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, int resident_max, GridTeams teams) {
+// Every block of a launch takes the resident form or a team (the host deals the blocks beyond kGridResMaxCols to teams, in
+// several launches when they do not fit the chip at once: launch_grid.inc).  SYM: the symmetric form; otherwise the
+// upper-triangular arithmetic over the MIRRORED storage (abi_plan.hip: mirror_lower_kernel).
+template <typename U, bool SYM, bool EXACT>
+__global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepArgs<float> A, GridTeams teams) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* io = smem;                                   // [2][4][32][65]: mm, ulog, hvt, eta -> mu, gamma, d, eta'
     float* la = smem + 2 * kGridIoFloats;               // [2][64][32] scaled eta_diff of a panel
     float* dg = la + 2 * kGridAFloats;                  // [2][64][64] diagonal tile of a panel, fp32
-    f32x4* cy = reinterpret_cast<f32x4*>(dg + 2 * kGridDiagFloats);   // [24][64] x 16 B: wave 1's carried tile
+    f32x4* cy = reinterpret_cast<f32x4*>(dg + 2 * kGridDiagFloats);   // [24][64] x 16 B: the carry wave's tile
     float* qx = dg + 2 * kGridDiagFloats + kGridCarryFloats;          // [2][32][68] q of a panel: to / from the chain
     __shared__ int s_blk;
     __shared__ int s_act[kGridModels];                  // column of the (m, G) arrays for each model slot
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    constexpr int NU = kGridNU;
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
     const int n_models = A.n_active;
     const float dq = A.dq;
     ExpTab tab;
@@ -1146,388 +935,22 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
         tm.size = teams.size[blockIdx.x];
         tm.gran = teams.gran + teams.goff[tb];
         tm.tag_base = teams.tag_base;
-        grid_block_resident<U, SYM, EXACT, MIR>(A, io, la, dg, cy, qx, s_act, A.blocks[tb], wave, lane, n_models, dq, tab, tm);
+        grid_block_resident<U, SYM, EXACT>(A, io, la, dg, cy, qx, s_act, A.blocks[tb], wave, lane, n_models, dq, tab, tm);
         __syncthreads();
     }
     for (;;) {
-        if (tid == 0) s_blk = teams.n_blocks + atomicAdd(A.counter, 1);       // (the team blocks are the head of the list)
+        if (tid == 0) s_blk = teams.queue_start + atomicAdd(A.counter, 1);    // (the blocks beyond the resident form are the head of the list)
         __syncthreads();
         const int blk = s_blk;
         __syncthreads();
         if (blk >= A.n_blocks) break;
         const BlockDesc bd = A.blocks[blk];
-        if (MIR || bd.size <= resident_max) {
-            // q of the whole block fits the updater waves' accumulator registers: resident form (above)
-            grid_block_resident<U, SYM, EXACT, MIR>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
+        if (bd.size > kGridResMaxCols) {                 // (never: the host gives such blocks a team)
+            if (tid == 0) atomicExch(A.error, 2);
             continue;
         }
-        const int64_t s0 = bd.start;
-        const int b = bd.size, stride = bd.stride;
-        const U* __restrict__ base = ldd + bd.ld_off;
-        const int np = (b + kPanel - 1) / kPanel;
-
-        // waves 1..7: stage the inputs of panel `pp` into io[pp & 1] (4 arrays x n_models rows of 64
-        // floats) and its diagonal tile, converted to fp32, into dg[pp & 1]; all loads first, then LDS
-        auto stage_inputs = [&](int pp, bool with_q) {
-            float* dst = io + (pp & 1) * kGridIoFloats;
-            const int r0 = pp * kPanel;
-            const int j = r0 + lane;
-            const bool ok = j < b;
-            const unsigned jo = (unsigned)s0 + (ok ? j : 0);
-            float v[kGridPerWave][5];
-#pragma unroll
-            for (int i = 0; i < kGridPerWave; ++i) {
-                const int g = min(wave - 1 + NU * i, kGridModels - 1);
-                const unsigned off = (unsigned)s_act[g] * (unsigned)A.m + jo;
-                v[i][0] = A.mu_mult[off]; v[i][1] = A.u_logs[off]; v[i][2] = A.shvt[off]; v[i][3] = A.eta[off];
-                v[i][4] = with_q ? A.q[off] : 0.0f;
-            }
-            const int nrows = min(kPanel, b - r0);
-            const U* __restrict__ dp = base + (int64_t)r0 * stride + r0 + lane;
-            float dv[kGridDiagPerWave];
-#pragma unroll
-            for (int i = 0; i < kGridDiagPerWave; ++i)
-                dv[i] = static_cast<float>(dp[(int64_t)min(wave - 1 + NU * i, nrows - 1) * stride]);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < kGridPerWave; ++i) {
-                const int g = wave - 1 + NU * i;
-                if (g < n_models) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) dst[a * kGridIoArr + g * kGridIoPitch + lane] = ok ? v[i][a] : 0.0f;
-                    if (with_q) qx[(pp & 1) * kGridQxFloats + g * kGridQxPitch + lane] = ok ? v[i][4] : 0.0f;
-                }
-            }
-            float* dd = dg + (pp & 1) * kGridDiagFloats;
-#pragma unroll
-            for (int i = 0; i < kGridDiagPerWave; ++i) {
-                const int t = wave - 1 + NU * i;
-                if (t < kPanel) dd[t * kPanel + lane] = dv[i];
-            }
-        };
-        // write the outputs and the final q of panel `pp` (left in io / qx[pp & 1] by the chain) to the state
-        auto flush_outputs = [&](int pp) {
-            const float* src = io + (pp & 1) * kGridIoFloats;
-            const float* qs = qx + (pp & 1) * kGridQxFloats;
-            const int j = pp * kPanel + lane;
-            if (j < b) {
-#pragma unroll
-                for (int i = 0; i < kGridPerWave; ++i) {
-                    const int g = wave - 1 + NU * i;
-                    if (g < n_models) {
-                        const unsigned off = (unsigned)s_act[g] * (unsigned)A.m + (unsigned)(s0 + j);
-                        A.var_mu[off] = src[0 * kGridIoArr + g * kGridIoPitch + lane];
-                        A.var_gamma[off] = src[1 * kGridIoArr + g * kGridIoPitch + lane];
-                        A.eta_diff[off] = src[2 * kGridIoArr + g * kGridIoPitch + lane];
-                        A.eta[off] = src[3 * kGridIoArr + g * kGridIoPitch + lane];
-                        A.q[off] = qs[g * kGridQxPitch + lane];
-                    }
-                }
-            }
-        };
-
-        if (wave > 0) stage_inputs(0, true);
-        __syncthreads();
-
-#ifdef VIPRS_GRID_PROFILE
-        __shared__ unsigned s_prof[32][12];
-#endif
-        for (int p = 0; p <= np; ++p) {
-            GPROF(0, wave == 0);
-            // ---- (1) wave 1 finishes tile p with a_{p-1}: its accumulators already hold q (updated through
-            //      a_{p-2}) and the LD rows came through LDS from the previous phase -- only 64 MFMAs sit
-            //      between the chain's two panels; the result goes to the chain through LDS
-            if (p > 0 && p < np && wave == 1) {
-                float R1[kPanel];
-                f32x16 acc0, acc1;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const f32x4 v = cy[i * 64 + lane];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) R1[4 * i + e] = v[e];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 v = cy[(16 + i) * 64 + lane], w = cy[(20 + i) * 64 + lane];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc0[4 * i + e] = v[e]; acc1[4 * i + e] = w[e]; }
-                }
-                tile_compute(acc0, acc1, R1, la + ((p - 1) & 1) * kGridAFloats, lane);
-                float* qd = qx + (p & 1) * kGridQxFloats + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int g = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    qd[g * kGridQxPitch] = acc0[r];
-                    qd[g * kGridQxPitch + 32] = acc1[r];
-                }
-            }
-            __syncthreads();
-            GPROF(1, wave == 0);
-            if (wave == 0) {
-                // ---- (2) chain: 64 serial SNP updates for all models
-                if (p < np) {
-#ifdef VIPRS_GRID_MFMA_CHAIN
-                    grid_chain_panel_mfma<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab);
-#else
-                    grid_chain_panel<SYM, EXACT>(A, io, la, dg, qx, p, b, s0, lane, n_models, dq, tab
-#ifdef VIPRS_GRID_PROFILE
-                                          , blk, &s_prof[0][0]
-#endif
-                                          );
-#endif
-                }
-            } else {
-                // ---- (3) waves 1..7, concurrently with the chain: outputs of panel p-1 out of io[(p-1)&1],
-                //      inputs of panel p+1 into the same buffer (each wave flushes and refills its own
-                //      rows, so only its own LDS order matters), then the other 64-column tiles of a_{p-1}
-                if (p > 0) flush_outputs(p - 1);
-                GPROF(5, wave == 1);
-                if (p + 1 < np) stage_inputs(p + 1, false);
-#ifdef VIPRS_GRID_PROFILE
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-                GPROF(6, wave == 1);
-                if (p > 0) {
-                    // a_{p-1} on every 64-column tile right of p+1 (p: done above; p+1: wave 1, below).  The
-                    // tiles LEFT of the chain (symmetric form: q of SNPs already visited keeps receiving
-                    // the later rows) are not needed again in this sweep: estep_grid_lower_pass_kernel
-                    // applies all their updates afterwards, in the same row order, with q read once.
-                    const int pp = p - 1;
-                    const float* a_lds = la + (pp & 1) * kGridAFloats;
-                    const int n_wide = (np + 1) / 2;                         // 128-column tiles of the block
-                    // Per tile: the accumulator loads and the first chunk of LD rows share one memory round trip, the other
-                    // three chunks stream through a two-chunk register ring under the MFMAs of their predecessors (round 2
-                    // waited for all 48 loads of a tile before its first MFMA and held 128 VGPRs of rows).  (Prefetching the
-                    // NEXT tile's accumulators as well needs 192 VGPRs + and spills: 4.4 instead of 2.7 ms.)
-                    auto active64 = [&](int ct) { return ct < np && ct > p + 1; };
-                    auto next_tile = [&](int T) {
-                        while (T < n_wide && !active64(2 * T) && !active64(2 * T + 1)) T += NU;
-                        return T;
-                    };
-                    auto tile_lane_ok = [&](int T) { return (lane & 16) ? active64(2 * T + 1) : active64(2 * T); };
-                    auto acc_issue = [&](f32x16 (&acc)[4], int T) {
-                        const int c0 = T * 2 * kPanel;
-                        if (c0 + 2 * kPanel <= b) wtile_load_acc_issue<true>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), lane);
-                        else wtile_load_acc_issue<false>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), lane);
-                    };
-                    auto acc_finish = [&](f32x16 (&acc)[4], int T) {
-                        const int c0 = T * 2 * kPanel;
-                        if (c0 + 2 * kPanel <= b) wtile_load_acc_finish<true>(acc, b, c0, tile_lane_ok(T), n_models, lane);
-                        else wtile_load_acc_finish<false>(acc, b, c0, tile_lane_ok(T), n_models, lane);
-                    };
-                    for (int T = next_tile((p + 2) / 2 + wave - 1); T < n_wide; T = next_tile(T + NU)) {
-                        f32x16 acc[4];
-                        const int c0 = T * 2 * kPanel;
-                        acc_issue(acc, T);
-                        res_tile_apply<U, 2>(acc, base, stride, pp, c0, lane, true, true, a_lds, [&]() { acc_finish(acc, T); });
-                        if (c0 + 2 * kPanel <= b) wtile_store_acc<true>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), n_models, lane);
-                        else wtile_store_acc<false>(acc, A, s_act, s0, b, c0, tile_lane_ok(T), n_models, lane);
-                    }
-                }
-                GPROF(11, wave == 1);
-                if (wave == 1 && p + 1 < np) {
-                    // tile p+1 stays with this wave across the barrier (see (1))
-                    float R0[kPanel], R1[kPanel];
-                    f32x16 acc0, acc1;
-                    tile_load_acc(acc0, acc1, A, s_act, s0, b, p + 1, n_models, lane);
-                    if (p > 0) {
-                        tile_load_rows<U>(R0, base, stride, b, p - 1, p + 1, lane);
-                        tile_load_rows<U>(R1, base, stride, b, p, p + 1, lane);
-                        tile_compute(acc0, acc1, R0, la + ((p - 1) & 1) * kGridAFloats, lane);
-                    } else {
-                        tile_load_rows<U>(R1, base, stride, b, p, p + 1, lane);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) cy[i * 64 + lane] = f32x4{R1[4 * i], R1[4 * i + 1], R1[4 * i + 2], R1[4 * i + 3]};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        cy[(16 + i) * 64 + lane] = f32x4{acc0[4 * i], acc0[4 * i + 1], acc0[4 * i + 2], acc0[4 * i + 3]};
-                        cy[(20 + i) * 64 + lane] = f32x4{acc1[4 * i], acc1[4 * i + 1], acc1[4 * i + 2], acc1[4 * i + 3]};
-                    }
-                }
-            }
-            GPROF(4, wave == 0); GPROF(7, wave == 1);
-            __syncthreads();
-        }
-#ifdef VIPRS_GRID_PROFILE
-        __syncthreads();
-        if (blk == 0 && tid == 0) {
-            for (int p = 0; p <= np && p < 32; ++p) {
-                const unsigned t = s_prof[p][1];
-                printf("phase %2d: carry %4lld | chain: qread %4lld loop %5lld end %5lld | w1: flush %5lld stage %5lld tiles %5lld end %5lld | tile0: issued %5lld arrived %5lld computed %5lld (x10ns)\n",
-                       p, (long long)(int)(t - s_prof[p][0]), (long long)(int)(s_prof[p][2] - t), (long long)(int)(s_prof[p][3] - t), (long long)(int)(s_prof[p][4] - t),
-                       (long long)(int)(s_prof[p][5] - t), (long long)(int)(s_prof[p][6] - t), (long long)(int)(s_prof[p][11] - t), (long long)(int)(s_prof[p][7] - t),
-                       (long long)(int)(s_prof[p][8] - t), (long long)(int)(s_prof[p][9] - t), (long long)(int)(s_prof[p][10] - t));
-            }
-        }
-        __syncthreads();
-#endif
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Upper-triangular second pass for all models at once (update_q_factor_matrix, e_step.hpp:266-303):
-//     q[g, j] += dq * dot(eta_diff[g, j+1 .. end), R[j, j+1 .. end))        for every active model g
-// as C[model][row] = sum_k E[model][k] * R[row][k] on the matrix cores -- per (model, row) the same
-// serial fma chain from 0 in column order as the spike-and-slab second pass (the zero lower-left part of
-// the repacked block is exactly neutral), with every LD tile read once for all models.  One wave owns
-// 64 rows of a block: LD tiles are loaded row-wise (16 B per lane) and transposed through LDS so that
-// lane n supplies row n as the B operand; the eta_diff tile goes through LDS as [k][model].
-// ---------------------------------------------------------------------------------------------
-constexpr int kGridEpiTPitch = kPanel + 1, kGridEpiEPitch = kGridModels + 1;
-// One eta_diff tile [64 k][33] per wave: the LDS operations of a wave execute in issue order, so the next tile's stores
-// need no second buffer behind this tile's reads -- and with 34 instead of 68 KB per workgroup three workgroups fit a CU
-// (registers permitting) instead of two: cfg3 upper form 2.406 -> 2.382 ms (fp32 LD), 2.085 -> 2.042 (int8), tools/multi_ab.py.
-// (-DGRID_EPI_BUFS=2: the double-buffered variant.)
-#ifndef GRID_EPI_BUFS
-#define GRID_EPI_BUFS 1
-#endif
-constexpr int kGridEpiBufs = GRID_EPI_BUFS;
-constexpr int kGridEpiWaveFloats = kGridEpiBufs * kPanel * kGridEpiEPitch;
-constexpr int kGridEpiWaves = 4;        // (3 waves x 2 workgroups per CU: 7 % slower; 2 x 3: the same)
-
-// (round 4) The LD tile is no longer transposed through LDS: lane n loads ITS OWN rows (n and 32 + n of the group; 16 bytes =
-// four consecutive columns per load, 16 loads per row and tile) and so holds the B operands of its accumulator columns
-// directly -- the MFMA's two k slots are the even (lanes 0-31) and odd (lanes 32-63) column of a pair, picked from the
-// loaded four by the lane's half.  Both halves load the same rows (the second read hits L1); what is gone are the 64 LDS
-// writes and 64 LDS reads per lane and tile that the transposition cost (the eta_diff tile still goes through LDS as
-// [k][model]).
-template <typename U>
-__global__ __launch_bounds__(64 * kGridEpiWaves) void estep_grid_upper_epilogue_kernel(EStepArgs<float> A,
-                                                                                       const EpiItem* items, int n_items,
-                                                                                       int32_t* counter) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int s_act[kGridModels];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* el = smem + wave * kGridEpiWaveFloats;       // [64 k][33]   eta_diff tile, [k][model]
-    const U* __restrict__ ldd = static_cast<const U*>(A.ld_dense);
-    const int n_models = A.n_active;
-    if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
-    __syncthreads();
-    const int half = lane >> 5, l31 = lane & 31;
-
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const EpiItem it = items[item];
-        const BlockDesc bd = A.blocks[it.blk];
-        const int b = bd.size, stride = bd.stride, r0 = it.row0;
-        const int64_t s0 = bd.start;
-        const int nrows = min(kPanel, b - r0);
-        // this lane's two rows (clamped into the group: rows past the block are loaded, never stored)
-        const char* __restrict__ row0p = reinterpret_cast<const char*>(ldd + bd.ld_off + (int64_t)(r0 + min(l31, nrows - 1)) * stride);
-        const char* __restrict__ row1p = reinterpret_cast<const char*>(ldd + bd.ld_off + (int64_t)(r0 + min(32 + l31, nrows - 1)) * stride);
-        f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-
-        // 8 pieces of 4 columns = half a tile (32 columns) of both rows per buffer, two buffers: the next half tile's loads
-        // are in flight while the current one is multiplied (fp32: 2 x 64 VGPRs of rows)
-        constexpr int PIECES = 8;
-        RawCols4<U> va0[PIECES], va1[PIECES], vb0[PIECES], vb1[PIECES];
-        float e[kGridModels];
-        auto load_e = [&](int c0) {
-            const unsigned off = (unsigned)s0 + (unsigned)min(c0 + lane, b - 1);
-#pragma unroll
-            for (int g = 0; g < kGridModels; ++g) e[g] = A.eta_diff[(unsigned)s_act[g] * (unsigned)A.m + off];
-        };
-        auto load_half = [&](RawCols4<U> (&w0)[PIECES], RawCols4<U> (&w1)[PIECES], int cc) {     // 32 columns from cc
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                w0[i] = load_cols4<U>(row0p + (size_t)(cc + 4 * i) * sizeof(U));
-                w1[i] = load_cols4<U>(row1p + (size_t)(cc + 4 * i) * sizeof(U));
-            }
-            asm volatile("" ::: "memory");
-        };
-        auto mult_half = [&](const RawCols4<U> (&w0)[PIECES], const RawCols4<U> (&w1)[PIECES], const float* eb, int h) {
-#pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-                // columns 32 h + 4 i .. + 3: the pairs (0, 1) and (2, 3); the lane's half picks its column of the pair
-                const int kk = 32 * h + 4 * i;
-                const float a0 = eb[(kk + half) * kGridEpiEPitch + l31];
-                const float a1 = eb[(kk + 2 + half) * kGridEpiEPitch + l31];
-                const float b00 = half ? w0[i].template get<1>() : w0[i].template get<0>();
-                const float b10 = half ? w1[i].template get<1>() : w1[i].template get<0>();
-                const float b01 = half ? w0[i].template get<3>() : w0[i].template get<2>();
-                const float b11 = half ? w1[i].template get<3>() : w1[i].template get<2>();
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b00, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b10, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b01, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b11, acc1, 0, 0, 0);
-            }
-        };
-        // integer LD (16 / 32 VGPRs per half tile): the next half tile's loads are in flight while the current one is
-        // multiplied (int8 upper, cfg3: 2.25 -> 2.08 ms per sweep); fp32 LD (2 x 64 VGPRs: one workgroup per CU less)
-        // measured slower that way (2.34 -> 2.40) and loads half by half
-        constexpr bool kPrefetch = sizeof(U) < 4;
-        int buf = 0;
-        if (kPrefetch) load_half(va0, va1, r0);
-        for (int c0 = r0; c0 < b; c0 += kPanel) {
-            float* eb = el + buf * (kPanel * kGridEpiEPitch);
-            load_e(c0);
-            if (kPrefetch) load_half(vb0, vb1, c0 + 32);                  // second half of this tile
-            else load_half(va0, va1, c0);
-            const bool colok = c0 + lane < b;
-#pragma unroll
-            for (int g = 0; g < kGridModels; ++g) eb[lane * kGridEpiEPitch + g] = (colok && g < n_models) ? e[g] : 0.0f;
-            __builtin_amdgcn_wave_barrier();
-            mult_half(va0, va1, eb, 0);
-            if constexpr (kPrefetch) {
-                // first half of the next tile (clamped to this one at the end of the row: loaded, never used)
-                load_half(va0, va1, (c0 + kPanel < b) ? c0 + kPanel : c0);
-                mult_half(vb0, vb1, eb, 1);
-            } else {
-                load_half(va0, va1, c0 + 32);            // (the same registers: one half tile of rows live at a time)
-                mult_half(va0, va1, eb, 1);
-            }
-            buf ^= kGridEpiBufs - 1;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int g = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (g < n_models) {
-                float* qc = A.q + (unsigned)s_act[g] * (unsigned)A.m + (unsigned)s0 + r0;
-                if (l31 < nrows) qc[l31] += A.dq * acc0[r];
-                if (32 + l31 < nrows) qc[32 + l31] += A.dq * acc1[r];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Symmetric form, columns left of the chain: q[g, c] of a SNP c already visited still receives
-// fma(R[j, c], dq * eta_diff[g, j], .) from every later SNP j of its block (e_step.hpp:623 with the
-// full row window), in the order of j.  None of these values is read again during the sweep, so
-// they are applied after it: one wave per 128-column tile keeps the tile's 32 x 128 accumulators in
-// registers and streams the rows below the tile's own panels once (LD lower triangle read once, q
-// read and written once), a = dq * eta_diff recomputed from the stored eta_diff exactly as the chain did.
-// ---------------------------------------------------------------------------------------------
-template <typename U>
-__global__ __launch_bounds__(64 * kGridLowWaves) void estep_grid_lower_pass_kernel(EStepArgs<float> A, const EpiItem* items,
-                                                                                   int n_items, int32_t* counter, int split,
-                                                                                   int skip_blocks_below) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int s_act[kGridModels];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* el = smem + wave * kGridLowWaveFloats;        // [2][64 rows][33]: dq * eta_diff of a panel, [row][model]
-    const int n_models = A.n_active;
-    const float dq = A.dq;
-    if (threadIdx.x < kGridModels) s_act[threadIdx.x] = A.active[min((int)threadIdx.x, n_models - 1)];
-    __syncthreads();
-
-    for (;;) {
-        int item = 0;
-        if (lane == 0) item = atomicAdd(counter, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
-        if (item >= n_items) break;
-        const EpiItem it = items[item];
-        if (it.blk < skip_blocks_below) continue;           // (a team block of the sweep: its left columns are done)
-        // row0 = index of the 128-column tile; split launches: 2 x tile + column-group pair
-        if (!split) grid_lower_tile<U, -1>(A, s_act, A.blocks[it.blk], it.row0, el, lane, n_models, dq);
-        else if (it.row0 & 1) grid_lower_tile<U, 1>(A, s_act, A.blocks[it.blk], it.row0 >> 1, el, lane, n_models, dq);
-        else grid_lower_tile<U, 0>(A, s_act, A.blocks[it.blk], it.row0 >> 1, el, lane, n_models, dq);
+        // q of the whole block fits the updater waves' accumulator registers
+        grid_block_resident<U, SYM, EXACT>(A, io, la, dg, cy, qx, s_act, bd, wave, lane, n_models, dq, tab);
     }
 }
 

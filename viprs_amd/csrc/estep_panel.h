@@ -18,13 +18,11 @@
 //
 // Symmetric form: columns LEFT of the current panel (q of SNPs already visited) keep receiving the
 // later rows as well (they are what the next sweep starts from).  Upper-triangular form: the
-// reference's second pass (update_q_factor, e_step.hpp:331-337) is folded into the sweep.  By default
-// (kFormMirror) the dense blocks hold the upper triangle MIRRORED into the lower one and the columns
-// left of the chain take the later rows exactly as in the symmetric form -- into per-row sums s, with
-// eta_diff as the multiplier: R[i, j] read as R[j, i], a row's sum in ascending column order, the
-// reference's dot bit for bit.  The round-4 form of that pass (kFormUpper: packed upper triangle,
-// per-row running sums extended by one panel of columns per phase through an LDS transposition,
-// HalfTileRows below) is kept behind VIPRS_UPPER_MIRROR=0.
+// reference's second pass (update_q_factor, e_step.hpp:331-337) is folded into the sweep: the dense
+// blocks hold the upper triangle MIRRORED into the lower one (kFormMirror) and the columns left of the
+// chain take the later rows exactly as in the symmetric form -- into per-row sums s, with eta_diff as
+// the multiplier: R[i, j] read as R[j, i], a row's sum in ascending column order, the reference's dot
+// bit for bit.
 //
 // Large blocks (a single CU pulls only ~50 GB/s from HBM) are shared by a TEAM of TS workgroups on
 // TS CUs: see the comment at `team` in the kernel.
@@ -266,101 +264,6 @@ __device__ __forceinline__ float diag_lower_update(const float* __restrict__ til
     return sv;
 }
 
-// Upper-triangular form, the reference's second pass (update_q_factor, e_step.hpp:331-337:
-//     q[j] += dq * dot(eta_diff[j+1 .. end), R[j, j+1 .. end)),  the dot a serial fma chain from 0 in column order)
-// done PROGRESSIVELY inside the sweep: when the chain has finished column panel `pp`, the tiles R[r, pp] of all
-// row panels r <= pp extend the running sums s[j] of their rows by the panel's 64 columns -- columns still arrive in
-// ascending order for every row, so the sums are the reference's, bit for bit.  One wave per tile, lane = row: each
-// lane runs the fma chain of its own row; the tile is loaded coalesced and handed to the rows through LDS (load_co /
-// to_rows) or, where that LDS is not available, lane by lane along the rows (load); eta_diff of a column half sits in
-// SGPRs for all tiles of a wave and phase.  The tile on the diagonal needs no mask: its entries on and left of the
-// diagonal are stored zeros.
-// (half a tile = 32 columns of 64 rows per unit, so that the next unit's loads can be in flight while the current one
-// is accumulated without a second tile's worth of registers)
-template <typename U> struct HalfTileRows {
-    static constexpr int C = 16 / (int)sizeof(U);      // columns per 16-byte load
-    static constexpr int N = (kPanel / 2) / C;         // loads per lane and half tile
-    RawRow<U, C> v[N];
-    __device__ __forceinline__ void load(const U* __restrict__ rowp) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = load_raw<U, C>(rowp + C * i);
-    }
-    // The same half tile with COALESCED loads: instruction i covers rows i * 64 / N .. of the row panel, N lanes per
-    // row (one 16-byte piece each) -- 8 .. 32 cache lines per instruction instead of 64.  `to_rows` then hands every
-    // lane the N pieces of its own row through a 32-row LDS buffer of the wave (two rounds; pieces rotated by the row
-    // so that both the 16-byte writes and the 16-byte reads are conflict-free).
-    static constexpr int kRowBytes = N * 16;
-    static constexpr int kRowsPerLoad = kPanel / N;
-    static constexpr int kBufBytes = 32 * kRowBytes;
-    static __device__ __forceinline__ int rot(int row) { return (row / (8 / N)) % N; }
-    __device__ __forceinline__ void load_co(const U* __restrict__ col0, int64_t stride, int row0, int b, int lane) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int row = min(row0 + i * kRowsPerLoad + lane / N, b - 1);      // rows past the block: clamped, never used
-            v[i] = load_raw<U, C>(col0 + (int64_t)row * stride + (lane % N) * C);
-        }
-    }
-    // The half tile ON THE DIAGONAL (column half `half` of tile R[pp, pp]): a 16-byte piece whose columns all lie on or
-    // left of the diagonal holds stored zeros -- those lanes read the plan's 16 zero bytes (`zero`, one hot cache line)
-    // instead: the zero half of every diagonal tile is never fetched from HBM.
-    __device__ __forceinline__ void load_co_diag(const U* __restrict__ col0, int64_t stride, int row0, int b, int lane, int half,
-                                                 const U* __restrict__ zero) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int rloc = i * kRowsPerLoad + lane / N;
-            const int row = min(row0 + rloc, b - 1);
-            const bool needed = half * (kPanel / 2) + (lane % N) * C + C - 1 > rloc;
-            v[i] = load_raw<U, C>(needed ? col0 + (int64_t)row * stride + (lane % N) * C : zero);
-        }
-    }
-    __device__ __forceinline__ void load_diag(const U* __restrict__ rowp, int lane, int half, const U* __restrict__ zero) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const bool needed = half * (kPanel / 2) + C * i + C - 1 > lane;
-            v[i] = load_raw<U, C>(needed ? rowp + C * i : zero);
-        }
-    }
-    __device__ __forceinline__ void to_rows(char* __restrict__ buf, int lane) {
-        static_assert(N == 2 || N == 4 || N == 8, "pieces per row");
-        RawRow<U, C> out[N];
-#pragma unroll
-        for (int round = 0; round < 2; ++round) {
-#pragma unroll
-            for (int k = 0; k < N / 2; ++k) {
-                const int i = round * (N / 2) + k;
-                const int row = k * kRowsPerLoad + lane / N;                      // 0 .. 31 within the round
-                const int slot = (lane % N + rot(row)) % N;
-                *reinterpret_cast<uint4*>(buf + row * kRowBytes + slot * 16) = uint4{v[i].w[0], v[i].w[1], v[i].w[2], v[i].w[3]};
-            }
-            __builtin_amdgcn_wave_barrier();
-            if ((lane >> 5) == round) {
-                const int row = lane & 31;
-#pragma unroll
-                for (int c = 0; c < N; ++c) {
-                    const uint4 t = *reinterpret_cast<const uint4*>(buf + row * kRowBytes + ((c + rot(row)) % N) * 16);
-                    out[c].w[0] = t.x; out[c].w[1] = t.y; out[c].w[2] = t.z; out[c].w[3] = t.w;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll
-        for (int c = 0; c < N; ++c) v[c] = out[c];
-    }
-    // s += sum_c R[row, c0 + c] * ed[c0 + c] in column order
-    // `ed`: eta_diff of the 32 columns, wave-uniform (read once per column half and phase, not once per tile).  No
-    // mask for the diagonal tile: the repacked block holds exact zeros on and left of the diagonal (abi_plan.hip,
-    // repack_dense_kernel on a zeroed buffer), and fma(0, e, s) == s bit for bit -- s starts at +0 and a sum of
-    // products is never -0 in round-to-nearest.
-    __device__ __forceinline__ float accumulate(float s, const float (&ed)[kPanel / 2]) const {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-#pragma unroll
-            for (int e = 0; e < C; ++e) s = __builtin_fmaf(v[i].get(e), ed[C * i + e], s);
-        }
-        return s;
-    }
-};
-
 // ---------------------------------------------------------------------------------------------
 // Model policies: what one SNP update computes (the serial chain evaluates `update` with the
 // lane-select table lookup; after the 64 steps every lane replays its own SNP with the per-lane
@@ -595,15 +498,15 @@ template <typename M> struct is_wide_mixture<M, std::enable_if_t<M::kWide>> { st
 // One role of the sweep kernel below: a workgroup either works as member `wg % team_size` of team `wg / team_size`
 // on the statically assigned blocks of a team class (TEAM), or pulls blocks from the small-block queue.
 // FORM: what the LD buffer holds and which arithmetic runs over it --
-//   kFormUpper   rows of the upper triangle (zeros on and left of the diagonal), the reference's low_memory = True arithmetic:
-//                trailing updates to the right of the chain + the second pass as per-row running sums (HalfTileRows)
 //   kFormSym     the symmetric matrix, the reference's low_memory = False arithmetic
 //   kFormMirror  the upper triangle MIRRORED into the lower one (zero diagonal), low_memory = True arithmetic: the second
 //                pass q[i] += dq * sum_{j > i} R[i, j] ed[j] reads R[i, j] as R[j, i] -- row j of the buffer, lane = column i,
 //                coalesced, the same strip update that carries the trailing updates, into the sums s instead of q (the
 //                sum of a row still takes its terms in ascending j: the reference's dot, bit for bit).  No transposition,
 //                no second kind of tile traffic: the instruction stream and the memory traffic of the symmetric form.
-constexpr int kFormUpper = 0, kFormSym = 1, kFormMirror = 2;
+// (Rounds 1-5 also had a form over the PACKED upper triangle -- zeros on and left of the diagonal, the second pass as
+//  per-row running sums behind an LDS transposition; removed in round 6 after a round on the mirrored form.)
+constexpr int kFormSym = 1, kFormMirror = 2;
 
 template <typename U, typename MODEL, int FORM, int NW, bool TEAM, int CPL>
 __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int qcap, float* __restrict__ smem, const int wg) {
@@ -614,46 +517,27 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     //     phase ahead of its use);
     //   mixtures (rolled chain loop): the same since round 4 (before: the off-diagonal tiles R[p-1, p] / R[p, p+1] here and the
     //     diagonal rows streamed from global memory by the chain wave; -DPANEL_MIX_UPPER_REGS keeps that for the upper form).
-    constexpr bool SYM = FORM != kFormUpper;        // the buffer holds both triangles: strips left and right of the chain
-    constexpr bool MIR = FORM == kFormMirror;       // ... but the arithmetic is the upper-triangular form's
+    // (the buffer holds both triangles in either form: strips left and right of the chain)
+    constexpr bool MIR = FORM == kFormMirror;       // the arithmetic is the upper-triangular form's
     constexpr bool SUMS = FORM != kFormSym;         // second-pass sums s[] and eta_diff of the last two panels in LDS
     constexpr bool kDiagInLds = !MODEL::kLaneParallel;
-    // The off-diagonal tile of the chain's next phase goes through LDS too (below) in the SYMMETRIC form.  The upper-
-    // triangular form keeps the chain's own register prefetch for fp32 / int16 LD: measured with nothing else changed
-    // (-DPANEL_UPPER_LDS_TILE; the LDS is there since the team classes keep only their own strips), the tile in LDS makes the
-    // cfg3 sweep 5 % SLOWER (0.792 -> 0.831 ms) although the chain loop itself gets faster -- the upper form's updater waves
-    // carry the second pass and are the busier side: one more tile to stage per phase, and a go-ahead to wait for, cost them
-    // more than the chain wins.  With int8 LD (a quarter of the bytes, a chain-bound sweep) it is the other way round
-    // (panel_upper_tile_in_lds, kernels_common.h).
-    // The K <= 8 mixture chain (components of one SNP across the lanes) follows the same scheme, in both LD forms:
-    // diagonal tiles staged in LDS, the off-diagonal tile of the next phase in the single gated buffer -- its chain wave
-    // issues no vector-memory instruction inside a panel either (it used to stream the diagonal rows from global memory,
-    // 16 rows ahead).
-    // (round 4: in the upper-triangular form too -- its chain used to stream the diagonal rows from global memory through a
-    //  16-row register window: cfg3 K = 4 1.217 -> 1.099 ms, int8 LD 1.100 -> 0.997, K = 8 1.425 -> 1.30; -DPANEL_MIX_UPPER_REGS:
-    //  the old form)
-    // ... and the wide mixtures (K = 9 .. 31): K = 10 / 20 1.98 / 2.76 -> 1.86 / 2.61 ms, upper form 2.00 / 2.86 -> 1.82 / 2.55.
-#ifdef PANEL_MIX_UPPER_REGS
-    constexpr bool kMixLds = MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value && SYM;
-#else
+    // The off-diagonal tile of the chain's next phase goes through LDS too (below), for every model and both forms: the
+    // chain wave issues no vector-memory instruction inside a panel.  The K <= 8 mixture chain (components of one SNP across
+    // the lanes) and the wide mixtures (K = 9 .. 31) follow the same scheme: diagonal tiles staged in LDS, the off-diagonal
+    // tile of the next phase in the single gated buffer.
     constexpr bool kMixLds = MODEL::kLaneParallel;
-#endif
     constexpr bool kStageDiag = kDiagInLds || kMixLds;          // what the updaters stage into lT: diagonal tiles
-    constexpr bool kTileInLds = (kDiagInLds && (SYM || panel_upper_tile_in_lds<U>())) || kMixLds;
     float* lq = smem;
     float* la = smem + qcap;
     float* lT = la + 2 * kPanel;
     // lane-per-SNP models: the off-diagonal tile R[p, p+1] the chain's NEXT phase starts with (ONE buffer: staged by the
     // updaters during phase p once the chain has consumed its predecessor -- s_tdone below)
     float* lTo = lT + 2 * kPanel * kPanel;
-    float* lmx = lTo + (kTileInLds ? kPanel * kPanel : 0);   // mixture chain only (kMixLdsFloats)
+    float* lmx = lTo + kPanel * kPanel;                      // mixture chain only (kMixLdsFloats)
     // upper-triangular form: eta_diff of the last two panels and the running second-pass sums s[j] of the block
-    // (panel_upper_lds_floats; behind the mixture scratch)
+    // (panel_mirror_lds_floats; behind the mixture scratch)
     float* led = lmx + ((MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value) ? kMixLdsFloats : 0);
     float* ls = led + 2 * kPanel;
-    // upper-triangular form: one 32-row transposition buffer per updater wave (HalfTileRows::to_rows), behind ls[qcap]
-    char* tbuf = reinterpret_cast<char*>(ls + qcap) + (threadIdx.x >> 6 ? (threadIdx.x >> 6) - 1 : 0) * kPanelUpperTransposeBytes;
-    constexpr bool kSecondPassViaLds = !(MODEL::kLaneParallel && !is_wide_mixture<MODEL>::value);
     // row loads in flight per updater lane: 64 VGPRs of row data whatever the strip width (team strips are narrower, see
     // panel_team_cols: more rows in flight, fewer memory round trips per phase on the critical path)
 #ifdef PANEL_TEAM_STRIP_DEPTH
@@ -669,15 +553,6 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const U* __restrict__ ldd = static_cast<const U*>(A0.ld_dense);
-    // Packed upper-triangular form (kFormUpper), integer LD: the 16-byte pieces of a DIAGONAL tile that lie on or left of the diagonal hold stored
-    // zeros; the lanes that would request them read the plan's 16 zero bytes instead (one hot cache line) -- in the chain's
-    // tile staging and in the second pass.  int8 upper, cfg3: 0.517 -> 0.507 ms (builds alternating on one box).  What it
-    // saves are REQUESTS through the vector-memory path, not HBM bytes: an int8 tile row is 64 bytes, half a cache line, and
-    // the line is fetched for its non-zero part anyway (PMC traffic 1.873 -> 1.868 GB).  NOT for fp32 LD: there the updater
-    // waves are bound by their instruction stream and the address selects cost more than the requests save (0.79 -> 0.87 ms;
-    // K = 4 mixture 1.09 -> 1.33) -- measured, EXPERIMENTS.md round 5.
-    constexpr bool kSkipDiagZeros = !SYM && sizeof(U) < 4;
-    const U* __restrict__ zero16 = ldd + A0.ld_zero_off;
     ExpTab tab;
     tab.init();
     unsigned long long my_skipped = 0;
@@ -757,10 +632,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
             // only ever meet a = 0)
             for (int i = tid; i < kPanel * kPanel / 4; i += NW * 64) {
                 const int row = i >> 4, tcol = (i & 15) * 4;
-                // (upper-triangular form: 4 columns on or left of the diagonal are stored zeros -- not fetched)
-                const bool needed = !kSkipDiagZeros || tcol + 3 > row;
-                *reinterpret_cast<float4*>(lT + row * kPanel + tcol) =
-                    load4<U>(needed ? base + (int64_t)min(row, b - 1) * stride + tcol : zero16);
+                *reinterpret_cast<float4*>(lT + row * kPanel + tcol) = load4<U>(base + (int64_t)min(row, b - 1) * stride + tcol);
             }
         }
         __syncthreads();
@@ -771,7 +643,6 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
         //      current panel's serial updates so that no HBM latency sits between two panels
         typename MODEL::In nxt_in{};
         float dnext[kChainPrefetch];                    // mixture chain: first diagonal rows of the next panel
-        float tnext[(kDiagInLds && !kTileInLds) ? kPanel : 1];   // register prefetch of tile R[p, p+1]: column `lane`, row by row
         if (wave == 0) {
             const bool live0 = lane < b;
             nxt_in = MODEL::load(A, s0 + (live0 ? lane : 0), live0);
@@ -857,11 +728,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                     }
                     PPROF(1, true);
                     if (p > 0) {
-                        if (kDiagInLds && !kTileInLds) {
-                            // a_{p-1} through tile R[p-1, p], prefetched into registers during the previous phase
-#pragma unroll
-                            for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(tnext[k], rl(a_prev, k), qc);
-                        } else if (kTileInLds) {
+                        {
                             // a_{p-1} through tile R[p-1, p], staged in LDS by the updaters during the previous phase: the
                             // chain wave issues NO vector-memory instruction between two panels and none inside one -- a
                             // global load per step stalls at issue behind the updaters' loads when the chip is loaded
@@ -888,15 +755,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #pragma unroll
                                 for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(trow[k], rl(a_prev, k), qc);
                             }
-                        } else {
-                            // a_{p-1} through tile R[p-1, p] (staged in LDS by the updaters last phase)
-                            const float* __restrict__ T = lT + (p & 1) * kPanel * kPanel;
-#pragma unroll
-                            for (int k = 0; k < kPanel; ++k) qc = __builtin_fmaf(T[k * kPanel + lane], rl(a_prev, k), qc);
                         }
                     }
 
-                    if (kTileInLds) {
+                    {
                         // the tile is consumed: the updaters may stage the next one (LDS executes a wave's operations in
                         // order, so the reads above precede this store)
                         if (lane == 0) *reinterpret_cast<volatile int*>(&s_tdone) = p + 1;
@@ -1003,7 +865,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             //  valid q in qc from here on, theirs is captured at their own step)
                             if (MIR) q_own = me ? qc : q_own;
                             qc = __builtin_fmaf(drow_jj, a, qc);
-                            if (SYM && !MIR) qc = (me && livej) ? qc - d : qc;                 // :527
+                            if (!MIR) qc = (me && livej) ? qc - d : qc;                 // :527
                         }
                         }
                         if (!kMixLds) {
@@ -1139,7 +1001,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             //  valid q in qc from here on, theirs is captured at their own step)
                             if (MIR) q_own = me ? qc : q_own;
                             qc = __builtin_fmaf(drow_jj, a, qc);
-                            if (SYM && !MIR) qc = (me && livej) ? qc - d : qc;                 // :527
+                            if (!MIR) qc = (me && livej) ? qc - d : qc;                 // :527
                             cmm = nmm; csv = nsv; cul = nul;
                         }
                         }
@@ -1182,18 +1044,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         //     their d exactly 0: they skip by themselves, no `live` test inside the loop;
                         float qcap_v = 0.0f;   // lane j keeps the q_j its own update consumed
                         const float* __restrict__ Dt = lT + (p & 1) * kPanel * kPanel + lane;
-                        // register prefetch (upper-triangular form): rows of panel p x columns of panel p+1, one row per
-                        // step, a whole phase ahead of its use (clamped into the block when there is no next panel; rows
-                        // past a partial last panel run into the slack behind the dense LD buffer: loaded, never used)
-                        const U* __restrict__ tptr = base + (int64_t)r0 * stride + min(r0 + kPanel, bpad - kPanel) + lane;
                         unsigned long long lane_bit = 1ull;
                         float qf = qc;
     #pragma unroll
                         for (int jj = 0; jj < kPanel; ++jj) {
-                            if (!kTileInLds) {
-                                tnext[jj] = static_cast<float>(*tptr);
-                                tptr += stride;
-                            }
                             const float dr = Dt[jj * kPanel];
                             const float d = MODEL::template delta<kLookupLane>(in, qf, tab, jj);
                             const float dz = (MODEL::kHasSkip && fabsf(d) < Eps<float>::value) ? 0.0f : d;   // :410
@@ -1207,7 +1061,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             qcap_v = sel_mask(qcap_v, qc, lane_bit);
                             qf = __builtin_fmaf(dr, sa, qc);
                             // (mirrored storage: qc of the lanes <= jj is no longer a q after this -- theirs was captured in qcap_v)
-                            qc = (SYM && !MIR) ? sel_mask(qf, qf - sdz, lane_bit) : qf;   // e_step.hpp:427 (own lane only)
+                            qc = !MIR ? sel_mask(qf, qf - sdz, lane_bit) : qf;   // e_step.hpp:427 (own lane only)
                             asm volatile("s_lshl_b64 %0, %0, 1" : "+s"(lane_bit) : : "scc");
                         }
                         q_own = qcap_v;
@@ -1246,12 +1100,10 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) {
                         const int row = 4 * min(uw + g * (NW - 1), kPanel / 4 - 1) + trow;
-                        // (upper-triangular form, diagonal tile: pieces on or left of the diagonal are stored zeros -- not fetched)
-                        const bool needed = !kSkipDiagZeros || !kStageDiag || tcol + 3 > row;
-                        v[g] = load4<U>(needed ? base + (int64_t)min(row_base + row, b - 1) * stride + (p + 1) * kPanel + tcol : zero16);
+                        v[g] = load4<U>(base + (int64_t)min(row_base + row, b - 1) * stride + (p + 1) * kPanel + tcol);
                     }
-                    float4 w[kTileInLds ? kGroups : 1];
-                    if (kTileInLds) {
+                    float4 w[kGroups];
+                    {
                         // ... and the off-diagonal tile R[p, p+1] its next phase STARTS with (rows of this panel; rows past a
                         // partial last panel are clamped: they only ever meet a = 0)
 #pragma unroll
@@ -1269,7 +1121,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         const int i = uw + g * (NW - 1);
                         if (i < kPanel / 4) *reinterpret_cast<float4*>(T + (4 * i + trow) * kPanel + tcol) = v[g];
                     }
-                    if (kTileInLds) {
+                    {
                         // the single buffer still holds R[p-1, p] until the chain has applied it (first thing in its phase)
                         while (*reinterpret_cast<volatile int*>(&s_tdone) < p + 1) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
@@ -1312,7 +1164,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
 #if defined(PANEL_TIMING_NO_SECOND_PASS) && PANEL_TIMING_NO_SECOND_PASS + 0 >= 2     // (timing experiments only: wrong results)
                     const bool active = (c < b) && cp > p;
 #else
-                    const bool active = (c < b) && (SYM ? (cp != pp && cp != p) : (cp > p));
+                    const bool active = (c < b) && cp != pp && cp != p;
 #endif
                     auto hand_off = [&]() {
                         if (TEAM && st == s_pri && p + 1 < np && p + 1 >= 2) {
@@ -1387,66 +1239,6 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                 PPROF(5, wave == 1);
                 if (p > 0) {
                     for (int k = uw; k < n_mine; k += NW - 1) do_strip(k);
-#ifdef PANEL_TIMING_NO_SECOND_PASS           // (traffic experiments only: wrong results)
-                    if (false) {
-#else
-                    if (!SYM) {
-#endif
-                        // second pass, column panel pp: tiles R[r, pp], r = 0 .. pp, of the row panels this member owns
-                        // (the owner of a strip owns the q -- and the sums -- of its rows), dealt to its updater waves
-                        const float edv = led[(pp & 1) * kPanel + lane];
-                        if (__ballot(edv != 0.0f) != 0) {
-                            // this wave's tiles: row panels r = uw, uw + NU, ... <= pp (teams: of the member's own strips);
-                            // the next tile's loads of the same column half are in flight while the current one is accumulated
-                            auto mine = [&](int r) { return !TEAM || (((r * kPanel) / kSW) % TS) == member; };
-                            int r = uw;
-                            while (r <= pp && !mine(r)) r += NW - 1;
-                            // Column half by column half (a row's sum still takes its columns in order): the 32 eta_diff
-                            // values of a half are read into SGPRs once and serve all tiles of the wave; the two row
-                            // buffers alternate between consecutive tiles.
-                            const int r_first = r;
-                            auto second_pass_half = [&](auto half_c) {
-                                constexpr int H = decltype(half_c)::value;
-                                float ed[kPanel / 2];
-#pragma unroll
-                                for (int c = 0; c < kPanel / 2; ++c) ed[c] = rl(edv, H * (kPanel / 2) + c);
-                                HalfTileRows<U> h0, h1;
-                                const U* __restrict__ col0 = base + pp * kPanel + H * (kPanel / 2);
-                                // coalesced loads + transposition through the wave's LDS buffer; the K <= 8 mixture (whose
-                                // chain scratch takes that LDS) loads lane-per-row
-                                auto fetch = [&](HalfTileRows<U>& h, int rr) {
-                                    if (kSkipDiagZeros && rr == pp) {          // the tile on the diagonal: its zero pieces are not fetched
-                                        if constexpr (kSecondPassViaLds) h.load_co_diag(col0, stride, rr * kPanel, b, lane, H, zero16);
-                                        else h.load_diag(col0 + (int64_t)min(rr * kPanel + lane, b - 1) * stride, lane, H, zero16);
-                                    } else {
-                                        if constexpr (kSecondPassViaLds) h.load_co(col0, stride, rr * kPanel, b, lane);
-                                        else h.load(col0 + (int64_t)min(rr * kPanel + lane, b - 1) * stride);
-                                    }
-                                };
-                                int r = r_first;
-                                if (r <= pp) fetch(h0, r);
-                                while (r <= pp) {
-                                    int rn = r + NW - 1;
-                                    while (rn <= pp && !mine(rn)) rn += NW - 1;
-                                    if (rn <= pp) fetch(h1, rn);
-                                    float* __restrict__ sl = ls + loc(r * kPanel + lane);
-                                    if constexpr (kSecondPassViaLds) h0.to_rows(tbuf, lane);
-                                    *sl = h0.accumulate(*sl, ed);
-                                    r = rn;
-                                    if (r > pp) break;
-                                    rn = r + NW - 1;
-                                    while (rn <= pp && !mine(rn)) rn += NW - 1;
-                                    if (rn <= pp) fetch(h0, rn);
-                                    sl = ls + loc(r * kPanel + lane);
-                                    if constexpr (kSecondPassViaLds) h1.to_rows(tbuf, lane);
-                                    *sl = h1.accumulate(*sl, ed);
-                                    r = rn;
-                                }
-                            };
-                            second_pass_half(std::integral_constant<int, 0>{});
-                            second_pass_half(std::integral_constant<int, 1>{});
-                        }
-                    }
                 }
             }
             PPROF(7, wave == 1);
@@ -1543,7 +1335,7 @@ __global__ __launch_bounds__(NW * 64, PANEL_MIN_WAVES) void estep_sweep_kernel(S
         // chains, 3-4 x longer per step, never wait for their updaters (2.5 % slower): all of those keep the wide strips.
         // (mirrored upper form: integer LD -- a chain-bound sweep whose teams wait for the hand-off behind the priority strip --
         //  takes the narrow strips as well; fp32 LD, bound by the stream, keeps the 16-byte loads like the symmetric form)
-        constexpr bool kNarrowForm = FORM == kFormUpper || (FORM == kFormMirror && sizeof(U) < 4);
+        constexpr bool kNarrowForm = FORM == kFormMirror && sizeof(U) < 4;
         constexpr int CPL_N = (MODEL::kLaneParallel || !kNarrowForm) ? CPL : panel_team_cols<U>();
         const int wg_t = wg - (team_cls ? S.n_wg[0] : 0);
         if (CPL_N != CPL && team_cls == 0 && S.narrow0)

@@ -18,7 +18,7 @@
 #pragma once
 #include "device_math.h"
 #include "estep_generic.h"
-#include "estep_panel.h"        // HalfTileRows: coalesced half-tile loads handed to lane-per-row chains through LDS
+#include "estep_panel.h"        // RawRow / load_raw, the model policies' helpers
 #include "kernels_common.h"
 
 namespace viprs {
@@ -538,6 +538,54 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
 
 constexpr int kTileGroupRows = 8;       // second pass: rows per record of the plan's row lists (a 64-row group starts at every 8th)
 
+// A half tile (64 rows x 32 columns) for a lane-per-ROW chain: COALESCED loads -- instruction i covers rows i * 64 / N .. of
+// the row panel, N lanes per row (one 16-byte piece each): 8 .. 32 cache lines per instruction instead of 64 -- and
+// `to_rows`, which hands every lane the N pieces of its own row through a 32-row LDS buffer of the wave (two rounds; pieces
+// rotated by the row so that both the 16-byte writes and the 16-byte reads are conflict-free).  (Half a tile per unit, so
+// that the next unit's loads can be in flight while the current one is accumulated without a second tile's worth of registers.)
+template <typename U> struct HalfTileRows {
+    static constexpr int C = 16 / (int)sizeof(U);      // columns per 16-byte load
+    static constexpr int N = (kPanel / 2) / C;         // loads per lane and half tile
+    RawRow<U, C> v[N];
+    static constexpr int kRowBytes = N * 16;
+    static constexpr int kRowsPerLoad = kPanel / N;
+    static constexpr int kBufBytes = 32 * kRowBytes;
+    static __device__ __forceinline__ int rot(int row) { return (row / (8 / N)) % N; }
+    __device__ __forceinline__ void load_co(const U* __restrict__ col0, int64_t stride, int row0, int b, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int row = min(row0 + i * kRowsPerLoad + lane / N, b - 1);      // rows past the block: clamped, never used
+            v[i] = load_raw<U, C>(col0 + (int64_t)row * stride + (lane % N) * C);
+        }
+    }
+    __device__ __forceinline__ void to_rows(char* __restrict__ buf, int lane) {
+        static_assert(N == 2 || N == 4 || N == 8, "pieces per row");
+        RawRow<U, C> out[N];
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+#pragma unroll
+            for (int k = 0; k < N / 2; ++k) {
+                const int i = round * (N / 2) + k;
+                const int row = k * kRowsPerLoad + lane / N;                      // 0 .. 31 within the round
+                const int slot = (lane % N + rot(row)) % N;
+                *reinterpret_cast<uint4*>(buf + row * kRowBytes + slot * 16) = uint4{v[i].w[0], v[i].w[1], v[i].w[2], v[i].w[3]};
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == round) {
+                const int row = lane & 31;
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(buf + row * kRowBytes + ((c + rot(row)) % N) * 16);
+                    out[c].w[0] = t.x; out[c].w[1] = t.y; out[c].w[2] = t.z; out[c].w[3] = t.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = out[c];
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Second pass of the upper-triangular form, update_q_factor (e_step.hpp:331-337): q[j] += dq * dot(eta_diff[win(j)],
 // row(j)), in the REFERENCE'S ORDER: dot() of e_step.hpp:82-104 is a serial fma chain over a row's columns in index order,
@@ -549,7 +597,7 @@ constexpr int kTileGroupRows = 8;       // second pass: rows per record of the p
 //   zeros there are SKIPPED, not multiplied -- fma(0, eta_diff, s) would turn a non-finite eta_diff[c], c <= j, into a NaN in
 //   q[j] that the reference does not produce.
 //   dense blocks, LD elements of 1 / 2 / 4 bytes: a tile of 64 rows x 32 columns is loaded coalesced and handed to the
-//     rows through the wave's LDS buffer (HalfTileRows, as the fp32 panel kernel's second pass does), eta_diff of the
+//     rows through the wave's LDS buffer (HalfTileRows above), eta_diff of the
 //     tile's 64 columns sits in LDS as doubles (broadcast reads); the next half tile's loads are in flight while the
 //     current one is accumulated; a tile whose eta_diff are all zero (skipped SNPs) is not read: fma(R, 0, s) == s.
 //   everything else (windowed components, 8-byte LD elements): element by element along the row.

@@ -82,7 +82,7 @@ struct viprs_plan {
     int64_t nnz = 0;
     int low_memory = 0;
     int mirror = 0;                  // upper-triangular form: the dense blocks currently hold the upper triangle mirrored into the lower one
-    bool use_mirror = true;          // ... which the panel kernels ask for (kFormMirror, estep_panel.h) unless VIPRS_UPPER_MIRROR=0
+                                     // (what the panel and grid kernels sweep; the float64 kernels read it with a zero lower triangle)
     int ld_dtype = 0;
     int device = 0;
     int n_cu = 0;
@@ -112,13 +112,6 @@ struct viprs_plan {
     viprs::DevBuf<int32_t> d_error;
     int grid_mfma = -1;                     // batched grid E-step on the matrix cores: 1 always, 0 never (per-(block,
                                             // model) items), -1 when the plan has enough blocks to fill the CUs (VIPRS_GRID_MFMA)
-    int64_t n_epi = 0;
-    viprs::DevBuf<viprs::EpiItem> d_epi_all;              // upper form, batched grid second pass: (block, 64-row group) items, longest first
-    viprs::DevBuf<viprs::EpiItem> d_low_items;            // symmetric form: (block, 128-column tile) items of the batched grid lower pass
-    int64_t n_low_items = 0;
-    int64_t n_low_items_big = 0;                          // ... of which belong to blocks beyond the resident form (they come first)
-    viprs::DevBuf<viprs::EpiItem> d_low_split;            // those again, as two half-tile items each: (block, 2 x tile + column-group pair)
-    int64_t n_low_split = 0;
     viprs::DevBuf<int32_t> d_lb;
     viprs::DevBuf<int64_t> d_ip;
     viprs::DevBuf<int32_t> d_rowlen;               // indptr[j+1] - indptr[j]

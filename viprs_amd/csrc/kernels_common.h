@@ -10,15 +10,12 @@
 #if (defined(PANEL_TIMING_NO_HANDOFF_WAIT) || \
     defined(PANEL_TIMING_NO_SECOND_PASS) || \
     defined(PANEL_NW) || \
-    defined(PANEL_MIX_UPPER_REGS) || \
-    defined(PANEL_UPPER_LDS_TILE) || \
     defined(PANEL_STRIP_DEPTH) || \
     defined(PANEL_MIN_WAVES) || \
     defined(PANEL_TEAM_STRIP_DEPTH) || \
     defined(PANEL_TEAM_CPL_F32) || \
     defined(PANEL_CHAIN_PRIO) || \
     defined(VIPRS_GRID_MFMA_CHAIN) || \
-    defined(GRID_EPI_BUFS) || \
     defined(VIPRS_GRID_PROFILE) || \
     defined(VIPRS_TILE_PROFILE) || \
     defined(VIPRS_SWEEP_TRACE) || \
@@ -45,16 +42,6 @@
 #define VIPRS_BF_PANEL_NW " PANEL_NW"
 #else
 #define VIPRS_BF_PANEL_NW ""
-#endif
-#ifdef PANEL_MIX_UPPER_REGS
-#define VIPRS_BF_PANEL_MIX_UPPER_REGS " PANEL_MIX_UPPER_REGS"
-#else
-#define VIPRS_BF_PANEL_MIX_UPPER_REGS ""
-#endif
-#ifdef PANEL_UPPER_LDS_TILE
-#define VIPRS_BF_PANEL_UPPER_LDS_TILE " PANEL_UPPER_LDS_TILE"
-#else
-#define VIPRS_BF_PANEL_UPPER_LDS_TILE ""
 #endif
 #ifdef PANEL_STRIP_DEPTH
 #define VIPRS_BF_PANEL_STRIP_DEPTH " PANEL_STRIP_DEPTH"
@@ -86,11 +73,6 @@
 #else
 #define VIPRS_BF_VIPRS_GRID_MFMA_CHAIN ""
 #endif
-#ifdef GRID_EPI_BUFS
-#define VIPRS_BF_GRID_EPI_BUFS " GRID_EPI_BUFS"
-#else
-#define VIPRS_BF_GRID_EPI_BUFS ""
-#endif
 #ifdef VIPRS_GRID_PROFILE
 #define VIPRS_BF_VIPRS_GRID_PROFILE " VIPRS_GRID_PROFILE"
 #else
@@ -111,7 +93,7 @@
 #else
 #define VIPRS_BF_VIPRS_PANEL_PROFILE ""
 #endif
-#define VIPRS_TU_BUILD_FLAGS VIPRS_BF_VIPRS_EXPERIMENTAL VIPRS_BF_PANEL_TIMING_NO_HANDOFF_WAIT VIPRS_BF_PANEL_TIMING_NO_SECOND_PASS VIPRS_BF_PANEL_NW VIPRS_BF_PANEL_MIX_UPPER_REGS VIPRS_BF_PANEL_UPPER_LDS_TILE VIPRS_BF_PANEL_STRIP_DEPTH VIPRS_BF_PANEL_MIN_WAVES VIPRS_BF_PANEL_TEAM_STRIP_DEPTH VIPRS_BF_PANEL_TEAM_CPL_F32 VIPRS_BF_PANEL_CHAIN_PRIO VIPRS_BF_VIPRS_GRID_MFMA_CHAIN VIPRS_BF_GRID_EPI_BUFS VIPRS_BF_VIPRS_GRID_PROFILE VIPRS_BF_VIPRS_TILE_PROFILE VIPRS_BF_VIPRS_SWEEP_TRACE VIPRS_BF_VIPRS_PANEL_PROFILE
+#define VIPRS_TU_BUILD_FLAGS VIPRS_BF_VIPRS_EXPERIMENTAL VIPRS_BF_PANEL_TIMING_NO_HANDOFF_WAIT VIPRS_BF_PANEL_TIMING_NO_SECOND_PASS VIPRS_BF_PANEL_NW VIPRS_BF_PANEL_STRIP_DEPTH VIPRS_BF_PANEL_MIN_WAVES VIPRS_BF_PANEL_TEAM_STRIP_DEPTH VIPRS_BF_PANEL_TEAM_CPL_F32 VIPRS_BF_PANEL_CHAIN_PRIO VIPRS_BF_VIPRS_GRID_MFMA_CHAIN VIPRS_BF_VIPRS_GRID_PROFILE VIPRS_BF_VIPRS_TILE_PROFILE VIPRS_BF_VIPRS_SWEEP_TRACE VIPRS_BF_VIPRS_PANEL_PROFILE
 
 namespace viprs {
 // abi_plan.hip: the registry behind viprs_build_flags(); every translation unit with kernels registers its own string
@@ -130,24 +112,7 @@ constexpr int kStrip = 256;         // padding unit of the per-block q arrays (o
 __host__ __device__ constexpr int panel_lds_floats(int qcap, bool offdiag_tile = false) {
     return qcap + 2 * kPanel + 2 * kPanel * kPanel + (offdiag_tile ? kPanel * kPanel : 0);
 }
-// Upper-triangular form of the lane-per-SNP models: does the chain's off-diagonal tile go through LDS (as it always does
-// in the symmetric form) or through the chain wave's own register prefetch?  fp32 LD: registers (the updater waves carry
-// the second pass and are the busier side; the tile in LDS makes the cfg3 sweep 5 % slower); int8 LD streams a quarter of
-// the bytes (int16: half), its sweep is bound by the chain: the tile in LDS makes it 8 % faster (int8 0.570 -> 0.522 ms, int16
-// 0.61 -> 0.56 ms; tools/ab_bench.py).
-template <typename U> __host__ __device__ constexpr bool panel_upper_tile_in_lds() {
-#ifdef PANEL_UPPER_LDS_TILE
-    return true;
-#else
-    return sizeof(U) <= 2;
-#endif
-}
-// upper-triangular form: eta_diff[2][64] of the last two panels + the running second-pass sums s[qcap]
-constexpr int kPanelUpperTransposeBytes = 32 * 128;         // per updater wave: 32 rows of a half tile (fp32: 128 B per row)
-__host__ __device__ constexpr int panel_upper_lds_floats(int qcap, int n_waves = 4) {
-    return 2 * kPanel + qcap + (n_waves - 1) * kPanelUpperTransposeBytes / 4;
-}
-// ... over mirrored storage (kFormMirror): eta_diff of the last two panels and the sums, no transposition buffers
+// upper-triangular form over mirrored storage (kFormMirror): eta_diff of the last two panels and the sums s[qcap]
 __host__ __device__ constexpr int panel_mirror_lds_floats(int qcap) { return 2 * kPanel + qcap; }
 constexpr int kPanelMaxK = 8;       // mixture components the lane-parallel panel chain handles with its inputs staged in LDS
 constexpr int kPanelWideMaxK = 31;  // ... and with scalar chains over v_readlane values (MixtureWideModel)
@@ -156,13 +121,9 @@ constexpr int kMixLdsFloats = 5 * kPanel * kPanelMaxK;
 constexpr int kMaxMixtureK = 64;    // generic mixture kernel (estep_generic.h): one lane per component
 constexpr int kGridModels = 32;     // batched grid kernel (estep_grid_mfma.h): models per launch (one 32-row MFMA tile)
 // ... its resident form: 6 owner waves x 2 tiles of 128 columns in accumulator registers = blocks of up to 1 536 SNPs
-// (the plan splits the lower-pass items by the same limit, abi_plan.hip)
 constexpr int kGridResOwners = 6, kGridResSlots = 2;
 constexpr int kGridResMaxCols = kGridResOwners * kGridResSlots * 2 * kPanel;
 constexpr int kBandMaxRingPanels = 256;   // band kernel (estep_band.h): 64 KB of q in the LDS ring
-
-// work item of the second-pass / lower-pass kernels: (block, first row of a 64-row group or tile index)
-struct EpiItem { int32_t blk; int32_t row0; };
 
 // One LD block as the device sees it.
 struct BlockDesc {
