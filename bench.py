@@ -1145,6 +1145,13 @@ def main():
                         "N >= 2 (per_rank.kernel_ms_avg ~ largest_block_chain_ms on the rank holding that block = at the physical "
                         "limit, not a scheduling defect).  `weak_scaling` is the figure that grows with N.",
             }
+            # (also under `config`, next to the workload it qualifies)
+            out["config"]["strong_scaling_ceiling"] = out["strong_scaling_ceiling"]
+            out["config"]["per_rank_projection"] = {
+                "time_model_ms": [float(x) for x in model_ranks], "slowest_rank_time_model_ms": model_ms,
+                "projected_value": total_snps / (model_ms * 1e-3),
+                "note": "every rank's sweep time model (max of its HBM stream, its largest block's chain and its chain throughput); "
+                        "no multi-GPU hardware curve exists for this build: the per-rank kernel times are what was measured"}
             out["startup_s_rank0"] = {"workload_built": t_built - t_start, "ld_resident": t_resident - t_built,
                                       "ld_entries": "generated on the device" if ld.ld_data is None else "built on the host, uploaded"}
         if weak is not None:

@@ -223,7 +223,9 @@ int viprs_state_sums_begin(viprs_state* state, double one_plus_lambda);
 int viprs_state_sums_end(viprs_state* state, double* out);
 /* The same two operations on ONE model (column `g`) of a grid state ((m, G) column-major arrays),
  * for the batched grid fit: e_step_grid takes half_var_tau = var_tau / 2 (e_step.hpp:616) where
- * e_step takes its square root, otherwise the formulas are those above.                            */
+ * e_step takes its square root, otherwise the formulas are those above.  (A grid state does not keep
+ * var_tau -- m x G doubles written per prep and read back per reduction: the sums form it again from n_j
+ * and the scalars of the column's last prep, the same expression, the same bits.)                   */
 int viprs_state_prep_column(viprs_state* state, int g, double logit_pi, double log_tau_beta, double sigma_epsilon,
                             double tau_beta, double one_plus_lambda);
 int viprs_state_sums_column(viprs_state* state, int g, double one_plus_lambda, double* out);

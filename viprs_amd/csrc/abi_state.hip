@@ -25,7 +25,7 @@ __global__ void prep_kernel(const double* __restrict__ n, int64_t m, double logi
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const double vt = n[i] * one_plus_lambda / sigma_eps + tau_beta;
-    var_tau_out[i] = vt;
+    if (var_tau_out) var_tau_out[i] = vt;              // (grid columns: not stored, the sums form it again)
     mu_mult[i] = (T)(n[i] / (vt * sigma_eps));
     u_logs[i] = (T)(logit_pi + 0.5 * (log_tau_beta - log(vt)));
     shvt[i] = half_not_sqrt ? (T)(0.5 * vt) : (T)sqrt(0.5 * vt);     // e_step_grid takes var_tau / 2 (e_step.hpp:616)
@@ -33,17 +33,17 @@ __global__ void prep_kernel(const double* __restrict__ n, int64_t m, double logi
 
 // the same for several columns of a grid state in one launch: blockIdx.y picks a row of `params`
 // (column, logit_pi, log_tau_beta, sigma_eps, tau_beta, one_plus_lambda)
+// (var_tau itself is not stored for a grid state: m x G doubles to write here and to read back in the sums -- the sums
+//  kernel forms it again from n_j and the column's scalars, the same expression, the same bits)
 template <typename T>
 __global__ void prep_columns_kernel(const double* __restrict__ n, int64_t m, const double* __restrict__ params,
-                                    T* __restrict__ mu_mult, T* __restrict__ u_logs, T* __restrict__ shvt,
-                                    double* __restrict__ var_tau_out) {
+                                    T* __restrict__ mu_mult, T* __restrict__ u_logs, T* __restrict__ shvt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const double* __restrict__ p = params + 6 * (int64_t)blockIdx.y;
     const int64_t off = (int64_t)p[0] * m;
     const double logit_pi = p[1], log_tau_beta = p[2], sigma_eps = p[3], tau_beta = p[4], one_plus_lambda = p[5];
     const double vt = n[i] * one_plus_lambda / sigma_eps + tau_beta;
-    var_tau_out[off + i] = vt;
     mu_mult[off + i] = (T)(n[i] / (vt * sigma_eps));
     u_logs[off + i] = (T)(logit_pi + 0.5 * (log_tau_beta - log(vt)));
     shvt[off + i] = (T)(0.5 * vt);                                    // e_step_grid takes var_tau / 2 (e_step.hpp:616)
@@ -85,14 +85,18 @@ __device__ __forceinline__ void sums_body(int64_t i0, int64_t i1, int nb, int bx
                                           const T* __restrict__ mu, const T* __restrict__ eta, const T* __restrict__ q,
                                           const T* __restrict__ ed, const T* __restrict__ beta,
                                           const double* __restrict__ var_tau, double one_plus_lambda,
-                                          const double* __restrict__ weight, double* __restrict__ out) {
+                                          const double* __restrict__ weight, double* __restrict__ out,
+                                          const double* __restrict__ n_snp = nullptr, double p_lam1 = 0.0, double p_sig = 1.0,
+                                          double p_tau = 0.0) {
+    // n_snp != nullptr: var_tau is not stored (grid states) -- formed as the prep kernels form it, n (1 + lambda) / sigma_eps + tau_beta
     __shared__ double red[kNSums][kSumsBlock];
     double acc[kNSums];
 #pragma unroll
     for (int k = 0; k < kNSums; ++k) acc[k] = 0.0;
     const double lo = 1e-15, hi = 1.0 - 1e-15;       // np.finfo(float64).resolution (VIPRS.py:509)
     for (int64_t i = i0 + (int64_t)bx * kSumsBlock + threadIdx.x; i < i1; i += (int64_t)nb * kSumsBlock) {
-        const double g = (double)gam[i], mud = (double)mu[i], vt = var_tau[i];
+        const double g = (double)gam[i], mud = (double)mu[i];
+        const double vt = n_snp ? n_snp[i] * p_lam1 / p_sig + p_tau : var_tau[i];
         const double zeta = g * (mud * mud + 1.0 / vt);                       // VIPRS.py:896
         acc[0] += weight ? g * weight[i] : g;                                  // sum_c mean(gamma_c) over merged chromosomes
         acc[1] += zeta;
@@ -129,11 +133,15 @@ __global__ __launch_bounds__(kSumsBlock) void sums_kernel(int64_t m, const T* __
                                                           const double* __restrict__ weight, double* __restrict__ partials,
                                                           const double* __restrict__ cols = nullptr) {
     if (cols) {
-        // several columns of a grid state in one launch: blockIdx.y picks (column, one_plus_lambda)
-        const int64_t off = (int64_t)cols[2 * blockIdx.y] * m;
-        one_plus_lambda = cols[2 * blockIdx.y + 1];
-        gam += off; mu += off; eta += off; q += off; ed += off; var_tau += off;
+        // columns of a grid state, one per blockIdx.y: a row of `cols` = (column, one_plus_lambda, and the scalars the
+        // column's last prep built var_tau from: one_plus_lambda, sigma_eps, tau_beta); `var_tau` is the per-SNP n here
+        const double* __restrict__ c = cols + 5 * (int64_t)blockIdx.y;
+        const int64_t off = (int64_t)c[0] * m;
+        gam += off; mu += off; eta += off; q += off; ed += off;
         partials += (int64_t)blockIdx.y * gridDim.x * kNSums;
+        sums_body<T>(0, m, (int)gridDim.x, (int)blockIdx.x, gam, mu, eta, q, ed, beta, nullptr, c[1], weight,
+                     partials + (int64_t)blockIdx.x * kNSums, var_tau, c[2], c[3], c[4]);
+        return;
     }
     sums_body<T>(0, m, (int)gridDim.x, (int)blockIdx.x, gam, mu, eta, q, ed, beta, var_tau, one_plus_lambda, weight,
                  partials + (int64_t)blockIdx.x * kNSums);
@@ -491,7 +499,7 @@ static int sums_columns_enqueue(viprs_state* S, int n) {
     sums_kernel<T><<<dim3(nb, n), kSumsBlock, 0, P->stream>>>(
         P->m, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const T*)S->f[VIPRS_FIELD_VAR_MU].p, (const T*)S->f[VIPRS_FIELD_ETA].p,
         (const T*)S->f[VIPRS_FIELD_Q].p, (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p, (const T*)S->f[VIPRS_FIELD_STD_BETA].p,
-        S->d_var_tau.p, 0.0, S->d_weight.p, S->d_partials.p, S->d_sumcols.p);
+        S->d_n.p, 0.0, S->d_weight.p, S->d_partials.p, S->d_sumcols.p);
     HIP_TRY(hipGetLastError());
     sums_final_kernel<<<n, 64 * kNSums, 0, P->stream>>>(S->d_partials.p, nb, S->d_sums.p);
     HIP_TRY(hipGetLastError());
@@ -607,6 +615,16 @@ int viprs_state_sums_end(viprs_state* S, double* out) {
     return sums_finish(S, out);
 }
 
+static void record_col_prep(viprs_state* S, int g, double one_plus_lambda, double sigma_eps, double tau_beta) {
+    if (S->col_prep.size() != (size_t)3 * S->width) S->col_prep.assign((size_t)3 * S->width, NAN);
+    S->col_prep[3 * (size_t)g] = one_plus_lambda;
+    S->col_prep[3 * (size_t)g + 1] = sigma_eps;
+    S->col_prep[3 * (size_t)g + 2] = tau_beta;
+}
+static bool col_prepped(const viprs_state* S, int g) {
+    return S->col_prep.size() == (size_t)3 * S->width && !std::isnan(S->col_prep[3 * (size_t)g]);
+}
+
 static int grid_column_check(viprs_state* S, int g) {
     if (!S) return fail(VIPRS_EINVAL, "null state");
     if (S->model_kind != VIPRS_MODEL_GRID) return fail(VIPRS_EINVAL, "not a grid state");
@@ -623,10 +641,7 @@ int viprs_state_prep_column(viprs_state* S, int g, double logit_pi, double log_t
     viprs_plan* P = S->plan;
     if (P->m == 0) return VIPRS_OK;
     HIP_TRY(hipSetDevice(P->device));
-    if (S->d_var_tau.n < (size_t)P->m * S->width) {      // one var_tau column per model
-        HIP_TRY(hipStreamSynchronize(P->stream));
-        HIP_TRY(S->d_var_tau.alloc((size_t)P->m * S->width));
-    }
+    record_col_prep(S, g, one_plus_lambda, sigma_epsilon, tau_beta);
     const int64_t off = (int64_t)g * P->m;
     const unsigned grid = (unsigned)((P->m + 255) / 256);
     if (S->float_dtype == VIPRS_F32)
@@ -634,13 +649,13 @@ int viprs_state_prep_column(viprs_state* S, int g, double logit_pi, double log_t
                                                         one_plus_lambda, (float*)S->f[VIPRS_FIELD_MU_MULT].p + off,
                                                         (float*)S->f[VIPRS_FIELD_U_LOGS].p + off,
                                                         (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p + off,
-                                                        S->d_var_tau.p + off, 1);
+                                                        nullptr, 1);
     else
         prep_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, logit_pi, log_tau_beta, sigma_epsilon, tau_beta,
                                                          one_plus_lambda, (double*)S->f[VIPRS_FIELD_MU_MULT].p + off,
                                                          (double*)S->f[VIPRS_FIELD_U_LOGS].p + off,
                                                          (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p + off,
-                                                         S->d_var_tau.p + off, 1);
+                                                         nullptr, 1);
     HIP_TRY(hipGetLastError());
     return VIPRS_OK;
 }
@@ -764,9 +779,9 @@ int viprs_state_prep_columns(viprs_state* S, int n, const double* params) {
     viprs_plan* P = S->plan;
     if (P->m == 0 || n == 0) return VIPRS_OK;
     HIP_TRY(hipSetDevice(P->device));
-    if (S->d_var_tau.n < (size_t)P->m * S->width) HIP_TRY(S->d_var_tau.alloc((size_t)P->m * S->width));
+    for (int i = 0; i < n; ++i) record_col_prep(S, (int)params[6 * i], params[6 * i + 5], params[6 * i + 3], params[6 * i + 4]);
     if (S->d_colparams.n < (size_t)6 * S->width) HIP_TRY(S->d_colparams.alloc((size_t)6 * S->width));
-    if (!S->h_params) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_params), (size_t)8 * S->width * sizeof(double), hipHostMallocDefault));
+    if (!S->h_params) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_params), (size_t)11 * S->width * sizeof(double), hipHostMallocDefault));
     if (!S->ev_prep) HIP_TRY(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
     else HIP_TRY(hipEventSynchronize(S->ev_prep));            // the previous launch has read its parameters
     memcpy(S->h_params, params, (size_t)6 * n * sizeof(double));
@@ -776,11 +791,11 @@ int viprs_state_prep_columns(viprs_state* S, int n, const double* params) {
     if (S->float_dtype == VIPRS_F32)
         prep_columns_kernel<float><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, S->d_colparams.p,
                                                                 (float*)S->f[VIPRS_FIELD_MU_MULT].p, (float*)S->f[VIPRS_FIELD_U_LOGS].p,
-                                                                (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+                                                                (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p);
     else
         prep_columns_kernel<double><<<grid, 256, 0, P->stream>>>(S->d_n.p, P->m, S->d_colparams.p,
                                                                  (double*)S->f[VIPRS_FIELD_MU_MULT].p, (double*)S->f[VIPRS_FIELD_U_LOGS].p,
-                                                                 (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p, S->d_var_tau.p);
+                                                                 (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(S->ev_prep, P->stream));
     return VIPRS_OK;
@@ -798,13 +813,23 @@ int viprs_state_sums_columns_begin(viprs_state* S, int n, const double* cols) {
     if (P->m == 0 && n > 0 && S->comm) return sums_enqueue_empty(S, kNSums * n, kNSums);
     if (P->m == 0 || n == 0) { S->sums_pending = false; S->sums_empty = true; return VIPRS_OK; }
     S->sums_empty = false;
-    if (S->d_var_tau.n < (size_t)P->m * S->width) return fail(VIPRS_EINVAL, "viprs_state_prep_column(s) has not been called");
+    for (int i = 0; i < n; ++i)
+        if (!col_prepped(S, (int)cols[2 * i])) return fail(VIPRS_EINVAL, "viprs_state_prep_column(s) has not been called");
     HIP_TRY(hipSetDevice(P->device));
     // (own buffer: the previous reduction that read it has been collected, nothing else does)
-    if (S->d_sumcols.n < (size_t)2 * S->width) HIP_TRY(S->d_sumcols.alloc((size_t)2 * S->width));
-    if (!S->h_params) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_params), (size_t)8 * S->width * sizeof(double), hipHostMallocDefault));
-    memcpy(S->h_params + (size_t)6 * S->width, cols, (size_t)2 * n * sizeof(double));
-    HIP_TRY(hipMemcpyAsync(S->d_sumcols.p, S->h_params + (size_t)6 * S->width, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    if (S->d_sumcols.n < (size_t)5 * S->width) HIP_TRY(S->d_sumcols.alloc((size_t)5 * S->width));
+    if (!S->h_params) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_params), (size_t)11 * S->width * sizeof(double), hipHostMallocDefault));
+    // device rows: (column, one_plus_lambda of these sums | what the column's last prep built var_tau from)
+    double* h = S->h_params + (size_t)6 * S->width;
+    for (int i = 0; i < n; ++i) {
+        const int g = (int)cols[2 * i];
+        h[5 * i] = cols[2 * i];
+        h[5 * i + 1] = cols[2 * i + 1];
+        h[5 * i + 2] = S->col_prep[3 * (size_t)g];
+        h[5 * i + 3] = S->col_prep[3 * (size_t)g + 1];
+        h[5 * i + 4] = S->col_prep[3 * (size_t)g + 2];
+    }
+    HIP_TRY(hipMemcpyAsync(S->d_sumcols.p, h, (size_t)5 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
     return S->float_dtype == VIPRS_F32 ? sums_columns_enqueue<float>(S, n) : sums_columns_enqueue<double>(S, n);
 }
 
@@ -837,11 +862,9 @@ int viprs_state_sums_column(viprs_state* S, int g, double one_plus_lambda, doubl
         return rc != VIPRS_OK ? rc : sums_finish(S, out);
     }
     if (P->m == 0) return VIPRS_OK;
-    if (S->d_var_tau.n < (size_t)P->m * S->width) return fail(VIPRS_EINVAL, "viprs_state_prep_column has not been called");
-    HIP_TRY(hipSetDevice(P->device));
-    const int64_t off = (int64_t)g * P->m;
-    return S->float_dtype == VIPRS_F32 ? sums_launch<float>(S, off, off, one_plus_lambda, out)
-                                       : sums_launch<double>(S, off, off, one_plus_lambda, out);
+    const double row[2] = {(double)g, one_plus_lambda};
+    rc = viprs_state_sums_columns_begin(S, 1, row);
+    return rc != VIPRS_OK ? rc : viprs_state_sums_columns_end(S, out);
 }
 
 int viprs_state_reset_column(viprs_state* S, int g, double pi) {

@@ -161,6 +161,7 @@ struct viprs_state {
     viprs::DevBuf<double> d_weight;                // optional per-SNP weight of sum [0] (several chromosomes in one plan)
     viprs::DevBuf<double> d_log_var_tau0;          // mixture: the log var_tau of the initial state (the reference's ELBO never refreshes it)
     viprs::DevBuf<double> d_colparams, d_sumcols;  // grid: per-column parameters of the batched prep / of the batched sums
+    std::vector<double> col_prep;                  // grid: (one_plus_lambda, sigma_eps, tau_beta) of every column's last prep (3 x width; NaN: none yet)
     int sums_cols = 0;                      // columns of the reduction in flight (grid: sums_columns_begin; groups: sums_groups_begin)
     // viprs_state_set_groups: contiguous SNP ranges with their own hyper-parameters and their own sums (one model per chromosome)
     int n_groups = 0, group_max_nb = 0;
