@@ -946,7 +946,10 @@ __global__ __launch_bounds__(64 * kGridWaves) void estep_grid_mfma_kernel(EStepA
         if (blk >= A.n_blocks) break;
         const BlockDesc bd = A.blocks[blk];
         if (bd.size > kGridResMaxCols) {                 // (never: the host gives such blocks a team)
-            if (tid == 0) atomicExch(A.error, 2);
+            // every thread stores (UNIFORM control flow: a divergent `if (tid == 0)` + `continue` here makes the compiler treat
+            // the block descriptor's fields as divergent in the whole loop body -- address arithmetic on the VALU instead of
+            // the SALU, +13 % VALU instructions, +17 % on the cfg3 sweep; EXPERIMENTS.md round 6)
+            __hip_atomic_store(A.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
         // q of the whole block fits the updater waves' accumulator registers

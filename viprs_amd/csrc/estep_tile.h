@@ -413,19 +413,24 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                 // read from LDS while step jj computes, the skip branch (e_step.hpp:410-413) is a select -- a skipped SNP
                 // applies a = 0 (fma(r, 0, q) == q) and keeps its outputs.
                 T r_nxt = static_cast<T>(tile_d[lane]);
-                // is this lane's column inside the window of row jj?  (dense: right of the diagonal in the upper form, any
-                // column in the symmetric one; windowed rows: the row's own bounds, read one step ahead like the tile row)
+                // Columns outside the window of row jj keep their q (see above).
+                //   windowed rows: the row's own bounds, read one step ahead like the tile row, and a select on the step;
+                //   dense blocks, upper form: a column c is outside the windows of the rows jj >= c only, so its final value is
+                //     the q its OWN step consumed -- captured beside the chain (`q_keep`: nothing depends on it), no select on
+                //     the serial path; symmetric form: every column of the panel is inside every window.
                 const int* const dws = s_ws + par * kPanel;
                 const int* const dwe = s_we + par * kPanel;
-                bool in_nxt = DENSE ? (!A.low_memory || lane > 0) : (p0 + lane >= dws[0] && p0 + lane < dwe[0]);
+                bool in_nxt = DENSE ? true : (p0 + lane >= dws[0] && p0 + lane < dwe[0]);
+                T q_keep = ql;
                 for (int jj = 0; jj < np; ++jj) {
                     const T r = r_nxt;
                     const bool in_win = in_nxt;
                     r_nxt = static_cast<T>(tile_d[min(jj + 1, kPanel - 1) * kPanel + lane]);
-                    {
+                    if constexpr (!DENSE) {
                         const int jn = min(jj + 1, kPanel - 1);
-                        in_nxt = DENSE ? (!A.low_memory || lane > jn) : (p0 + lane >= dws[jn] && p0 + lane < dwe[jn]);
+                        in_nxt = p0 + lane >= dws[jn] && p0 + lane < dwe[jn];
                     }
+                    if constexpr (DENSE) q_keep = (lane == jj) ? ql : q_keep;
                     const T qj = readlane_f64(ql, jj);
                     const T eta_old = readlane_f64(c_eta, jj);
                     T mu[KM], gam[KM], d;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                     const bool skip = MODEL::kSkip && fabs(d) < eps;                          // e_step.hpp:410
                     const T de = skip ? (T)0 : d;                                             // :412
                     const T a = A.dq * de;
-                    const T v = in_win ? __builtin_fma(r, a, ql) : ql;                        // :421, in-panel columns of the row's window
+                    const T v = (DENSE || in_win) ? __builtin_fma(r, a, ql) : ql;             // :421, in-panel columns of the row's window
                     const bool own = lane == jj;
                     ql = (own && !A.low_memory) ? v - de : v;                                 // :427
                     const bool take = own && !skip;                                           // :416-418, :431
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(NW * 64) void estep_tile_f64_kernel(EStepArgs<doubl
                 TPROF(5);
                 const unsigned long long applied = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(applied_v >> 32)) << 32) |
                                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)applied_v);
+                if (DENSE && A.low_memory) ql = q_keep;
                 if (lane < np) {
                     const int64_t j = s0 + p0 + lane;
                     qv[p0 + lane] = ql;
@@ -655,7 +661,8 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_exact_ke
                 h0.load_co(col0, bd.stride, r0, b, lane);
                 h1.load_co(col0 + kPanel / 2, bd.stride, r0, b, lane);
                 const bool diag = ct == r0 / kPanel;              // the tile that holds the rows' own diagonal (wave-uniform)
-                auto accumulate = [&](const H& h, int c0) {
+                auto accumulate = [&](const H& h, int c0, auto masked) {
+                    constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
                     for (int i = 0; i < H::N; ++i) {
                         const double2* __restrict__ ep = reinterpret_cast<const double2*>(edl + c0 + H::C * i);
@@ -664,16 +671,17 @@ __global__ __launch_bounds__(kTileThreads, 2) void tile_f64_second_pass_exact_ke
                             const double2 ee = ep[x >> 1];
                             const int cc = c0 + H::C * i + x;     // column inside the tile; this lane's row sits at `lane`
                             const T t0 = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x), ee.x, s);
-                            s = (diag && cc <= lane) ? s : t0;
+                            s = (MASK && cc <= lane) ? s : t0;
                             const T t1 = __builtin_fma(raw_elem_f64<U, H::C>(h.v[i], x + 1), ee.y, s);
-                            s = (diag && cc + 1 <= lane) ? s : t1;
+                            s = (MASK && cc + 1 <= lane) ? s : t1;
                         }
                     }
                 };
+                // (one tile in np carries the mask: a uniform branch, the other tiles keep the plain fma chain)
                 h0.to_rows(tbuf, lane);
-                accumulate(h0, 0);
+                if (diag) accumulate(h0, 0, std::true_type{}); else accumulate(h0, 0, std::false_type{});
                 h1.to_rows(tbuf, lane);
-                accumulate(h1, kPanel / 2);
+                if (diag) accumulate(h1, kPanel / 2, std::true_type{}); else accumulate(h1, kPanel / 2, std::false_type{});
             }
         } else {
             // row r0 + lane: columns [ws, we) at ld[base + c]
