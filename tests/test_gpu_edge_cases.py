@@ -554,3 +554,33 @@ def test_nonfinite_inputs_mixture_and_grid(gpu, model, low_memory, monkeypatch):
             S.clear_plan_cache()
     _assert_equal_with_nonfinite(got, ref)
     assert np.isnan(ref["q"][s[0]:s[1]]).any() and np.isfinite(ref["q"][s[2]:s[3]]).all()
+
+
+def test_kernel_time_does_not_depend_on_the_queue_depth(gpu):
+    """The HIP events that time a sweep bracket the kernel launch itself (`record_start_event`, adjacent to
+    hipLaunchKernel): a sweep submitted into an EMPTY stream -- where the start event is reached at once and anything the
+    host does before the launch would count as kernel time -- reports the same kernel time as sweeps submitted back to back.
+    (Round 5's driver run showed a 1.9 ms 'sweep' among ten of 0.38: host time inside the bracket; profiles/r06_stall.md.)"""
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld = syn.make_ld(syn.block_sizes("cfg2"), low_memory=True, kind="longrange")
+    inp = syn.make_inputs(syn.make_sumstats(ld))
+    plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)
+    st = DeviceState(plan, "float32", "spike_slab")
+    for k in ("std_beta", "u_logs", "sqrt_half_var_tau", "mu_mult"):
+        st.upload(k, getattr(inp, k))
+    for _ in range(30):
+        st.reset(inp.pi); st.e_step(ld.dq_scale, sync=False)
+    st.synchronize()
+    plan.timing_reset()
+    for _ in range(40):
+        st.reset(inp.pi); st.e_step(ld.dq_scale, sync=False)
+    st.synchronize()
+    full = np.median(plan.timing_history(which=1)[5:])
+    empty = []
+    for _ in range(40):
+        st.reset(inp.pi)
+        st.synchronize()
+        st.e_step(ld.dq_scale, sync=True)
+        empty.append(plan.last_kernel_ms(1))
+    assert abs(np.median(empty) / full - 1.0) < 0.05, (full, np.median(empty))
+    plan.close()

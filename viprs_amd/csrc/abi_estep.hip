@@ -133,14 +133,14 @@ int run_spike_slab(viprs_state* S, double dq) {
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
         if (!P->dense_h.empty()) {
-            HIP_TRY(hipEventRecord(ev[2], P->stream));
+            P->pending_start_event = ev[2];              // recorded by the launcher, adjacent to the kernel launch
             switch (P->ld_dtype) {
                 case VIPRS_LD_F32: rc = launch_panel<float>(P, A, kPanelSpikeSlab); break;
                 case VIPRS_LD_I8: rc = launch_panel<int8_t>(P, A, kPanelSpikeSlab); break;
                 case VIPRS_LD_I16: rc = launch_panel<int16_t>(P, A, kPanelSpikeSlab); break;
                 default: rc = fail(VIPRS_EINVAL, "dense schedule with unsupported LD dtype"); break;
             }
-            if (rc != VIPRS_OK) return rc;
+            if (rc != VIPRS_OK) { P->pending_start_event = nullptr; return rc; }
             HIP_TRY(hipEventRecord(ev[3], P->stream));
         }
         if (use_band(P)) rc = launch_band_u(P, A, kBandSpikeSlab);
@@ -205,7 +205,12 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
     P->math_used = 0;
     hipEvent_t* ev = P->ev.data() + 4 * (P->sweeps % viprs_plan::kRing);
     P->ev_dense_only[P->sweeps % viprs_plan::kRing] = true;      // [2] .. [3] bracket all kernels of the call
-    HIP_TRY(hipEventRecord(ev[2], P->stream));
+    {
+        // the panel and batched-grid launchers record the start event themselves, adjacent to their (first) kernel launch
+        const bool panel_ok0 = S->float_dtype == VIPRS_F32 && !P->dense_h.empty() && (model == kGenGrid || S->width <= kPanelWideMaxK);
+        if (panel_ok0) P->pending_start_event = ev[2];
+        else HIP_TRY(hipEventRecord(ev[2], P->stream));
+    }
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
         A.active = d_active;
@@ -241,7 +246,8 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         rc = launch_tile_f64_u(P, A, model, true);
         if (rc == VIPRS_OK) rc = launch_tile_f64_u(P, A, model, false);
     }
-    if (rc != VIPRS_OK) return rc;
+    if (rc != VIPRS_OK) { P->pending_start_event = nullptr; return rc; }
+    { const int rc2 = record_start_event(P); if (rc2 != VIPRS_OK) return rc2; }      // (never pending here; belt and braces)
     HIP_TRY(hipEventRecord(ev[3], P->stream));
     P->sweeps++;
     return VIPRS_OK;

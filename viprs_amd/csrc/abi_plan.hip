@@ -419,6 +419,13 @@ std::map<int, hipEvent_t> g_gate_event;        // per device: completion of the 
 std::map<int, const viprs_plan*> g_gate_plan;  // ... and the plan whose stream it went to (the same plan again: already
                                                //     ordered by its own stream; forgotten when that plan is destroyed)
 }  // namespace
+int record_start_event(viprs_plan* P) {
+    if (P->pending_start_event) {
+        HIP_TRY(hipEventRecord(P->pending_start_event, P->stream));
+        P->pending_start_event = nullptr;
+    }
+    return VIPRS_OK;
+}
 int team_launch_gate(viprs_plan* P) {
     std::lock_guard<std::mutex> lock(g_gate_mutex);
     auto it = g_gate_event.find(P->device);

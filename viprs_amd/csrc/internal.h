@@ -145,6 +145,10 @@ struct viprs_plan {
     bool ev_dense_only[kRing] = {};         // ring slot: only [2] .. [3] were recorded (they bracket the whole sweep)
     int64_t sweeps = 0;                     // sweeps recorded since the last timing reset
     viprs_state* scratch = nullptr;         // state used by the one-shot host-buffer calls
+    // start event of the sweep being enqueued, recorded by the panel / grid launcher IMMEDIATELY in front of its first kernel
+    // launch (record_start_event): with an empty stream the event is reached at once, and whatever the host does between the
+    // record and the launch -- occupancy query, team split, launch gate, a scheduler hiccup -- would count as kernel time
+    hipEvent_t pending_start_event = nullptr;
 
     ~viprs_plan();
 };
@@ -207,6 +211,7 @@ int plan_create_generated(viprs_plan** out, int64_t m, const int32_t* lb, const 
 // waits for the previous gated launch on this device, `team_launch_done` records this one.  (Other PROCESSES on the
 // same device cannot be ordered from here: the bounded spins report VIPRS_EDEVICE instead of hanging.)
 int ensure_upper_storage(viprs_plan* P, bool mirrored);
+int record_start_event(viprs_plan* P);
 int team_launch_gate(viprs_plan* P);
 int team_launch_done(viprs_plan* P);
 
