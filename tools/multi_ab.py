@@ -1,6 +1,6 @@
 """A/B/C... of several builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
     python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix [K=n]] [uniform] [fast] [sizes=a,b,..] [shard=N]
-(each library runs in its own subprocess, 3 rounds; LIB may carry environment switches: path,VIPRS_UPPER_MIRROR=0)"""
+(each library runs in its own subprocess, 3 rounds; LIB may carry environment switches: path,VIPRS_TEAM0=16)"""
 import os, subprocess, sys
 sep = sys.argv.index('--') if '--' in sys.argv else len(sys.argv)
 libs = sys.argv[1:sep]
