@@ -584,3 +584,25 @@ def test_kernel_time_does_not_depend_on_the_queue_depth(gpu):
         empty.append(plan.last_kernel_ms(1))
     assert abs(np.median(empty) / full - 1.0) < 0.05, (full, np.median(empty))
     plan.close()
+
+
+def test_state_destroyed_after_its_plan(gpu):
+    """Finalizers of a garbage collector run in any order: a `DeviceState` may be destroyed AFTER its `LDPlan` (the plan's
+    weak set of states is already cleared then).  `viprs_state_destroy` must not read the plan (it used to take the device
+    index from it: freed memory, `hipSetDevice(garbage)`, and "invalid device ordinal" left behind as the thread's last error
+    -- which the next plan creation reported as its own kernel launch failing: a once-in-three-runs failure of the suite)."""
+    import ctypes
+    from viprs_amd import _lib as L
+    from viprs_amd.plan import DeviceState, LDPlan
+    ld, ss, inp = syn.make_problem(sizes=[200, 90], low_memory=True, seed=5)
+    for _ in range(20):
+        plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)
+        st = DeviceState(plan, "float32", "spike_slab")
+        h_state, st._h = st._h, ctypes.c_void_p()          # detach: the plan's close() will not find the state
+        plan._states.discard(st)
+        plan.close()
+        junk = [np.full(4096, -1, dtype=np.int64) for _ in range(8)]      # (let the allocator reuse the plan's memory)
+        L.check(L.lib.viprs_state_destroy(h_state))
+        del junk
+        again = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, True)  # raised ViprsHipError: invalid device ordinal
+        again.close()

@@ -188,6 +188,9 @@ static int plan_create_impl(viprs_plan** out, int64_t m, const int32_t* lb, cons
     if (P->nnz > 0 && !ld_data && !ex && !fill) return fail(VIPRS_EINVAL, "ld_data is null");
 
     HIP_TRY(hipSetDevice(device));
+    // hipGetLastError() behind the launches below must report THOSE launches: an error left behind by an earlier, unchecked
+    // call of this thread (another library's, a finalizer's) is cleared here
+    (void)hipGetLastError();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     P->n_cu = prop.multiProcessorCount;

@@ -325,8 +325,10 @@ int viprs_state_create(viprs_state** out, viprs_plan* plan, int float_dtype, int
     if (model_kind == VIPRS_MODEL_SPIKE_SLAB) width = 1;
     if (width < 1) return fail(VIPRS_EINVAL, "width must be >= 1");
     HIP_TRY(hipSetDevice(plan->device));
+    (void)hipGetLastError();                 // (an error left behind by an earlier, unchecked call of this thread is not ours)
     std::unique_ptr<viprs_state> S(new viprs_state());
     S->plan = plan;
+    S->device = plan->device;
     S->float_dtype = float_dtype;
     S->model_kind = model_kind;
     S->width = width;
@@ -348,7 +350,10 @@ int viprs_state_create(viprs_state** out, viprs_plan* plan, int float_dtype, int
 
 int viprs_state_destroy(viprs_state* S) {
     if (!S) return VIPRS_OK;
-    (void)hipSetDevice(S->plan->device);
+    // (S->device, not S->plan->device: finalizers of a garbage collector run in any order, and a state destroyed after its
+    //  plan would read freed memory here -- hipSetDevice(garbage) then leaves "invalid device ordinal" as the thread's last
+    //  error, which the next hipGetLastError() behind a kernel launch reports as that launch's failure)
+    (void)hipSetDevice(S->device);
     delete S;
     return VIPRS_OK;
 }

@@ -155,6 +155,7 @@ struct viprs_plan {
 
 struct viprs_state {
     viprs_plan* plan = nullptr;
+    int device = 0;                         // (own copy: viprs_state_destroy must not read the plan -- a garbage collector may have destroyed it first)
     int float_dtype = VIPRS_F32;
     int model_kind = VIPRS_MODEL_SPIKE_SLAB;
     int width = 1;
