@@ -1,5 +1,5 @@
 """A/B/C... of several builds of the library on the same box, alternating, kernel ms p50 of 30 sweeps each:
-    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [grid|mix [K=n]] [uniform] [fast] [sizes=a,b,..] [shard=N]
+    python tools/multi_ab.py LIB_A LIB_B [LIB_C ...] -- [upper] [int8|int16] [f64] [grid|mix [K=n]] [uniform] [fast] [sizes=a,b,..] [shard=N]
 (each library runs in its own subprocess, 3 rounds; LIB may carry environment switches: path,VIPRS_TEAM0=16)"""
 import os, subprocess, sys
 sep = sys.argv.index('--') if '--' in sys.argv else len(sys.argv)
@@ -22,7 +22,9 @@ model = "grid" if "grid" in sys.argv else "mixture" if "mix" in sys.argv else "s
 width = {"grid": 32, "mixture": 4, "spike_slab": 1}[model]
 for a in sys.argv:
     if a.startswith("K="): width = int(a[2:])          # mix K=8: another number of components
-plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper, math_mode="fast" if "fast" in sys.argv else "exact"); ds = DeviceState(plan, "float32", model, width)
+plan = LDPlan(ld.ld_left_bound, ld.ld_indptr, ld.ld_data, upper, math_mode="fast" if "fast" in sys.argv else "exact"); ft = "float64" if "f64" in sys.argv else "float32"     # f64: float64 state (the tile kernels)
+ds = DeviceState(plan, ft, model, width)
+_up = ds.upload; ds.upload = lambda k, a: _up(k, np.asarray(a, dtype=ft, order="F" if (model == "grid" and np.ndim(a) == 2) else "C"))
 ds.upload("std_beta", inp.std_beta)
 active, pi0 = None, inp.pi
 if model == "spike_slab":
@@ -32,13 +34,14 @@ else:
     pi0 = extra.pop("pi")
     for k, a in extra.items(): ds.upload(k, a)
     if model == "grid": active = np.arange(width, dtype=np.int32)
+pi0 = np.asarray(pi0, dtype=ft) if np.ndim(pi0) else pi0
 for _ in range(5): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
 ds.synchronize(); plan.timing_reset()
 import time
 t0 = time.perf_counter()
 for _ in range(30): ds.reset(pi0); ds.e_step(ld.dq_scale, active, sync=False)
 ds.synchronize(); wall = (time.perf_counter() - t0) / 30 * 1e3
-t = np.array(plan.timing_history(which=1))
+t = np.array(plan.timing_history(which=0 if ft == 'float64' else 1))      # (float64: whole-sweep bracket)
 print("%.4f %.4f %.4f  wall ms/step %.4f" % (np.median(t), np.percentile(t, 10), np.percentile(t, 90), wall))
 '''
 for rnd in range(3):

@@ -777,6 +777,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         };
                         static_assert(kChainPrefetch == 16 && kPanel == 64, "window indexing");
                         float win[kChainPrefetch], rmm[kChainPrefetch], rsv[kChainPrefetch], rul[kChainPrefetch];
+                        float rvec = in.beta - qc;                         // lane j: beta_j - q_j, read by step j (:505)
                         const float* __restrict__ DtW = lT + (p & 1) * kPanel * kPanel + lane;    // kMixLds: the panel's diagonal tile in LDS
 #pragma unroll
                         for (int k = 0; k < kChainPrefetch; ++k) {
@@ -804,8 +805,8 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                                 rsv[k] = *cptr(A.shvt, jj + kChainPrefetch);
                                 rul[k] = *cptr(A.u_logs, jj + kChainPrefetch);
                             }
-                            const float qj = rl(qc, jj), lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
-                            const float r = rl(in.beta, jj) - qj;                              // :505
+                            const float lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
+                            const float r = rl(rvec, jj);                                      // :505, formed in lane jj (below)
                             const float mu = cmm * r;                                          // :509
                             const float t = csv * mu;
                             float u = __builtin_fmaf(t, t, cul);                               // :511
@@ -865,6 +866,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             //  valid q in qc from here on, theirs is captured at their own step)
                             if (MIR) q_own = me ? qc : q_own;
                             qc = __builtin_fmaf(drow_jj, a, qc);
+                            rvec = in.beta - qc;                                        // (as in the K <= 8 chain below)
                             if (!MIR) qc = (me && livej) ? qc - d : qc;                 // :527
                         }
                         }
@@ -909,6 +911,7 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                         // rounds -- a DPP operand needs two wait states behind the VALU write it reads, every round.
                         // K == 4 exactly (BASELINE configs[3]): no masking of the terms either.
                         constexpr bool K4 = decltype(k4_c)::value;
+                        float rvec = in.beta - qc;                         // lane j: beta_j - q_j, read by step j (:505)
                         // Rolled in 4 groups of kChainPrefetch = 16 steps (the fully unrolled mixture chain does
                         // not fit the instruction cache): the row consumed at step 16 g + k was loaded 16 steps
                         // earlier into the same register win[k]; the last group loads the first rows of the NEXT
@@ -937,8 +940,8 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             }
                             const int jn = (jj + 1 < kPanel) ? jj + 1 : jj;
                             const float nmm = Lmm[jn * K + kc], nsv = Lsv[jn * K + kc], nul = Lul[jn * K + kc];
-                            const float qj = rl(qc, jj), lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
-                            const float r = rl(in.beta, jj) - qj;                              // :505
+                            const float lnp = rl(in.lnp, jj), eta_old = rl(in.eta_old, jj);
+                            const float r = rl(rvec, jj);                                      // :505, formed in lane jj (below)
                             const float mu = cmm * r;                                          // :509
                             const float t = csv * mu;
                             float u = __builtin_fmaf(t, t, cul);                               // :511
@@ -1001,6 +1004,9 @@ __device__ __forceinline__ void panel_role(const EStepArgs<float>& A0, const int
                             //  valid q in qc from here on, theirs is captured at their own step)
                             if (MIR) q_own = me ? qc : q_own;
                             qc = __builtin_fmaf(drow_jj, a, qc);
+                            // what the NEXT step starts from, beta - q of lane jj + 1, before anything else is done to q: the
+                            // subtraction of the own term (lane jj only) stays off the path from a to the next step's mu
+                            rvec = in.beta - qc;
                             if (!MIR) qc = (me && livej) ? qc - d : qc;                 // :527
                             cmm = nmm; csv = nsv; cul = nul;
                         }
