@@ -637,24 +637,29 @@ def split_into_chromosomes(ld, ss):
     return ArrayDataLoader(lds, sss), sizes
 
 
-def measure_per_chromosome(ld, ss, device, iters=12, warm=3, math_mode="exact"):
+def measure_per_chromosome(ld, ss, device, iters=12, warm=3, math_mode="exact", mixture_k=0):
     """22 independent per-chromosome models (what `viprs_fit` runs unless --genomewide): ONE lock-step batch on one plan
     (`VIPRSPerChromosome`: per-group hyper-parameters and sums, one sweep per EM round) against the same 22 models fitted
     one after the other by `VIPRS` (one plan, one sweep, one reduction per chromosome per iteration).  ms per EM ROUND =
     one iteration of every chromosome's model; a fixed start (pi = 0.01, sigma_epsilon = 0.8), stopping rules held off
     (`min_iter`) so that every round updates all 22 models."""
-    from viprs_amd.model import VIPRS, VIPRSPerChromosome
+    from viprs_amd.model import VIPRS, VIPRSMix, VIPRSMixPerChromosome, VIPRSPerChromosome
     gdl, sizes = split_into_chromosomes(ld, ss)
     lm = bool(ld.low_memory)
     theta = {"pi": 0.01, "sigma_epsilon": 0.8}
+    batch_cls, one_cls, kw, what = VIPRSPerChromosome, VIPRS, {}, "models"
+    if mixture_k:               # (`mixture_k` = K: VIPRSMix per chromosome, `VIPRSMixPerChromosome` against K-component fits in turn)
+        theta = {"pis": 0.01 * np.array([0.4, 0.3, 0.2, 0.1])[:mixture_k] if mixture_k <= 4 else np.full(mixture_k, 0.01 / mixture_k),
+                 "sigma_epsilon": 0.8}
+        batch_cls, one_cls, kw, what = VIPRSMixPerChromosome, VIPRSMix, {"K": mixture_k}, f"VIPRSMix(K={mixture_k}) models"
     n_it = warm + iters
-    out = {"name": "22 per-chromosome models (the reference's default mode, bin/viprs_fit:232-238): lock-step batch vs one fit after the other",
+    out = {"name": f"22 per-chromosome {what} (the reference's default mode, bin/viprs_fit:232-238): lock-step batch vs one fit after the other",
            "unit": "ms per EM round (one iteration of all 22 models)", "iterations": iters, "warmup_iterations": warm,
            "math_mode": math_mode, "snps": int(ld.m), "low_memory": lm, "chromosomes": 22,
            "snps_per_chromosome": [int(np.sum(sizes[c])) for c in sorted(sizes)],
            "largest_block_per_chromosome": [int(np.max(sizes[c])) for c in sorted(sizes)]}
     stamps = []
-    model = VIPRSPerChromosome(gdl, low_memory=lm, device=device, math_mode=math_mode)
+    model = batch_cls(gdl, low_memory=lm, device=device, math_mode=math_mode, **kw)
     model.fit(max_iter=n_it, min_iter=n_it + 1, theta_0=dict(theta), on_iteration=lambda i: stamps.append(time.perf_counter()))
     d = np.diff(np.array(stamps))[warm - 1:]
     plan = model._plans["*"]
@@ -669,7 +674,7 @@ def measure_per_chromosome(ld, ss, device, iters=12, warm=3, math_mode="exact"):
     per_chrom, sweep_k, same = [], [], True
     for c, sub in gdl.split_by_chromosome().items():
         st = []
-        one = VIPRS(sub, low_memory=lm, device=device, math_mode=math_mode)
+        one = one_cls(sub, low_memory=lm, device=device, math_mode=math_mode, **kw)
         one.fit(max_iter=n_it, min_iter=n_it + 1, theta_0=dict(theta), on_iteration=lambda i: st.append(time.perf_counter()))
         dd = np.diff(np.array(st))[warm - 1:]
         per_chrom.append(float(np.median(dd)) * 1e3 if len(dd) else float("nan"))
@@ -995,6 +1000,7 @@ def main():
             if args.config == "cfg3":
                 # the reference's default operating mode: one model per chromosome -- 22 of them in one lock-step batch
                 secondary.append(measure_per_chromosome(ld, ss, device, math_mode=args.math))
+                secondary.append(measure_per_chromosome(ld, ss, device, math_mode=args.math, mixture_k=4, iters=8))
                 # BASELINE configs[0] and configs[1], each with the CPU baseline of its own workload
                 for cfg_small, cpu_s in (("cfg1", 2.0), ("cfg2", 6.0)):
                     secondary.append(measure_small_config(args, cfg_small, device, barrier, max(10, args.steps),

@@ -262,7 +262,7 @@ int viprs_state_reset_column(viprs_state* state, int g, double pi);
  * A chromosome-sized fit cannot fill the device (its sweep is bound by the chain of its largest LD block), 22 of them in
  * one plan cost one genome-wide sweep.  A GROUP is a contiguous SNP range made of whole LD blocks:
  *   viprs_state_set_groups        group g = SNPs [group_start[g], group_start[g+1]); n_groups + 1 entries covering 0 .. m;
- *                                 n_groups = 0 removes the groups.  Spike-and-slab states only.
+ *                                 n_groups = 0 removes the groups.  Spike-and-slab and mixture (K <= 8) states.
  *   viprs_state_prep_groups       viprs_state_prep with per-group scalars: n rows of 6 doubles
  *                                 (group, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda); only the listed
  *                                 groups' SNPs are rewritten (a converged group keeps the inputs of its last E-step).
@@ -276,6 +276,16 @@ int viprs_state_set_groups(viprs_state* state, int n_groups, const int64_t* grou
 int viprs_state_prep_groups(viprs_state* state, int n, const double* params);
 int viprs_state_sums_groups_begin(viprs_state* state, int n, const double* rows);
 int viprs_state_sums_groups_end(viprs_state* state, double* out);
+/* The same for a mixture state (one VIPRSMix model per chromosome; K = the state's width):
+ *   viprs_state_prep_mixture_groups       viprs_state_prep_mixture with per-group parameters: n rows of 4 + 3 K doubles
+ *                                         (group, log_null_pi, sigma_epsilon, one_plus_lambda, logit_pi[K], log_tau_beta[K],
+ *                                         tau_beta[K])
+ *   viprs_state_sums_mixture_groups_begin n rows of 2 doubles (group, one_plus_lambda)
+ *   viprs_state_sums_mixture_groups_end   n rows of 7 + 6 K doubles, the layout of viprs_state_sums_mixture_end
+ * viprs_state_set_log_var_tau takes the (m, K) array of all groups as before. */
+int viprs_state_prep_mixture_groups(viprs_state* state, int n, const double* params);
+int viprs_state_sums_mixture_groups_begin(viprs_state* state, int n, const double* rows);
+int viprs_state_sums_mixture_groups_end(viprs_state* state, double* out);
 
 /* ---- multi-GPU: RCCL over xGMI for the scalar reductions of the EM iteration -------------------------
  * One process per GPU; LD blocks are sharded over the ranks (independent units: within one E-step call

@@ -253,27 +253,34 @@ def per_chromosome_cases():
          dict(ld_kind="longrange", ld_dtype=np.int8), dict(n_of={20: 1e5, 21: 5e4, 22: 1e5}, h2_of={20: 0.2, 21: 0.3, 22: 0.08})),
         ("fitchr_ss_2chr_sym_fixed_sigma", {21: [260, 200], 22: [310]}, dict(low_memory=False, fix_params={"sigma_epsilon": 0.9}), {},
          dict(n_of={21: 1e5, 22: 6e4})),
+        # VIPRSMix per chromosome (the same fan-out, whatever the model class: bin/viprs_fit:1079-1086)
+        ("fitchr_mix_k4_3chr_upper", {20: [280, 160], 21: [350], 22: [200, 120, 90]}, dict(low_memory=True, K=4), {},
+         dict(n_of={20: 1e5, 21: 5e4, 22: 2e5}, h2_of={20: 0.25, 21: 0.1, 22: 0.15})),
     ]
+    from viprs.model.VIPRSMix import VIPRSMix
     for name, chrom_sizes, kw, ld_kw, data_kw in cases:
         if ONLY and name not in ONLY:
             continue
         ld_dtype, ld_kind = ld_kw.get("ld_dtype", np.float32), ld_kw.get("ld_kind", "ar1")
         gdl, inputs = make_loader(GWADataLoader, chrom_sizes, ld_dtype, seed=611, ld_kind=ld_kind, **data_kw)
         theta_0 = {"pi": 0.01, "sigma_epsilon": 0.8}
+        cls = VIPRS
+        if "K" in kw:                                   # no RNG: explicit mixing proportions
+            theta_0, cls = {"pis": 0.01 * np.array([0.4, 0.3, 0.2, 0.1]), "sigma_epsilon": 0.8}, VIPRSMix
         out = dict(ld_kind=ld_kind, dequantize_on_the_fly=bool(kw.get("dequantize_on_the_fly", False)),
                    float_precision=str(kw.get("float_precision", "float32")), theta0_pi=0.01, theta0_sigma_epsilon=0.8,
-                   low_memory=kw.get("low_memory", True), K=0,
+                   low_memory=kw.get("low_memory", True), K=kw.get("K", 0), theta0_pis=np.asarray(theta_0.get("pis", [])),
                    fix_sigma_epsilon=kw.get("fix_params", {}).get("sigma_epsilon", np.nan), chroms=np.array(sorted(chrom_sizes)))
         for c in sorted(chrom_sizes):
-            model = VIPRS(sub_loader(GWADataLoader, gdl, c), **{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
+            model = cls(sub_loader(GWADataLoader, gdl, c), **{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
             model.fit(max_iter=100, theta_0=dict(theta_0), disable_pbar=True)
             model.validation_std_beta = {c: inputs[c][2].validation_std_beta}
             ld_sym, ld_up, ss = inputs[c]
             out.update({
                 f"n_{c}": model.n, f"elbo_history_{c}": np.array(model.history["ELBO"], dtype=np.float64),
                 f"nit_{c}": model.optim_result.nit, f"success_{c}": bool(model.optim_result.success),
-                f"message_{c}": str(model.optim_result.message), f"final_pi_{c}": np.float64(model.pi),
-                f"final_tau_beta_{c}": np.float64(model.tau_beta), f"final_sigma_epsilon_{c}": np.float64(model.sigma_epsilon),
+                f"message_{c}": str(model.optim_result.message), f"final_pi_{c}": np.asarray(model.pi, dtype=np.float64),
+                f"final_tau_beta_{c}": np.asarray(model.tau_beta, dtype=np.float64), f"final_sigma_epsilon_{c}": np.float64(model.sigma_epsilon),
                 f"final_sigma_g_{c}": np.float64(model._sigma_g), f"pseudo_r2_{c}": np.float64(model.pseudo_validate()),
                 f"sizes_{c}": np.array(chrom_sizes[c]), f"std_beta_{c}": ss.std_beta, f"n_per_snp_{c}": ss.n_per_snp,
                 f"rho_{c}": ld_sym.rho, f"validation_std_beta_{c}": ss.validation_std_beta, f"pip_{c}": model.pip[c],

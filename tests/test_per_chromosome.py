@@ -17,7 +17,7 @@ from tests.test_fit import loader_from_fixture
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-FITCHR = sorted(glob.glob(os.path.join(HERE, "golden", "fitchr_*.npz")))
+FITCHR = sorted(glob.glob(os.path.join(HERE, "golden", "fitchr_ss_*.npz")))      # (fitchr_mix_*: tests/test_per_chromosome_mix.py)
 IDS = [os.path.basename(p)[:-4] for p in FITCHR]
 FX4 = os.path.join(HERE, "golden", "fitchr_ss_4chr_upper.npz")     # four chromosomes, free sigma_epsilon
 

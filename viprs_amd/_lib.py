@@ -97,6 +97,9 @@ _PROTOS = {
     "viprs_state_prep_groups": (_i, [_vp, _i, _vp]),
     "viprs_state_sums_groups_begin": (_i, [_vp, _i, _vp]),
     "viprs_state_sums_groups_end": (_i, [_vp, _vp]),
+    "viprs_state_prep_mixture_groups": (_i, [_vp, _i, _vp]),
+    "viprs_state_sums_mixture_groups_begin": (_i, [_vp, _i, _vp]),
+    "viprs_state_sums_mixture_groups_end": (_i, [_vp, _vp]),
     "viprs_comm_unique_id": (_i, [_vp]),
     "viprs_comm_create": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
     "viprs_comm_destroy": (_i, [_vp]),

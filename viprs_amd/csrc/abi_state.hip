@@ -228,21 +228,22 @@ __global__ void prep_mixture_kernel(const double* __restrict__ n, int64_t m, int
     }
 }
 
-// VIPRSMix._partial_sums on the device (float64): per-workgroup partials, fixed order
+// VIPRSMix._partial_sums on the device (float64): per-workgroup partials, fixed order.  `sums_mixture_body`: workgroup `bx`
+// of `nb` over SNPs [i0, i1) -- a plan's SNPs, or one SNP group of it reduced exactly as a plan of its own would be.
 template <typename T>
-__global__ __launch_bounds__(kSumsBlock) void sums_mixture_kernel(int64_t m, int K, const T* __restrict__ gam,
-                                                                  const T* __restrict__ mu, const T* __restrict__ eta,
-                                                                  const T* __restrict__ q, const T* __restrict__ ed,
-                                                                  const T* __restrict__ beta, const double* __restrict__ var_tau,
-                                                                  const double* __restrict__ log_var_tau0, double one_plus_lambda,
-                                                                  double* __restrict__ partials) {
+__device__ __forceinline__ void sums_mixture_body(int64_t i0, int64_t i1, int nb, int bx, int K, const T* __restrict__ gam,
+                                                  const T* __restrict__ mu, const T* __restrict__ eta,
+                                                  const T* __restrict__ q, const T* __restrict__ ed,
+                                                  const T* __restrict__ beta, const double* __restrict__ var_tau,
+                                                  const double* __restrict__ log_var_tau0, double one_plus_lambda,
+                                                  double* __restrict__ partials) {
     constexpr int NMAX = kMixSums(kMixResidentK);
     const int N = kMixSums(K);
     double acc[NMAX];
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) acc[k] = 0.0;
     const double lo = 1e-15, hi = 1.0 - 1e-15;
-    for (int64_t i = (int64_t)blockIdx.x * kSumsBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kSumsBlock) {
+    for (int64_t i = i0 + (int64_t)bx * kSumsBlock + threadIdx.x; i < i1; i += (int64_t)nb * kSumsBlock) {
         double zeta = 0.0, gsum = 0.0;
 #pragma unroll
         for (int k = 0; k < kMixResidentK; ++k) {
@@ -291,7 +292,60 @@ __global__ __launch_bounds__(kSumsBlock) void sums_mixture_kernel(int64_t m, int
         else src = 6 + ((nidx - 6) / K) * kMixResidentK + (nidx - 6) % K;
         double a = red[src][0];
         for (int w = 1; w < kSumsBlock / 64; ++w) a = (src == NMAX - 1) ? fmax(a, red[src][w]) : a + red[src][w];
-        partials[(int64_t)blockIdx.x * N + nidx] = a;
+        partials[nidx] = a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSumsBlock) void sums_mixture_kernel(int64_t m, int K, const T* __restrict__ gam,
+                                                                  const T* __restrict__ mu, const T* __restrict__ eta,
+                                                                  const T* __restrict__ q, const T* __restrict__ ed,
+                                                                  const T* __restrict__ beta, const double* __restrict__ var_tau,
+                                                                  const double* __restrict__ log_var_tau0, double one_plus_lambda,
+                                                                  double* __restrict__ partials) {
+    sums_mixture_body<T>(0, m, (int)gridDim.x, (int)blockIdx.x, K, gam, mu, eta, q, ed, beta, var_tau, log_var_tau0, one_plus_lambda,
+                         partials + (int64_t)blockIdx.x * kMixSums(K));
+}
+
+// SNP groups of a mixture state (one model per chromosome in one plan): blockIdx.y picks a row (group, one_plus_lambda)
+template <typename T>
+__global__ __launch_bounds__(kSumsBlock) void sums_mixture_groups_kernel(const int64_t* __restrict__ gstart, const double* __restrict__ rows,
+                                                                         int K, const T* __restrict__ gam, const T* __restrict__ mu,
+                                                                         const T* __restrict__ eta, const T* __restrict__ q,
+                                                                         const T* __restrict__ ed, const T* __restrict__ beta,
+                                                                         const double* __restrict__ var_tau,
+                                                                         const double* __restrict__ log_var_tau0,
+                                                                         double* __restrict__ partials) {
+    const int g = (int)rows[2 * blockIdx.y];
+    const int64_t i0 = gstart[g], i1 = gstart[g + 1];
+    const int nb = sums_blocks(i1 - i0);
+    if ((int)blockIdx.x >= nb) return;
+    sums_mixture_body<T>(i0, i1, nb, (int)blockIdx.x, K, gam, mu, eta, q, ed, beta, var_tau, log_var_tau0, rows[2 * blockIdx.y + 1],
+                         partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kMixSums(K));
+}
+
+// per-SNP inputs of the groups listed in `params`: rows of 4 + 3 K doubles (group, log_null_pi, sigma_eps, one_plus_lambda,
+// logit_pi[K], log_tau_beta[K], tau_beta[K]); blockIdx.y picks the row, only the group's SNPs are written
+template <typename T>
+__global__ void prep_mixture_groups_kernel(const double* __restrict__ n, const int64_t* __restrict__ gstart, int K,
+                                           const double* __restrict__ params, T* __restrict__ mu_mult, T* __restrict__ u_logs,
+                                           T* __restrict__ shvt, T* __restrict__ lnp, double* __restrict__ var_tau_out) {
+    const double* __restrict__ p = params + (int64_t)(4 + 3 * K) * blockIdx.y;
+    const int g = (int)p[0];
+    const double log_null_pi = p[1], sigma_eps = p[2], one_plus_lambda = p[3];
+    const double* __restrict__ logit_pi = p + 4;
+    const double* __restrict__ log_tau = p + 4 + K;
+    const double* __restrict__ tau = p + 4 + 2 * K;
+    const int64_t end = gstart[g + 1];
+    for (int64_t i = gstart[g] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (int64_t)gridDim.x * blockDim.x) {
+        lnp[i] = (T)log_null_pi;
+        for (int k = 0; k < K; ++k) {
+            const double vt = n[i] * one_plus_lambda / sigma_eps + tau[k];
+            var_tau_out[i * K + k] = vt;
+            mu_mult[i * K + k] = (T)(n[i] / (vt * sigma_eps));
+            u_logs[i * K + k] = (T)(logit_pi[k] + 0.5 * (log_tau[k] - log(vt)));
+            shvt[i * K + k] = (T)sqrt(0.5 * vt);
+        }
     }
 }
 
@@ -311,6 +365,28 @@ __global__ void sums_final_generic_kernel(const double* __restrict__ partials, i
     }
     if (lane == 0) out[k] = a;
 }
+
+// the same per group: workgroup (k, y) adds the sums_blocks(group's SNPs) partials of sum k of row y (`stride` slots per row)
+__global__ void sums_final_generic_groups_kernel(const double* __restrict__ partials, int stride, int n_sums,
+                                                 const int64_t* __restrict__ gstart, const double* __restrict__ rows,
+                                                 double* __restrict__ out) {
+    const int g = (int)rows[2 * blockIdx.y];
+    const int n_blocks = sums_blocks(gstart[g + 1] - gstart[g]);
+    partials += (int64_t)blockIdx.y * stride * n_sums;
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const bool is_max = (k == n_sums - 1);
+    double a = 0.0;
+    for (int b = lane; b < n_blocks; b += 64) {
+        const double v = partials[(int64_t)b * n_sums + k];
+        a = is_max ? fmax(a, v) : a + v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(a, off, 64);
+        a = is_max ? fmax(a, o) : a + o;
+    }
+    if (lane == 0) out[(int64_t)blockIdx.y * n_sums + k] = a;
+}
+
 
 }  // namespace
 
@@ -896,11 +972,19 @@ int viprs_state_reset_column(viprs_state* S, int g, double pi) {
 }
 
 
-// ---- SNP groups: one spike-and-slab model per chromosome, all of them in ONE plan / state (bin/viprs_fit:232-238 fits one
+// doubles per row of the groups' prep parameters (viprs_state_prep_groups / viprs_state_prep_mixture_groups)
+static size_t group_prep_width(const viprs_state* S) {
+    return S->model_kind == VIPRS_MODEL_MIXTURE ? (size_t)4 + 3 * (size_t)S->width : 6;
+}
+
+// ---- SNP groups: one spike-and-slab (or mixture) model per chromosome, all of them in ONE plan / state (bin/viprs_fit:232-238 fits one
 // model per chromosome unless --genomewide; the chromosomes' LD blocks are independent, so their E-steps share one sweep)
 int viprs_state_set_groups(viprs_state* S, int n_groups, const int64_t* group_start) {
     if (!S) return fail(VIPRS_EINVAL, "null state");
-    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EUNSUPPORTED, "SNP groups: spike-and-slab states only");
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB && S->model_kind != VIPRS_MODEL_MIXTURE)
+        return fail(VIPRS_EUNSUPPORTED, "SNP groups: spike-and-slab and mixture states only");
+    if (S->model_kind == VIPRS_MODEL_MIXTURE && S->width > kMixResidentK)
+        return fail(VIPRS_EUNSUPPORTED, "device-resident mixture iteration: K <= 8");
     viprs_plan* P = S->plan;
     if (n_groups == 0) {                         // back to one set of hyper-parameters
         S->n_groups = 0;
@@ -924,10 +1008,11 @@ int viprs_state_set_groups(viprs_state* S, int n_groups, const int64_t* group_st
     for (int g = 0; g < n_groups; ++g) S->group_max_nb = std::max(S->group_max_nb, sums_blocks(group_start[g + 1] - group_start[g]));
     HIP_TRY(S->d_group_start.alloc((size_t)n_groups + 1));
     HIP_TRY(hipMemcpy(S->d_group_start.p, group_start, sizeof(int64_t) * ((size_t)n_groups + 1), hipMemcpyHostToDevice));
-    HIP_TRY(S->d_group_prep.alloc((size_t)6 * n_groups));
+    const size_t pw = group_prep_width(S);
+    HIP_TRY(S->d_group_prep.alloc(pw * n_groups));
     HIP_TRY(S->d_group_sumrows.alloc((size_t)2 * n_groups));
     if (S->h_gparams) { HIP_TRY(hipHostFree(S->h_gparams)); S->h_gparams = nullptr; }
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_gparams), (size_t)8 * n_groups * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_gparams), (pw + 2) * n_groups * sizeof(double), hipHostMallocDefault));
     return VIPRS_OK;
 }
 
@@ -945,6 +1030,7 @@ static int group_rows_check(const viprs_state* S, int n, const double* rows, int
 int viprs_state_prep_groups(viprs_state* S, int n, const double* params) {
     int rc = group_rows_check(S, n, params, 6);
     if (rc != VIPRS_OK) return rc;
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EINVAL, "not a spike-and-slab state (viprs_state_prep_mixture_groups)");
     viprs_plan* P = S->plan;
     if (P->m == 0 || n == 0) return VIPRS_OK;
     if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
@@ -1011,6 +1097,7 @@ extern "C" {
 int viprs_state_sums_groups_begin(viprs_state* S, int n, const double* rows) {
     int rc = group_rows_check(S, n, rows, 2);
     if (rc != VIPRS_OK) return rc;
+    if (S->model_kind != VIPRS_MODEL_SPIKE_SLAB) return fail(VIPRS_EINVAL, "not a spike-and-slab state (viprs_state_sums_mixture_groups_begin)");
     viprs_plan* P = S->plan;
     S->sums_cols = n;
     if (P->m == 0 && n > 0 && S->comm) return sums_enqueue_empty(S, kNSums * n, kNSums);
@@ -1019,7 +1106,7 @@ int viprs_state_sums_groups_begin(viprs_state* S, int n, const double* rows) {
     if (!S->d_var_tau.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp / viprs_state_prep_groups have not been called");
     HIP_TRY(hipSetDevice(P->device));
     // (own half of the pinned staging: the previous reduction that read it has been collected)
-    double* h = S->h_gparams + (size_t)6 * S->n_groups;
+    double* h = S->h_gparams + group_prep_width(S) * S->n_groups;
     memcpy(h, rows, (size_t)2 * n * sizeof(double));
     HIP_TRY(hipMemcpyAsync(S->d_group_sumrows.p, h, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
     return S->float_dtype == VIPRS_F32 ? sums_groups_enqueue<float>(S, n) : sums_groups_enqueue<double>(S, n);
@@ -1028,6 +1115,123 @@ int viprs_state_sums_groups_begin(viprs_state* S, int n, const double* rows) {
 int viprs_state_sums_groups_end(viprs_state* S, double* out) {
     if (S && S->n_groups == 0) return fail(VIPRS_EINVAL, "viprs_state_set_groups has not been called");
     return viprs_state_sums_columns_end(S, out);          // same landing buffer and bookkeeping: sums_cols rows of VIPRS_N_SUMS
+}
+
+// ---- the same for a mixture state (VIPRSMix per chromosome) ----
+int viprs_state_prep_mixture_groups(viprs_state* S, int n, const double* params) {
+    if (!S) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    const int K = S->width, W = 4 + 3 * K;
+    int rc = group_rows_check(S, n, params, W);
+    if (rc != VIPRS_OK) return rc;
+    viprs_plan* P = S->plan;
+    if (P->m == 0 || n == 0) return VIPRS_OK;
+    if (!S->d_n.p) return fail(VIPRS_EINVAL, "viprs_state_set_n_per_snp has not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    if (S->d_var_tau.n < (size_t)P->m * K) {
+        HIP_TRY(hipStreamSynchronize(P->stream));
+        HIP_TRY(S->d_var_tau.alloc((size_t)P->m * K));
+    }
+    if (!S->ev_prep) HIP_TRY(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(S->ev_prep));            // the previous launch has read its parameters
+    memcpy(S->h_gparams, params, (size_t)W * n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(S->d_group_prep.p, S->h_gparams, (size_t)W * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    int64_t longest = 0;
+    for (int i = 0; i < n; ++i) {
+        const int g = (int)params[(size_t)W * i];
+        longest = std::max(longest, S->group_start[(size_t)g + 1] - S->group_start[(size_t)g]);
+    }
+    const dim3 grid((unsigned)std::max<int64_t>(1, (longest + 255) / 256), (unsigned)n);
+    if (S->float_dtype == VIPRS_F32)
+        prep_mixture_groups_kernel<float><<<grid, 256, 0, P->stream>>>(
+            S->d_n.p, S->d_group_start.p, K, S->d_group_prep.p, (float*)S->f[VIPRS_FIELD_MU_MULT].p,
+            (float*)S->f[VIPRS_FIELD_U_LOGS].p, (float*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p,
+            (float*)S->f[VIPRS_FIELD_LOG_NULL_PI].p, S->d_var_tau.p);
+    else
+        prep_mixture_groups_kernel<double><<<grid, 256, 0, P->stream>>>(
+            S->d_n.p, S->d_group_start.p, K, S->d_group_prep.p, (double*)S->f[VIPRS_FIELD_MU_MULT].p,
+            (double*)S->f[VIPRS_FIELD_U_LOGS].p, (double*)S->f[VIPRS_FIELD_SQRT_HALF_VAR_TAU].p,
+            (double*)S->f[VIPRS_FIELD_LOG_NULL_PI].p, S->d_var_tau.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(S->ev_prep, P->stream));
+    return VIPRS_OK;
+}
+
+}  // extern "C"
+
+template <typename T>
+static int sums_mixture_groups_enqueue(viprs_state* S, int n) {
+    viprs_plan* P = S->plan;
+    const int K = S->width, N = kMixSums(K), nb = S->group_max_nb;
+    const size_t need = (size_t)nb * N * n;
+    if (S->d_partials.n < need) HIP_TRY(S->d_partials.alloc(need));
+    if (S->d_sums.n < (size_t)N * S->n_groups) HIP_TRY(S->d_sums.alloc((size_t)N * S->n_groups));
+    const size_t hcap = (size_t)N * S->n_groups + 1;
+    if (S->h_sums_cap < hcap) {
+        if (S->h_sums) HIP_TRY(hipHostFree(S->h_sums));
+        S->h_sums = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_sums), hcap * sizeof(double), hipHostMallocDefault));
+        S->h_sums_cap = hcap;
+    }
+    sums_mixture_groups_kernel<T><<<dim3(nb, n), kSumsBlock, 0, P->stream>>>(
+        S->d_group_start.p, S->d_group_sumrows.p, K, (const T*)S->f[VIPRS_FIELD_VAR_GAMMA].p, (const T*)S->f[VIPRS_FIELD_VAR_MU].p,
+        (const T*)S->f[VIPRS_FIELD_ETA].p, (const T*)S->f[VIPRS_FIELD_Q].p, (const T*)S->f[VIPRS_FIELD_ETA_DIFF].p,
+        (const T*)S->f[VIPRS_FIELD_STD_BETA].p, S->d_var_tau.p, S->d_log_var_tau0.p, S->d_partials.p);
+    HIP_TRY(hipGetLastError());
+    sums_final_generic_groups_kernel<<<dim3(N, n), 64, 0, P->stream>>>(S->d_partials.p, nb, N, S->d_group_start.p,
+                                                                      S->d_group_sumrows.p, S->d_sums.p);
+    HIP_TRY(hipGetLastError());
+    if (S->comm) {
+        const int rc = comm_reduce_on_stream(S->comm, S->d_sums.p, N * n, N, P->stream);
+        if (rc != VIPRS_OK) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(S->h_sums, S->d_sums.p, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost, P->stream));
+    HIP_TRY(hipMemcpyAsync(S->h_sums + (size_t)N * n, P->d_error.p, sizeof(int32_t), hipMemcpyDeviceToHost, P->stream));
+    S->sums_cols = n;
+    S->sums_pending = true;
+    return VIPRS_OK;
+}
+
+extern "C" {
+
+int viprs_state_sums_mixture_groups_begin(viprs_state* S, int n, const double* rows) {
+    if (!S) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    int rc = group_rows_check(S, n, rows, 2);
+    if (rc != VIPRS_OK) return rc;
+    viprs_plan* P = S->plan;
+    const int N = kMixSums(S->width);
+    S->sums_cols = n;
+    if (P->m == 0 && n > 0 && S->comm) return sums_enqueue_empty(S, N * n, N);
+    if (P->m == 0 || n == 0) { S->sums_pending = false; S->sums_empty = true; return VIPRS_OK; }
+    S->sums_empty = false;
+    if (S->d_var_tau.n < (size_t)P->m * S->width || !S->d_log_var_tau0.p)
+        return fail(VIPRS_EINVAL, "viprs_state_prep_mixture_groups / viprs_state_set_log_var_tau have not been called");
+    HIP_TRY(hipSetDevice(P->device));
+    double* h = S->h_gparams + group_prep_width(S) * S->n_groups;
+    memcpy(h, rows, (size_t)2 * n * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(S->d_group_sumrows.p, h, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, P->stream));
+    return S->float_dtype == VIPRS_F32 ? sums_mixture_groups_enqueue<float>(S, n) : sums_mixture_groups_enqueue<double>(S, n);
+}
+
+int viprs_state_sums_mixture_groups_end(viprs_state* S, double* out) {
+    if (!S || !out) return fail(VIPRS_EINVAL, "null argument");
+    if (S->model_kind != VIPRS_MODEL_MIXTURE) return fail(VIPRS_EINVAL, "not a mixture state");
+    if (S->n_groups == 0) return fail(VIPRS_EINVAL, "viprs_state_set_groups has not been called");
+    const size_t total = (size_t)kMixSums(S->width) * S->sums_cols;
+    if (S->sums_empty) {
+        for (size_t k = 0; k < total; ++k) out[k] = 0.0;
+        return VIPRS_OK;
+    }
+    if (!S->sums_pending) return fail(VIPRS_EINVAL, "no device sums in flight (viprs_state_sums_mixture_groups_begin)");
+    viprs_plan* P = S->plan;
+    HIP_TRY(hipSetDevice(P->device));
+    HIP_TRY(hipStreamSynchronize(P->stream));
+    S->sums_pending = false;
+    for (size_t k = 0; k < total; ++k) out[k] = S->h_sums[k];
+    int32_t e = 0;
+    memcpy(&e, S->h_sums + total, sizeof(e));
+    return e != 0 ? check_device_error(P) : VIPRS_OK;
 }
 
 }  // extern "C"

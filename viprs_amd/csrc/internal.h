@@ -172,8 +172,8 @@ struct viprs_state {
     int n_groups = 0, group_max_nb = 0;
     std::vector<int64_t> group_start;              // n_groups + 1 entries
     viprs::DevBuf<int64_t> d_group_start;
-    viprs::DevBuf<double> d_group_prep, d_group_sumrows;   // per-launch parameter rows (6 / 2 doubles per listed group)
-    double* h_gparams = nullptr;                   // pinned staging of both (8 x n_groups)
+    viprs::DevBuf<double> d_group_prep, d_group_sumrows;   // per-launch parameter rows (6, mixture: 4 + 3 K / 2 doubles per listed group)
+    double* h_gparams = nullptr;                   // pinned staging of both
     size_t h_sums_cap = 0;
     double* h_sums = nullptr;               // pinned landing buffer of the device sums
     bool sums_pending = false, sums_empty = false;

@@ -18,6 +18,8 @@ package itself.)
 """
 import logging
 
+from types import SimpleNamespace
+
 import numpy as np
 
 from ..parallel import BlockShard, LocalComm, broadcast_from_root, shard_blocks
@@ -756,6 +758,57 @@ class VIPRS:
                 self.sync_host()
                 self.history[t.__name__].append(t(self))
 
+    # ---- one EM iteration behind its E-step (VIPRS.py:995-1094) -------------------------------------------
+    def _new_fit_progress(self, prev_elbo=-np.inf):
+        """What the stopping rules carry from one iteration to the next."""
+        return SimpleNamespace(prev_elbo=prev_elbo, prev_sigma_g=self._sigma_g, plateau=ConditionStreak(),
+                               dropping=ConditionStreak())
+
+    def _restart_state(self, theta_0, param_0):
+        self.initialize_theta(theta_0)
+        self.initialize_variational_parameters(param_0)
+
+    def _after_e_step(self, i, st, theta_0, param_0, min_iter, f_abs_tol, x_abs_tol, patience):
+        """M-step, history and the stopping rules of iteration `i`; the outcome goes to `self.optim_result`."""
+        res = self.optim_result
+        self.m_step()
+        self.update_theta_history()
+        max_eta_diff = self._max_eta_diff                                              # :997
+        elbo = self.history["ELBO"][-1]
+        prev_elbo = st.prev_elbo
+        st.plateau.update((i > min_iter) and np.isclose(self._sigma_g, st.prev_sigma_g, atol=x_abs_tol, rtol=0.0)
+                          and max_eta_diff < x_abs_tol * 10, i)                        # :1003-1008
+        st.dropping.update((elbo < prev_elbo) and not np.isclose(elbo, prev_elbo, atol=1e3 * f_abs_tol, rtol=1e-4), i)
+
+        stop = None                                                                    # (success, message)
+        if self.mse() < 0.0:                                                           # :1025-1044
+            if "sigma_epsilon" not in self.fix_params:
+                logger.info("Iteration %d | MSE is negative; restarting with sigma_epsilon fixed.", i)
+                self._restart_state(theta_0, param_0)
+                self.fix_params["sigma_epsilon"] = self.sigma_epsilon = 0.95
+                return
+            stop = (False, f"The MSE is negative ({self.mse():.6f}).")
+        elif not np.isfinite(elbo):
+            stop = (False, "Objective (ELBO) is undefined.")
+        elif self.sigma_epsilon < 0.0:
+            stop = (False, "Residual variance estimate is negative.")
+        elif self.get_heritability() > 1.0 or self.get_heritability() < 0.0:
+            stop = (False, "Estimated heritability is out of bounds.")
+        elif (i > min_iter) and np.isclose(prev_elbo, elbo, atol=f_abs_tol, rtol=0.0):
+            stop = (True, "Objective (ELBO) converged successfully.")
+        elif (i > min_iter) and max_eta_diff < x_abs_tol:
+            stop = (True, "Variational parameters converged successfully.")
+        elif st.plateau.counter > patience:
+            stop = (True, "LD-weighted variational parameters converged successfully.")
+        elif st.dropping.counter > patience:
+            stop = (False, "The objective (ELBO) is decreasing.")
+
+        if stop is None:
+            res.update(elbo)
+        else:
+            res.update(elbo, stop_iteration=True, success=stop[0], message=stop[1])
+        st.prev_elbo, st.prev_sigma_g = elbo, self._sigma_g
+
     # ---- EM loop (VIPRS.py:909-1124): same stopping rules, evaluated on the reduced sums ------------
     def fit(self, max_iter=1000, theta_0=None, param_0=None, continued=False, disable_pbar=True, min_iter=3,
             f_abs_tol=1e-6, x_abs_tol=1e-6, patience=10, on_iteration=None, **kwargs):
@@ -770,53 +823,14 @@ class VIPRS:
             self._reduce()
             self.optim_result.update(self.elbo(), increment=False)
             prev_elbo = self.elbo()
-        prev_sigma_g = self._sigma_g
-        plateau, dropping = ConditionStreak(), ConditionStreak()
+        st = self._new_fit_progress(prev_elbo)
         res = self.optim_result
 
         for i in range(first, first + max_iter):
             if res.stop_iteration:
                 break
             self.e_step()
-            self.m_step()
-            self.update_theta_history()
-            max_eta_diff = self._max_eta_diff                                          # :997
-            elbo = self.history["ELBO"][-1]
-            plateau.update((i > min_iter) and np.isclose(self._sigma_g, prev_sigma_g, atol=x_abs_tol, rtol=0.0)
-                           and max_eta_diff < x_abs_tol * 10, i)                       # :1003-1008
-            dropping.update((elbo < prev_elbo) and not np.isclose(elbo, prev_elbo, atol=1e3 * f_abs_tol, rtol=1e-4), i)
-
-            stop = None                                                                # (success, message)
-            if self.mse() < 0.0:                                                       # :1025-1044
-                if "sigma_epsilon" not in self.fix_params:
-                    logger.info("Iteration %d | MSE is negative; restarting with sigma_epsilon fixed.", i)
-                    self.initialize_theta(theta_0)
-                    self.initialize_variational_parameters(param_0)
-                    self.fix_params["sigma_epsilon"] = self.sigma_epsilon = 0.95
-                    if on_iteration is not None:
-                        on_iteration(i)
-                    continue
-                stop = (False, f"The MSE is negative ({self.mse():.6f}).")
-            elif not np.isfinite(elbo):
-                stop = (False, "Objective (ELBO) is undefined.")
-            elif self.sigma_epsilon < 0.0:
-                stop = (False, "Residual variance estimate is negative.")
-            elif self.get_heritability() > 1.0 or self.get_heritability() < 0.0:
-                stop = (False, "Estimated heritability is out of bounds.")
-            elif (i > min_iter) and np.isclose(prev_elbo, elbo, atol=f_abs_tol, rtol=0.0):
-                stop = (True, "Objective (ELBO) converged successfully.")
-            elif (i > min_iter) and max_eta_diff < x_abs_tol:
-                stop = (True, "Variational parameters converged successfully.")
-            elif plateau.counter > patience:
-                stop = (True, "LD-weighted variational parameters converged successfully.")
-            elif dropping.counter > patience:
-                stop = (False, "The objective (ELBO) is decreasing.")
-
-            if stop is None:
-                res.update(elbo)
-            else:
-                res.update(elbo, stop_iteration=True, success=stop[0], message=stop[1])
-            prev_elbo, prev_sigma_g = elbo, self._sigma_g
+            self._after_e_step(i, st, theta_0, param_0, min_iter, f_abs_tol, x_abs_tol, patience)
             if on_iteration is not None:
                 on_iteration(i)
 

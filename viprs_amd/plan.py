@@ -513,6 +513,25 @@ class DeviceState:
         L.check(L.lib.viprs_state_sums_groups_end(self._h, _ptr(out)))
         return out
 
+    def prep_mixture_groups(self, params):
+        """`prep_mixture` with per-group parameters: rows (group, log_null_pi, sigma_epsilon, one_plus_lambda, logit_pi[K],
+        log_tau_beta[K], tau_beta[K])."""
+        p = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, 4 + 3 * self.width)
+        L.check(L.lib.viprs_state_prep_mixture_groups(self._h, int(p.shape[0]), _ptr(p)))
+
+    def sums_mixture_groups_begin(self, groups, one_plus_lambda):
+        r = np.ascontiguousarray(np.column_stack([np.asarray(groups, dtype=np.float64),
+                                                  np.broadcast_to(np.asarray(one_plus_lambda, dtype=np.float64),
+                                                                  (len(groups),))]))
+        self._n_sum_cols = int(r.shape[0])
+        L.check(L.lib.viprs_state_sums_mixture_groups_begin(self._h, self._n_sum_cols, _ptr(r)))
+
+    def sums_mixture_groups_end(self):
+        """(n, 7 + 6 K) rows in the layout of `sums_mixture_end`."""
+        out = np.zeros((self._n_sum_cols, 7 + 6 * self.width), dtype=np.float64)
+        L.check(L.lib.viprs_state_sums_mixture_groups_end(self._h, _ptr(out)))
+        return out
+
     # -- one model (column) of a grid state -----------------------------------------------------
     def prep_column(self, g, logit_pi, log_tau_beta, sigma_epsilon, tau_beta, one_plus_lambda):
         L.check(L.lib.viprs_state_prep_column(self._h, int(g), float(logit_pi), float(log_tau_beta),
