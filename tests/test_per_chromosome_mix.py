@@ -237,6 +237,24 @@ def test_mixture_group_prep_and_sums_equal_a_plan_per_chromosome(gpu, ftype):
     # a subset of the groups, in the order asked for
     st.sums_mixture_groups_begin(np.array([2, 0]), 1.0)
     assert np.array_equal(st.sums_mixture_groups_end(), got[[2, 0]])
-    # spike-and-slab entry points refuse a mixture state
+    # error behaviour: the spike-and-slab entry points refuse a mixture state (and the other way round), a row that names no
+    # group, sums before any prep of a fresh state, groups on a mixture wider than the device-resident iteration covers
     with pytest.raises(ValueError):
         st.prep_groups(np.zeros((1, 6)))
+    with pytest.raises(ValueError):
+        st.sums_groups_begin(np.arange(3), 1.0)
+    bad = rows[:1].copy()
+    bad[0, 0] = 3
+    with pytest.raises(ValueError, match="out of range"):
+        st.prep_mixture_groups(bad)
+    ss_state = DeviceState(plan, ftype, "spike_slab")
+    ss_state.set_groups(gs)
+    with pytest.raises(ValueError):
+        ss_state.prep_mixture_groups(np.zeros((1, 7)))
+    fresh = DeviceState(plan, ftype, "mixture", K)
+    fresh.set_groups(gs)
+    with pytest.raises(ValueError, match="have not been called"):
+        fresh.sums_mixture_groups_begin(np.arange(3), 1.0)
+    wide = DeviceState(plan, ftype, "mixture", 10)
+    with pytest.raises(NotImplementedError):
+        wide.set_groups(gs)
