@@ -14,7 +14,8 @@ row of device sums in place of the model's own reduction -- the dtypes and round
 A group's prep and sums are bit-identical to those of a plan of that chromosome alone, so the batch reproduces
 ``{c: VIPRSMix(loader_of_c, K).fit() for c in chromosomes}`` on this device bit for bit.
 
-Results are keyed by chromosome as in ``VIPRSPerChromosome``: ``pi[c]`` / ``tau_beta[c]`` are K-vectors.
+Results are keyed by chromosome as in ``VIPRSPerChromosome``: ``pi[c]`` / ``tau_beta[c]`` are K-vectors, ``history[c]`` and
+``optim_results[c]`` are the chromosome's own.
 """
 import contextlib
 import logging
@@ -23,7 +24,7 @@ import numpy as np
 
 from ..utils.optim import OptimizeResult
 from .VIPRSMix import VIPRSMix
-from .VIPRSPerChromosome import VIPRSPerChromosome
+from .VIPRSPerChromosome import PerChromosomeGroups
 
 logger = logging.getLogger(__name__)
 
@@ -32,7 +33,7 @@ _MODEL_ATTRS = ("pi", "sigma_epsilon", "tau_beta", "_sigma_g", "fix_params", "hi
                 "_max_eta_diff")
 
 
-class VIPRSMixPerChromosome(VIPRSPerChromosome, VIPRSMix):
+class VIPRSMixPerChromosome(PerChromosomeGroups, VIPRSMix):
 
     def __init__(self, gdl, K=1, prior_multipliers=None, lambda_min=None, **kwargs):
         self._cur = None                      # index of the chromosome whose model is swapped in (None: none)
@@ -271,7 +272,7 @@ class VIPRSMixPerChromosome(VIPRSPerChromosome, VIPRSMix):
 
     def get_heritability(self):
         if isinstance(self.pi, dict):
-            return VIPRSPerChromosome.get_heritability(self)
+            return PerChromosomeGroups.get_heritability(self)
         return VIPRSMix.get_heritability(self)
 
     def get_average_effect_size_variance(self):

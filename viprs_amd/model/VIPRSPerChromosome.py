@@ -37,12 +37,15 @@ from .VIPRS import VIPRS, _is_numeric
 logger = logging.getLogger(__name__)
 
 
-class VIPRSPerChromosome(VIPRS):
+class PerChromosomeGroups:
+    """What the per-chromosome batches of every model family share (mixed in FRONT of the model class): the chromosomes as
+    SNP groups of the one device state, their sample sizes / SNP counts / lambda_min, the convergence mask over LD blocks, the
+    per-chromosome result tables."""
 
     _always_merge = True
 
     def __init__(self, gdl, lambda_min=None, **kwargs):
-        """Arguments of ``VIPRS``; ``lambda_min='infer'`` gives every chromosome the value of ITS LD matrix (each of the
+        """Arguments of the model class; ``lambda_min='infer'`` gives every chromosome the value of ITS LD matrix (each of the
         reference's per-chromosome models infers its own, VIPRS.py:186-191)."""
         infer = lambda_min is not None and not _is_numeric(lambda_min)
         super().__init__(gdl, lambda_min=None if infer else lambda_min, **kwargs)
@@ -60,7 +63,7 @@ class VIPRSPerChromosome(VIPRS):
         self._em = None
         if self._e_step_fn is None:
             if not self._merged:
-                raise NotImplementedError("VIPRSPerChromosome runs on the device-resident one-plan layout "
+                raise NotImplementedError(type(self).__name__ + " runs on the device-resident one-plan layout "
                                           "(device_resident=True, merge_chromosomes=True)")
             ds, plan = self._dstate["*"], self._plans["*"]
             sizes = [int(self.shapes.get(c, 0)) for c in self.groups]
@@ -70,6 +73,25 @@ class VIPRSPerChromosome(VIPRS):
             # (`right`: a chromosome without local SNPs shares its start with the next one, which owns the block)
             self._block_group = np.searchsorted(self._group_start, starts[:-1], side="right") - 1
             self._active_mask = None
+
+    def _set_active(self, active_groups):
+        """The chromosomes whose models still iterate: the LD blocks of the others leave the sweep."""
+        if self._e_step_fn is not None:
+            return
+        flags = np.zeros(len(self.groups), dtype=bool)
+        flags[active_groups] = True
+        mask = flags[self._block_group]
+        self._plans["*"].set_active_blocks(None if mask.all() else mask)
+
+    def get_heritability(self):
+        return {c: self._sigma_g[c] / (self._sigma_g[c] + self.sigma_epsilon[c]) for c in self.groups}
+
+    def to_history_table(self):
+        import pandas as pd
+        return pd.concat([pd.DataFrame(h).assign(Chromosome=c) for c, h in self.history.items()])
+
+
+class VIPRSPerChromosome(PerChromosomeGroups, VIPRS):
 
     # ---- per-group scalar context: lets the base class's scalar code run for one chromosome ------------------------
     @contextlib.contextmanager
@@ -115,14 +137,6 @@ class VIPRSPerChromosome(VIPRS):
         self._log_var_tau[c] = np.log(self.var_tau[c])
 
     # ---- one lock-step iteration: E-step of the active groups, their sums ------------------------------------------------
-    def _set_active(self, active_groups):
-        if self._e_step_fn is not None:
-            return
-        flags = np.zeros(len(self.groups), dtype=bool)
-        flags[active_groups] = True
-        mask = flags[self._block_group]
-        self._plans["*"].set_active_blocks(None if mask.all() else mask)
-
     def _sweep(self, a, em):
         if self._e_step_fn is None:
             ds = self._dstate["*"]
@@ -297,9 +311,6 @@ class VIPRSPerChromosome(VIPRS):
 
     objective = elbo
 
-    def get_heritability(self):
-        return {c: self._sigma_g[c] / (self._sigma_g[c] + self.sigma_epsilon[c]) for c in self.groups}
-
     def get_proportion_causal(self):
         return dict(self.pi)
 
@@ -318,7 +329,3 @@ class VIPRSPerChromosome(VIPRS):
                          ("Lambda_min", self._lambda_group[self._gindex[c]]), ("tau_beta", float(self.tau_beta[c]))):
                 rows.append({"Parameter": k, "Value": v, "Chromosome": c})
         return pd.DataFrame(rows)
-
-    def to_history_table(self):
-        import pandas as pd
-        return pd.concat([pd.DataFrame(h).assign(Chromosome=c) for c, h in self.history.items()])
