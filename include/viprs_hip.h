@@ -329,7 +329,9 @@ int viprs_device_synchronize(int device);
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* HIP-event time (ms) of the kernels of the last viprs_state_e_step / viprs_e_step* call on
  * this plan, measured on the stream they were launched on.  `which`: 0 = all kernels of the
- * sweep, 1 = dominant (panel) kernel only.                                                    */
+ * sweep, 1 = dominant (panel) kernel only, 2 = HOST time the library spent between recording that
+ * kernel's start event and recording its end event (the launch call: a start event recorded into
+ * an empty stream is reached at once, so host time spent there counts into the event bracket). */
 int viprs_plan_last_kernel_ms(viprs_plan* plan, int which, double* ms);
 /* Every sweep records its HIP events into a ring of 256 entries.  `timing_reset` forgets them;
  * `timing_history` returns the durations (ms) of the most recent min(capacity, 256, recorded)

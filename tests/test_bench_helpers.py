@@ -334,3 +334,15 @@ def test_bench_under_the_real_torch_launcher(tmp_path):
     assert out["per_rank"]["kernel_ms_avg"] == pytest.approx([0.5, 0.51])
     left = [f for f in os.listdir(tmp_path) if f.startswith("viprs_filecomm") or f.startswith("viprs_comm")]
     assert left == [], left
+
+
+def test_clean_kernel_times_uses_the_host_stamp_not_the_kernel_time():
+    """`bench.clean_kernel_times`: a sweep leaves the mean only on EVIDENCE -- host time stamped inside its event bracket --
+    never because its kernel time is large."""
+    import bench
+    k = [2.0954, 0.6944, 0.6946, 0.7016, 1.9, 0.6925]
+    host = [1.4198, 0.3322, 0.0078, 0.0075, 0.0068, 0.0077]
+    good, bad = bench.clean_kernel_times(k, host)
+    assert bad == [0, 1] and good == [0.6946, 0.7016, 1.9, 0.6925]          # the 1.9 ms sweep has no host time: it stays
+    assert bench.clean_kernel_times(k, []) == (k, [])                        # no stamps (older library): nothing is dropped
+    assert bench.clean_kernel_times([0.7, 0.7], [0.5, 0.6]) == ([0.7, 0.7], [0, 1])      # never an empty mean

@@ -142,15 +142,16 @@ int run_spike_slab(viprs_state* S, double dq) {
             }
             if (rc != VIPRS_OK) { P->pending_start_event = nullptr; return rc; }
             HIP_TRY(hipEventRecord(ev[3], P->stream));
+            P->host_t1[P->sweeps % viprs_plan::kRing] = host_clock_ms();
         }
         if (use_band(P)) rc = launch_band_u(P, A, kBandSpikeSlab);
         else if (!P->ragged_h.empty()) rc = launch_generic_u<float>(P, A, kGenSpikeSlab, false);
     } else {
         // float64 state: the panel kernels specialise float; every block takes the panel-walking kernel of estep_tile.h
         EStepArgs<double> A = make_args<double>(S, dq);
-        if (!P->dense_h.empty()) HIP_TRY(hipEventRecord(ev[2], P->stream));
+        if (!P->dense_h.empty()) { P->host_t0[P->sweeps % viprs_plan::kRing] = host_clock_ms(); HIP_TRY(hipEventRecord(ev[2], P->stream)); }
         rc = launch_tile_f64_u(P, A, kGenSpikeSlab, true);
-        if (rc == VIPRS_OK && !P->dense_h.empty()) HIP_TRY(hipEventRecord(ev[3], P->stream));
+        if (rc == VIPRS_OK && !P->dense_h.empty()) { HIP_TRY(hipEventRecord(ev[3], P->stream)); P->host_t1[P->sweeps % viprs_plan::kRing] = host_clock_ms(); }
         if (rc == VIPRS_OK) rc = launch_tile_f64_u(P, A, kGenSpikeSlab, false);
     }
     if (rc != VIPRS_OK) return rc;
@@ -209,7 +210,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
         // the panel and batched-grid launchers record the start event themselves, adjacent to their (first) kernel launch
         const bool panel_ok0 = S->float_dtype == VIPRS_F32 && !P->dense_h.empty() && (model == kGenGrid || S->width <= kPanelWideMaxK);
         if (panel_ok0) P->pending_start_event = ev[2];
-        else HIP_TRY(hipEventRecord(ev[2], P->stream));
+        else { P->host_t0[P->sweeps % viprs_plan::kRing] = host_clock_ms(); HIP_TRY(hipEventRecord(ev[2], P->stream)); }
     }
     if (S->float_dtype == VIPRS_F32) {
         EStepArgs<float> A = make_args<float>(S, dq);
@@ -249,6 +250,7 @@ int run_generic_model(viprs_state* S, double dq, int model, const int32_t* d_act
     if (rc != VIPRS_OK) { P->pending_start_event = nullptr; return rc; }
     { const int rc2 = record_start_event(P); if (rc2 != VIPRS_OK) return rc2; }      // (never pending here; belt and braces)
     HIP_TRY(hipEventRecord(ev[3], P->stream));
+    P->host_t1[P->sweeps % viprs_plan::kRing] = host_clock_ms();
     P->sweeps++;
     return VIPRS_OK;
 }
@@ -402,6 +404,11 @@ int viprs_e_step_grid(viprs_plan* P, int float_dtype, int G, const void* std_bet
 static int sweep_ms(viprs_plan* P, int64_t sweep, int which, double* ms) {
     hipEvent_t* ev = P->ev.data() + 4 * (sweep % viprs_plan::kRing);
     float t = 0.f;
+    if (which == 2) {           // host time between the record of the dominant kernel's start event and the record of its end event
+        const double d = P->host_t1[sweep % viprs_plan::kRing] - P->host_t0[sweep % viprs_plan::kRing];
+        *ms = d > 0.0 ? d : 0.0;
+        return VIPRS_OK;
+    }
     if (which == 1 || P->ev_dense_only[sweep % viprs_plan::kRing]) {
         if (which == 1 && P->dense_h.empty() && !P->ev_dense_only[sweep % viprs_plan::kRing]) { *ms = 0.0; return VIPRS_OK; }
         HIP_TRY(hipEventSynchronize(ev[3]));

@@ -1,6 +1,7 @@
 // C ABI, part 1 (include/viprs_hip.h): error reporting, device query, the LD plan -- validation, block
 // discovery, upload and re-lay-out of the LD data ("load LD to memory", VIPRS.__init__, VIPRS.py:151-172).
 #include "internal.h"
+#include <chrono>
 
 using namespace viprs;
 
@@ -422,8 +423,12 @@ std::map<int, hipEvent_t> g_gate_event;        // per device: completion of the 
 std::map<int, const viprs_plan*> g_gate_plan;  // ... and the plan whose stream it went to (the same plan again: already
                                                //     ordered by its own stream; forgotten when that plan is destroyed)
 }  // namespace
+double host_clock_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 int record_start_event(viprs_plan* P) {
     if (P->pending_start_event) {
+        P->host_t0[P->sweeps % viprs_plan::kRing] = host_clock_ms();
         HIP_TRY(hipEventRecord(P->pending_start_event, P->stream));
         P->pending_start_event = nullptr;
     }

@@ -143,6 +143,7 @@ struct viprs_plan {
     static constexpr int kRing = 256;
     std::vector<hipEvent_t> ev;             // 4 * kRing
     bool ev_dense_only[kRing] = {};         // ring slot: only [2] .. [3] were recorded (they bracket the whole sweep)
+    double host_t0[kRing] = {}, host_t1[kRing] = {};   // host clock (ms) at the start event's record and behind the end event's: which = 2
     int64_t sweeps = 0;                     // sweeps recorded since the last timing reset
     viprs_state* scratch = nullptr;         // state used by the one-shot host-buffer calls
     // start event of the sweep being enqueued, recorded by the panel / grid launcher IMMEDIATELY in front of its first kernel
@@ -213,6 +214,7 @@ int plan_create_generated(viprs_plan** out, int64_t m, const int32_t* lb, const 
 // same device cannot be ordered from here: the bounded spins report VIPRS_EDEVICE instead of hanging.)
 int ensure_upper_storage(viprs_plan* P, bool mirrored);
 int record_start_event(viprs_plan* P);
+double host_clock_ms();
 int team_launch_gate(viprs_plan* P);
 int team_launch_done(viprs_plan* P);
 
