@@ -585,7 +585,7 @@ def test_kernel_time_does_not_depend_on_the_queue_depth(gpu):
     assert abs(np.median(empty) / full - 1.0) < 0.05, (full, np.median(empty))
     # which = 2: the HOST time the library spent between recording the start event and recording the end event of each sweep
     # (the launch call) -- a sweep whose kernel time is off while this is large was not slow on the device
-    host = np.array(plan.timing_history(which=2))
+    host = np.array(plan.timing_history(which=2))[-40:]                       # (the 40 sweeps into an empty stream)
     assert host.shape == (40,) and (host >= 0).all() and np.median(host) < 0.1, host
     slow = np.array(empty) > 1.5 * np.median(empty)
     assert (host[slow] > 0.1).all(), (np.array(empty)[slow], host[slow])      # every outlier is explained by its host stamp
