@@ -80,3 +80,24 @@ def test_fit_with_rccl_comm_reproduces_the_single_process_fit(comm):
     np.testing.assert_array_equal(a.history["ELBO"], b.history["ELBO"])
     for c in a.chromosomes:
         np.testing.assert_array_equal(a.pip[c], b.pip[c])
+
+
+@pytest.mark.parametrize("family", ["spike_slab", "mixture"])
+def test_per_chromosome_batch_with_rccl_comm(comm, family):
+    """The lock-step batch of per-chromosome models with the groups' sums reduced by the communicator on the plan's stream (one
+    all-gather for all groups: `viprs_state_sums_groups_*` / `viprs_state_sums_mixture_groups_*` with `viprs_state_set_comm`)
+    against the batch without a communicator: the same trajectories, bit for bit at world size 1."""
+    from viprs_amd.data import ArrayDataLoader
+    from viprs_amd.model import VIPRSMixPerChromosome, VIPRSPerChromosome
+    gdl = ArrayDataLoader.synthetic({1: [200, 90, 310], 2: [150, 260], 3: [330]}, seed=23)
+    if family == "mixture":
+        cls, kw, theta = VIPRSMixPerChromosome, {"K": 3}, {"pis": np.array([0.01, 0.005, 0.002]), "sigma_epsilon": 0.85}
+    else:
+        cls, kw, theta = VIPRSPerChromosome, {}, {"pi": 0.02, "sigma_epsilon": 0.85}
+    a = cls(gdl, low_memory=True, **kw).fit(max_iter=15, theta_0=dict(theta))
+    b = cls(gdl, low_memory=True, comm=comm, **kw).fit(max_iter=15, theta_0=dict(theta))
+    assert b._device_reduce
+    for c in a.groups:
+        np.testing.assert_array_equal(a.history[c]["ELBO"], b.history[c]["ELBO"])
+        np.testing.assert_array_equal(a.pip[c], b.pip[c])
+        assert a.optim_results[c].nit == b.optim_results[c].nit
