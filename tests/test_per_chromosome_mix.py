@@ -77,9 +77,11 @@ def check_identical_to_sequential(model, seq):
             assert np.array_equal(getattr(model, name)[c], getattr(one, name)[c]), (c, name)
 
 
-def test_mix_lockstep_fit_cpu_host_logic():
+@pytest.mark.parametrize("host", ["vector", "scalar"])
+def test_mix_lockstep_fit_cpu_host_logic(host):
+    """Both forms of the host side: the array form (`LockstepMixEM`, the default) and `VIPRSMix`'s own scalar code per model."""
     fx = np.load(FXM)
-    model = build(fx).fit(max_iter=100, theta_0=theta_of(fx))
+    model = build(fx, host=host).fit(max_iter=100, theta_0=theta_of(fx))
     check_against_fixture(model, fx)
     check_identical_to_sequential(model, sequential_fits(fx))
     chroms = sorted(int(c) for c in fx["chroms"])
@@ -92,6 +94,38 @@ def test_mix_lockstep_fit_cpu_host_logic():
     # a second fit on the same object starts from scalars again
     again = model.fit(max_iter=100, theta_0=theta_of(fx))
     check_against_fixture(again, fx)
+
+
+@pytest.mark.parametrize("precision", ["float32", "float64"])
+@pytest.mark.parametrize("fix", [{}, {"sigma_epsilon": 0.85}, {"pi": 0.02}, {"tau_beta": 400.0}])
+def test_mix_vector_host_equals_scalar_host(fix, precision):
+    """The array form against the scalar form, `==` on everything a fit returns, with hyper-parameters fixed in the ways that
+    change the DTYPES the serial code computes in (a fixed sigma_epsilon stays a float32 scalar, a fixed scalar tau_beta makes
+    the starting tau vector float32, a fixed overall proportion rescales pi) and tracked parameters."""
+    fx = np.load(FXM)
+    theta = theta_of(fx)
+    if "sigma_epsilon" in fix:
+        theta.pop("sigma_epsilon")
+    from viprs_amd.model import VIPRSMixPerChromosome
+    out = {}
+    for host in ("vector", "scalar"):
+        kw = model_kwargs(fx, host=host, fix_params=dict(fix),
+                          tracked_params=["pi", "heritability", "sigma_epsilon", "tau_beta", "sigma_g", "max_eta_diff"])
+        kw["float_precision"] = precision
+        out[host] = VIPRSMixPerChromosome(loader_from_fixture(fx), **kw).fit(max_iter=25, theta_0=dict(theta))
+    a, b = out["vector"], out["scalar"]
+    for c in a.groups:
+        for key in a.history[c]:
+            x, y = a.history[c][key], b.history[c][key]
+            assert len(x) == len(y) and all(np.array_equal(u, v, equal_nan=True) and np.asarray(u).dtype == np.asarray(v).dtype
+                                            for u, v in zip(x, y)), (c, key)
+        r, r1 = a.optim_results[c], b.optim_results[c]
+        assert (r.nit, r.success, r.message) == (r1.nit, r1.success, r1.message)
+        for name in ("pi", "tau_beta", "sigma_epsilon", "_sigma_g"):
+            u, v = getattr(a, name)[c], getattr(b, name)[c]
+            assert np.array_equal(u, v) and np.asarray(u).dtype == np.asarray(v).dtype, (c, name, u, v)
+        for name in ("pip", "post_mean_beta", "post_var_beta", "q", "var_gamma", "var_mu", "eta", "eta_diff", "var_tau"):
+            assert np.array_equal(getattr(a, name)[c], getattr(b, name)[c]), (c, name)
 
 
 def test_mix_per_chromosome_theta_and_tracked_params():
@@ -123,11 +157,12 @@ def test_mix_negative_mse_restarts_only_that_chromosome():
     ss = dict(gdl.sumstats_table)
     ss[bad] = SumstatsArrays(ss[bad].get_snp_pseudo_corr() * np.float32(6.0), ss[bad].n_per_snp)
     gdl = ArrayDataLoader(gdl.ld, ss)
-    model = VIPRSMixPerChromosome(gdl, **model_kwargs(fx)).fit(max_iter=30, theta_0=theta_of(fx))
     seq = sequential_fits(fx, loader=gdl, max_iter=30)
     assert seq[bad].fix_params.get("sigma_epsilon") == 0.95, "the test input no longer triggers the restart"
-    check_identical_to_sequential(model, seq)
-    assert model.sigma_epsilon[bad] == 0.95
+    for host in ("vector", "scalar"):
+        model = VIPRSMixPerChromosome(gdl, host=host, **model_kwargs(fx)).fit(max_iter=30, theta_0=theta_of(fx))
+        check_identical_to_sequential(model, seq)
+        assert model.sigma_epsilon[bad] == 0.95
 
 
 _WORKER = r"""
