@@ -7,10 +7,14 @@ from its own ``(pi_k, tau_beta_k, sigma_epsilon)``, ONE sweep updates all groups
 ``viprs_state_sums_mixture_groups_*`` returns the 6 + 6 K sums and max |eta_diff| per group, converged chromosomes leave
 the sweep (``viprs_plan_set_active_blocks``).
 
-The host side of an iteration is NOT a vectorised restatement here: each chromosome's model is the scalar code of
-``VIPRSMix`` / ``VIPRS`` itself (``m_step``, ``elbo``, ``mse``, the stopping rules of ``VIPRS._after_e_step``) run with that
-chromosome's hyper-parameters, sample size, SNP count, history and optimisation record swapped in (``_as_model``) and its
-row of device sums in place of the model's own reduction -- the dtypes and roundings are the serial fit's by construction.
+The host side of an iteration exists in two forms that are held `==` (tests/test_per_chromosome_mix.py):
+
+* ``host="scalar"``: each chromosome's model is the scalar code of ``VIPRSMix`` / ``VIPRS`` itself (``m_step``, ``elbo``, ``mse``,
+  the stopping rules of ``VIPRS._after_e_step``) run with that chromosome's hyper-parameters, sample size, SNP count, history
+  and optimisation record swapped in (``_as_model``) and its row of device sums in place of the model's own reduction -- the
+  dtypes and roundings are the serial fit's by construction (~40 us per model and iteration);
+* ``host="vector"`` (default): the same as array operations over the active models (``_lockstep_mix.LockstepMixEM``).
+
 A group's prep and sums are bit-identical to those of a plan of that chromosome alone, so the batch reproduces
 ``{c: VIPRSMix(loader_of_c, K).fit() for c in chromosomes}`` on this device bit for bit.
 
