@@ -4,7 +4,6 @@ per-kernel times of an ITERATION (prep, sweep, sums) rather than of the sweep al
 import os
 import sys
 
-import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench as B                                     # noqa: E402
